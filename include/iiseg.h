@@ -1,0 +1,161 @@
+/*
+ * iiseg.h -- C ABI of libiiseg_hip.so, the MI355X (gfx950) kernel library behind the
+ * iterative-inference hot path of adri-romsor/iterative_inference_segm.
+ *
+ * The reference has no FFI: its device boundary is the four Theano functions compiled at
+ * iterative_inference.py:187-210 (pred_fcn_fn, pred_dae_fn, de_fn, val_fn), whose graphs are
+ * made of the Lasagne layers cited per entry point below.  Each entry point replaces the
+ * Theano op(s) that those layers lower to.
+ *
+ * Conventions:
+ *   - plain C, no torch types; all tensor pointers are DEVICE pointers to C-contiguous NCHW
+ *     float32 unless stated; the caller owns every byte (inputs, outputs, workspaces);
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); it never
+ *     allocates, never synchronises, and is safe to capture into a hipGraph;
+ *   - return value: IISEG_OK (0) or a negative iiseg_status; iiseg_strerror() names it;
+ *   - calls on different streams are thread-safe; one stream = program order.
+ */
+#ifndef IISEG_H
+#define IISEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum iiseg_status {
+    IISEG_OK = 0,
+    IISEG_ERR_NULL = -1,       /* a required pointer is NULL                         */
+    IISEG_ERR_SHAPE = -2,      /* inconsistent / unsupported shape                   */
+    IISEG_ERR_ALIGN = -3,      /* pointer not aligned as the kernel requires         */
+    IISEG_ERR_LAUNCH = -4,     /* hipLaunchKernel / hipGetLastError failed           */
+    IISEG_ERR_UNSUPPORTED = -5 /* valid request, but no kernel variant implements it */
+} iiseg_status;
+
+const char* iiseg_strerror(int status);
+/* ABI version, bumped on any signature change. */
+int iiseg_abi_version(void);
+/* Name of the GPU architecture the library was compiled for ("gfx950"). */
+const char* iiseg_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution (stride 1), fp32 MFMA.
+ * Replaces: Lasagne Conv2DLayer / DilatedConv2DLayer (+ fused Elemwise bias/ReLU), i.e.
+ * Theano CorrMM, at models/fcn8.py:34-85,92-93,102-103; models/fcn_down.py:102-104;
+ * models/fcn_up.py:83-86; models/contextmod_dae.py:74-105.  Fusions: the h-concat of
+ * models/model_helpers.py:93-94 (two sources, h first), DePool2D of layers/mylayers.py:88-115
+ * as an input gather, ElemwiseSumLayer/CroppingLayer of models/fcn_up.py:96-113 as epilogue.
+ * ------------------------------------------------------------------------------------- */
+
+#define IISEG_CONV_RELU 1u   /* out = max(out, 0)                                   */
+#define IISEG_CONV_UNPOOL 2u /* logical input = eq-mask unpool(up=x1, pre, pooled)  */
+
+typedef struct iiseg_conv_desc {
+    /* logical input (after concat / unpool): (B, C1 + C2, H, W) */
+    int32_t B, C1, C2, H, W;
+    /* filter */
+    int32_t Cout, KH, KW, pad, dil;
+    /* logical output is (H + 2*pad - dil*(KH-1), W + 2*pad - dil*(KW-1)); only the window
+     * [oy0, oy0+OH) x [ox0, ox0+OW) is computed and `out` is (B, Cout, OH, OW). */
+    int32_t oy0, ox0, OH, OW;
+    /* optional epilogue add: out += add[b, co, ay0 + oy, ax0 + ox]; add is (B, Cout, AH, AW) */
+    int32_t AH, AW, ay0, ax0;
+    uint32_t flags;
+    /* packed-weight geometry produced by iiseg_conv_pack_f32 */
+    int32_t Kpad, Mpad;
+} iiseg_conv_desc;
+
+/* Number of int32x4 entries of the gather table for `d` (== d->Kpad). */
+int iiseg_conv_ktab_entries(const iiseg_conv_desc* d);
+/* Fills d->Kpad / d->Mpad for the (C1+C2, KH, KW, Cout) of `d`. */
+int iiseg_conv_plan(iiseg_conv_desc* d);
+
+/* Packs reference-layout weights into the kernel layout Wp[Kpad][Mpad] (k = (c*KH+ky)*KW+kx)
+ * and builds the gather table.  `w` element (o, c, ky, kx) is read at
+ * w[o*stride_o + c*stride_c + ky*KW + kx], which covers Conv2DLayer W[out,in,kh,kw]
+ * (stride_o = Cin*KH*KW, stride_c = KH*KW) and DilatedConv2DLayer W[in,out,kh,kw]
+ * (stride_o = KH*KW, stride_c = Cout*KH*KW; P11).  wp: Kpad*Mpad floats; ktab: Kpad*4 int32. */
+int iiseg_conv_pack_f32(void* stream, const iiseg_conv_desc* d, const float* w,
+                        int64_t stride_o, int64_t stride_c, float* wp, int32_t* ktab);
+
+/* out = epilogue(conv(input)).  x2 may be NULL when C2 == 0.  With IISEG_CONV_UNPOOL:
+ * x1 = up (B, C1, H/2, W/2), pre (B, C1, H, W), pooled (B, C1, H/2, W/2), C2 must be 0.
+ * bias (Cout) and add may be NULL. */
+int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                   const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
+                   const float* bias, const float* add, float* out);
+
+/* ---------------------------------------------------------------------------------------
+ * 2x2/2 max-pool, ignore_border (floor).  Replaces Pool2DLayer(x, 2): models/fcn8.py:38-72,
+ * models/fcn_down.py:122.   x (B,C,H,W) -> out (B,C,H/2,W/2)
+ * ------------------------------------------------------------------------------------- */
+int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC, int32_t H,
+                         int32_t W);
+
+/* Equality-mask unpool, materialised (the fused form is IISEG_CONV_UNPOOL).  Replaces
+ * DePool2D.get_output_for, layers/mylayers.py:88-115:
+ * out[y,x] = (y < 2h && x < 2w && pre[y,x] == pooled[y/2,x/2]) ? up[y/2,x/2] : 0 */
+int iiseg_unpool_eqmask_f32(void* stream, const float* up, const float* pre,
+                            const float* pooled, float* out, int32_t BC, int32_t H, int32_t W);
+
+/* ---------------------------------------------------------------------------------------
+ * Small-channel transposed convolution (gather form), crop='valid', linear.
+ * Replaces Deconv2DLayer (Theano CorrMM_gradInputs): models/fcn8.py:90,100,109;
+ * models/fcn_up.py:41-45.  w is the reference layout W[Cin][Cout][K][K]; the kernel applies
+ * the spatial flip of Lasagne's filter_flip=True gradient form.
+ * Only the window [oy0,oy0+OH) x [ox0,ox0+OW) of the (H-1)*s+K output is produced.
+ * Optional: out += add[b, c, ay0+oy, ax0+ox] (add is (B,Cout,AH,AW)); Cout <= 16.
+ * ------------------------------------------------------------------------------------- */
+typedef struct iiseg_deconv_desc {
+    int32_t B, Cin, H, W, Cout, K, stride;
+    int32_t oy0, ox0, OH, OW;
+    int32_t AH, AW, ay0, ax0;
+} iiseg_deconv_desc;
+
+int iiseg_deconv_f32(void* stream, const iiseg_deconv_desc* d, const float* x, const float* w,
+                     const float* bias, const float* add, float* out);
+
+/* ---------------------------------------------------------------------------------------
+ * Channel softmax of a center-cropped score map.  Replaces the crop + dimshuffle + reshape +
+ * softmax + reshape + dimshuffle tail of models/fcn8.py:115-130,187-191 and
+ * models/fcn_up.py:104-113,154-169.   score (B,C,SH,SW) -> out (B,C,H,W), window at (sy0,sx0),
+ * C <= 32.  If `minuend` (B,C,H,W) is non-NULL the result is minuend - softmax, which is
+ * de_fn's  -(pred_dae - y_hat)  of iterative_inference.py:203-204.
+ * ------------------------------------------------------------------------------------- */
+int iiseg_crop_softmax_f32(void* stream, const float* score, const float* minuend, float* out,
+                           int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0,
+                           int32_t sx0, int32_t H, int32_t W);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused refinement step.  Replaces, per image, iterative_inference.py:203-204 (de = y - r),
+ * :270 (y - step*de), :273 (clip) and the per-pixel part of :275 (||de||_2 over channels):
+ *   r = softmax_c(score[window]); de = y - r; if active[b]: y = clip(y - step*de, 0, 1)
+ *   partial[b][blk] = sum over the block's pixels of ||de||_2
+ * y (B,C,H,W) is updated in place; active (B) int32; partial (B, nblk) float64 where
+ * nblk = iiseg_refine_partials(H, W).
+ * iiseg_refine_finalize then applies :275-277 per image: norm = sum(partial[b])/(H*W);
+ * if active[b]: iters[b] += 1; if norm < eps: active[b] = 0   (update first, then test).
+ * ------------------------------------------------------------------------------------- */
+int iiseg_refine_partials(int32_t H, int32_t W);
+int iiseg_refine_update_f32(void* stream, const float* score, float* y, const int32_t* active,
+                            double* partial, int32_t B, int32_t C, int32_t SH, int32_t SW,
+                            int32_t sy0, int32_t sx0, int32_t H, int32_t W, float step);
+int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, int32_t* iters,
+                          double* last_norm, int32_t B, int32_t nblk, int32_t HW, double eps);
+
+/* ---------------------------------------------------------------------------------------
+ * Metrics accumulator.  Replaces val_fn, iterative_inference.py:206-210 = metrics.py:11-37
+ * (jaccard), :40-65 (accuracy), :144-156 (squared_error, int-void branch):
+ *   cm[i*(C+1) + j] += #(argmax_c y == i  and  argmax_c t == j), i < C, j <= C (j == C: void)
+ *   sums[0] += sum_px mask * mean_c (y - t[:C])^2 ;  sums[1] += sum_px mask, mask = sum_c t[:C]
+ * y (B,C,H,W), t one-hot (B,C+1,H,W) with void last.  cm: C*(C+1) int64, sums: 2 float64,
+ * both ACCUMULATED into (zero them first); C <= 31.
+ * ------------------------------------------------------------------------------------- */
+int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm, double* sums,
+                        int32_t B, int32_t C, int32_t HW);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IISEG_H */

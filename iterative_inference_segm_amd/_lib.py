@@ -1,0 +1,81 @@
+"""ctypes binding of libiiseg_hip.so (the C ABI of include/iiseg.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing a
+compute path raises.  The product never routes through the CPU oracle.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
+
+ABI_VERSION = 1
+
+CONV_RELU = 1
+CONV_UNPOOL = 2
+
+
+class ConvDesc(C.Structure):
+    """struct iiseg_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in
+                ('B', 'C1', 'C2', 'H', 'W', 'Cout', 'KH', 'KW', 'pad', 'dil',
+                 'oy0', 'ox0', 'OH', 'OW', 'AH', 'AW', 'ay0', 'ax0')] + \
+               [('flags', C.c_uint32), ('Kpad', C.c_int32), ('Mpad', C.c_int32)]
+
+
+class DeconvDesc(C.Structure):
+    """struct iiseg_deconv_desc"""
+    _fields_ = [(n, C.c_int32) for n in
+                ('B', 'Cin', 'H', 'W', 'Cout', 'K', 'stride', 'oy0', 'ox0', 'OH', 'OW',
+                 'AH', 'AW', 'ay0', 'ax0')]
+
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); mirrors include/iiseg.h one to one
+SIGNATURES = {
+    'iiseg_strerror': (C.c_char_p, [C.c_int]),
+    'iiseg_abi_version': (C.c_int, []),
+    'iiseg_target_arch': (C.c_char_p, []),
+    'iiseg_conv_ktab_entries': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_plan': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_pack_f32': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp, _vp]),
+    'iiseg_conv_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
+    'iiseg_maxpool2x2_f32': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    'iiseg_unpool_eqmask_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]),
+    'iiseg_deconv_f32': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),
+    'iiseg_crop_softmax_f32': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8),
+    'iiseg_refine_partials': (C.c_int, [_i32, _i32]),
+    'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
+    'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
+    'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'libiiseg_hip.so is missing (%s). Build it with '
+            '`python -m iterative_inference_segm_amd.build`; there is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.iiseg_abi_version() != ABI_VERSION:
+        raise RuntimeError('libiiseg_hip.so ABI %d != binding ABI %d; rebuild'
+                           % (lib.iiseg_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().iiseg_strerror(status).decode()
+        raise RuntimeError('%s failed: %s (iiseg_status %d)' % (what, msg, status))

@@ -1,0 +1,112 @@
+"""The compiled-function level of the reference (iterative_inference.py:187-210) on MI355X:
+
+    pred_fcn_fn(X)        -> [H_1..H_k, Y]          (:188)
+    pred_dae_fn(H..., Y)  -> R                      (:190)
+    de_fn(H..., Y)        -> Y - R                  (:204)
+    val_fn(Y, T)          -> [acc, jacc(2,C), mse]  (:210)
+
+plus `refine(H, Y, step, num_iter)` which replaces the per-image numpy loop of :258-284 with a
+batched device loop that keeps the reference's per-image semantics (per-image early stop,
+update applied before the test).  Arguments and results are device tensors
+(C-contiguous NCHW float32): no host round trip per call.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+EPSILON = 1e-3  # iterative_inference.py:53
+
+
+class Metrics:
+    """Result of one val_fn call kept on the device: confusion counts (C x (C+1), prediction x
+    truth with the void column last) and [sum mask*mse_px, sum mask]."""
+
+    def __init__(self, n_classes, device):
+        self.C = n_classes
+        self.cm = torch.zeros(n_classes * (n_classes + 1), dtype=torch.int64, device=device)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=device)
+
+    @staticmethod
+    def reduce_host(cm, sums, n_classes):
+        """(acc, jacc(2,C), mse) from raw accumulators, as metrics.py:11-65,144-156 define them."""
+        C = n_classes
+        cm = np.asarray(cm, dtype=np.float64).reshape(C, C + 1)
+        nonvoid = cm[:, :C]
+        tp = np.diag(nonvoid)
+        denom = nonvoid.sum(1) + nonvoid.sum(0) - tp      # TP + FP + FN  (metrics.py:30-35)
+        jacc = np.stack([tp, denom], axis=0)
+        total = nonvoid.sum()
+        acc = float(tp.sum() / total) if total > 0 else float('nan')   # void-masked (:52-63)
+        mse = float(sums[0] / sums[1]) if sums[1] > 0 else float('nan')  # (:153-154)
+        return acc, jacc, mse
+
+    def result(self):
+        return Metrics.reduce_host(self.cm.cpu().numpy(), self.sums.cpu().numpy(), self.C)
+
+
+class IterativeInference:
+    """Bundles a segmentation net and a DAE and exposes the reference's four functions."""
+
+    def __init__(self, fcn, dae, n_classes, void_labels=(11,), device='cuda'):
+        self.fcn, self.dae = fcn, dae
+        self.n_classes = n_classes
+        self.void_labels = list(void_labels)
+        # the metrics kernel implements the one-hot/void-last contract of the reference's
+        # datasets: void == n_classes (iterative_inference.py:125)
+        if self.void_labels and self.void_labels != [n_classes]:
+            raise NotImplementedError('void_labels must be [] or [n_classes]')
+        self.device = device
+
+    # ---- reference function level -------------------------------------------------------
+    def pred_fcn_fn(self, X):
+        return self.fcn(self._dev(X))
+
+    def pred_dae_fn(self, *args):
+        return self.dae(*[self._dev(a) for a in args])
+
+    def de_fn(self, *args):
+        return self.dae.residual(*[self._dev(a) for a in args])
+
+    def val_fn(self, Y, T):
+        """[acc, jacc, mse] on the host (synchronises); use `val_device` inside loops."""
+        acc, jacc, mse = self.val_device(Y, T).result()
+        return [acc, jacc, mse]
+
+    def val_device(self, Y, T):
+        m = Metrics(self.n_classes, self.device)
+        ops.confusion_accumulate(self._dev(Y), self._dev(T), m.cm, m.sums)
+        return m
+
+    # ---- fused loop ---------------------------------------------------------------------
+    def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False):
+        """Batched replacement of iterative_inference.py:258-284.
+
+        for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
+                                    y = clip(y - step*(y - softmax(score)), 0, 1)  # :270-273
+                                    per image: stop once mean_px ||de||_2 < eps     # :275-277
+        Returns (Y_ii, iters_used[B] int32, last_norm[B] float64), all on the device.
+        """
+        H = [self._dev(h) for h in (H if isinstance(H, (list, tuple)) else [H])]
+        y = self._dev(Y)
+        if not inplace:
+            y = y.clone()
+        B, _, Hh, Ww = y.shape
+        st = ops.RefineState(B, Hh, Ww, y.device)
+        eps_eff = eps if early_stop else -1.0
+        for _ in range(int(num_iter)):
+            score = self.dae.scores(H, y)
+            ops.refine_update(score, y, st, step, off=(0, 0))
+            ops.refine_finalize(st, eps_eff)
+        return y, st.iters, st.last_norm
+
+    def _dev(self, a):
+        if isinstance(a, torch.Tensor):
+            t = a
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a))
+        if t.dtype != torch.float32:
+            t = t.to(torch.float32)
+        if not t.is_cuda:
+            t = t.to(self.device, non_blocking=True)
+        return t.contiguous()

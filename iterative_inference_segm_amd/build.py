@@ -1,0 +1,65 @@
+"""In-tree build of libiiseg_hip.so (hipcc, gfx950 only).
+
+`python -m iterative_inference_segm_amd.build` or `__graft_entry__.build()`.  hipcc
+cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+LIB = os.path.join(HERE, 'libiiseg_hip.so')
+SOURCES = ['abi.hip', 'conv_igemm.hip', 'pool_unpool.hip', 'deconv.hip', 'tail.hip', 'metrics.hip']
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libiiseg_hip.so.  Returns the path."""
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'iiseg.h')]
+    flags = ['-O3', '--offload-arch=' + ARCH, '-fPIC', '-std=c++17', '-I' + INCLUDE, '-I' + CSRC,
+             '-Wall', '-Wno-unused-function']
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + flags + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr))
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n' + r.stderr)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

@@ -1,0 +1,368 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4), fp32 in / fp32 accumulate on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32, a k-ordered fmaf chain per output element).
+//
+// GEMM view:  D[co][p] = sum_k Wp[k][co] * X[k][p],  k = (c, ky, kx),  p = (b, oy, ox).
+// Output channels are the MFMA row index and pixels the column index, so that one accumulator
+// register of a wave covers 32 consecutive pixels of one channel: 128-byte NCHW stores.
+//
+// X is never materialised: each workgroup gathers its [BK][BN] slice straight from the NCHW
+// activation(s) through a per-layer table (one int4 per k: element offset, dy, dx, channel /
+// source id), which makes kernel size, padding, dilation, the two-source h-concat and the
+// equality-mask unpool (DePool2D) properties of the gather, not of the kernel.
+//
+// Replaces Theano CorrMM behind Lasagne Conv2DLayer (reference models/fcn8.py:34-85,
+// models/fcn_down.py:102-104, models/fcn_up.py:83-86); see include/iiseg.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "iiseg.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;  // k-tile depth: 8 MFMA k-steps
+
+struct ConvParams {
+    const float* x1;
+    const float* x2;
+    const float* pre;
+    const float* pooled;
+    const float* wp;
+    const int4* ktab;
+    const float* bias;
+    const float* add;
+    float* out;
+    int B, C1, C2, H, W;
+    int h2, w2;  // pooled dims (unpool mode)
+    int Cout, OH, OW, oy0, ox0;
+    int AH, AW, ay0, ax0;
+    int Kpad, Mpad;
+    int P;            // B*OH*OW
+    int n_ptiles, n_mtiles;
+    int relu;
+};
+
+// Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give
+// each XCD a contiguous run of tiles and, inside a run, walk groups of 8 pixel-tiles x all
+// channel-tiles so that co-resident blocks of one XCD share both X rows and W rows in its L2.
+__device__ inline void tile_of_block(int bid, int nblocks, int n_p, int n_m, int& pt, int& mt) {
+    const int q = nblocks / 8, r = nblocks % 8;
+    const int xcd = bid % 8, l = bid / 8;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + l;
+    constexpr int GP = 8;
+    const int gsize = GP * n_m;
+    const int g = v / gsize, rr = v % gsize;
+    const int gp = min(GP, n_p - g * GP);
+    pt = g * GP + rr % gp;
+    mt = rr / gp;
+}
+
+template <int BM, int BN, int WM, int WN, bool UNPOOL>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile (channels x pixels)
+    constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+    constexpr int RG = 256 / BN;                 // gather row groups
+    constexpr int XROWS = BK / RG;               // gathered elements per thread per k-tile
+    constexpr int WVEC = BK * BM / 4;            // float4 per weight tile
+    constexpr int WPT = (WVEC + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(BN >= 64 && 256 % BN == 0, "row group must be wave-uniform");
+
+    __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Xs[2][BK][BN];
+
+    int pt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
+    const int p0 = pt * BN, m0 = mt * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int OHW = p.OH * p.OW, HW = p.H * p.W;
+
+    // ---- gather setup: this thread's pixel and row group ------------------------------
+    const int lp = tid % BN;
+    const int rg = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int pg = p0 + lp;
+    const bool pvalid = pg < p.P;
+    int gb = 0, goy = 0, gox = 0;
+    if (pvalid) {
+        gb = pg / OHW;
+        const int rem = pg - gb * OHW;
+        goy = rem / p.OW;
+        gox = rem - goy * p.OW;
+    }
+    goy += p.oy0;
+    gox += p.ox0;
+    const int pixoff = goy * p.W + gox;  // may address outside the image; guarded per tap
+    const float* xb1;
+    const float* xb2 = nullptr;
+    const float* preb = nullptr;
+    const float* poolb = nullptr;
+    if constexpr (UNPOOL) {
+        const size_t hw2 = (size_t)p.h2 * p.w2;
+        xb1 = p.x1 + (size_t)gb * p.C1 * hw2;      // up
+        poolb = p.pooled + (size_t)gb * p.C1 * hw2;
+        preb = p.pre + (size_t)gb * p.C1 * HW;
+    } else {
+        xb1 = p.x1 + (size_t)gb * p.C1 * HW;
+        xb2 = p.x2 ? p.x2 + (size_t)gb * p.C2 * HW : p.x1;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float xv[XROWS];
+    float xq[UNPOOL ? XROWS : 1];  // pooled value (unpool mode)
+    float xu[UNPOOL ? XROWS : 1];  // up value
+    float4 wv[WPT];
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < XROWS; ++j) {
+            const int krow = rg + RG * j;
+            const int4 e = p.ktab[kt * BK + krow];  // wave-uniform -> scalar load
+            const int iy = goy + e.y, ix = gox + e.z;
+            bool ok = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            if constexpr (UNPOOL) {
+                // DePool2D (layers/mylayers.py:95-114): value of up where pre == pooled, inside
+                // the 2h x 2w region covered by pooling windows
+                ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+                const int offp = (e.w & 0xFFFFFF) * (p.h2 * p.w2) + (iy >> 1) * p.w2 + (ix >> 1);
+                xv[j] = ok ? preb[pixoff + e.x] : 0.f;
+                xq[j] = ok ? poolb[offp] : 1.f;
+                xu[j] = ok ? xb1[offp] : 0.f;
+            } else {
+                const float* src = (e.w >> 30) ? xb2 : xb1;
+                xv[j] = ok ? src[pixoff + e.x] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int idx = tid + 256 * j;
+            if (WVEC % 256 == 0 || idx < WVEC) {
+                const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+                wv[j] = *reinterpret_cast<const float4*>(
+                    p.wp + (size_t)(kt * BK + row) * p.Mpad + m0 + c4 * 4);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XROWS; ++j) {
+            float v = xv[j];
+            if constexpr (UNPOOL) v = (xv[j] == xq[j]) ? xu[j] : 0.f;
+            Xs[buf][rg + RG * j][lp] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int idx = tid + 256 * j;
+            if (WVEC % 256 == 0 || idx < WVEC) {
+                const int row = idx / (BM / 4), c4 = idx % (BM / 4);
+                *reinterpret_cast<float4*>(&Ws[buf][row][c4 * 4]) = wv[j];
+            }
+        }
+    };
+
+    const int nkt = p.Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = ks * 2 + lh;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ws[buf][kk][wm * WTM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Xs[buf][kk][wn * WTN + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, skip add, ReLU, NCHW store ------------------------------------
+    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pe = p0 + wn * WTN + j * 32 + l31;
+        if (pe >= p.P) continue;
+        const int eb = pe / OHW;
+        const int rem = pe - eb * OHW;
+        float* outp = p.out + (size_t)eb * p.Cout * OHW + rem;
+        const float* addp = nullptr;
+        size_t AHW = 0;
+        if (p.add) {
+            const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
+            AHW = (size_t)p.AH * p.AW;
+            addp = p.add + (size_t)eb * p.Cout * AHW + (size_t)(p.ay0 + eoy) * p.AW + p.ax0 + eox;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[co];
+                    if (addp) v += addp[(size_t)co * AHW];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    outp[(size_t)co * OHW] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ void conv_pack_kernel(const float* __restrict__ w, int64_t so, int64_t sc, float* wp,
+                                 int4* ktab, int C1, int C2, int KH, int KW, int pad, int dil,
+                                 int H, int W, int Cout, int K, int Kpad, int Mpad) {
+    const int64_t n = (int64_t)Kpad * Mpad;
+    const int KK = KH * KW;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i / Mpad), m = (int)(i % Mpad);
+        float v = 0.f;
+        if (k < K && m < Cout) {
+            const int c = k / KK, r = k % KK;
+            v = w[m * so + c * sc + r];
+        }
+        wp[i] = v;
+        if (m == 0) {
+            int4 e;
+            if (k < K) {
+                const int c = k / KK, r = k % KK;
+                const int ky = r / KW, kx = r % KW;
+                const int dy = ky * dil - pad, dx = kx * dil - pad;
+                const int src = c >= C1 ? 1 : 0;
+                const int cl = src ? c - C1 : c;
+                e.x = cl * H * W + dy * W + dx;
+                e.y = dy;
+                e.z = dx;
+                e.w = cl | (src << 30);
+            } else {  // padded k: always out of bounds -> contributes 0
+                e.x = 0;
+                e.y = -(1 << 24);
+                e.z = 0;
+                e.w = 0;
+            }
+            ktab[k] = e;
+        }
+    }
+}
+
+int pick_bm(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+}  // namespace
+
+extern "C" int iiseg_conv_plan(iiseg_conv_desc* d) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->C1 <= 0 || d->C2 < 0) return IISEG_ERR_SHAPE;
+    const int K = (d->C1 + d->C2) * d->KH * d->KW;
+    const int bm = pick_bm(d->Cout);
+    d->Kpad = (K + BK - 1) / BK * BK;
+    d->Mpad = (d->Cout + bm - 1) / bm * bm;
+    return IISEG_OK;
+}
+
+extern "C" int iiseg_conv_ktab_entries(const iiseg_conv_desc* d) { return d ? d->Kpad : IISEG_ERR_NULL; }
+
+static int check_desc(const iiseg_conv_desc* d) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
+        d->KH <= 0 || d->KW <= 0 || d->pad < 0 || d->dil <= 0 || d->OH <= 0 || d->OW <= 0 ||
+        d->oy0 < 0 || d->ox0 < 0)
+        return IISEG_ERR_SHAPE;
+    const int fullH = d->H + 2 * d->pad - d->dil * (d->KH - 1);
+    const int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
+    if (fullH <= 0 || fullW <= 0 || d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW)
+        return IISEG_ERR_SHAPE;
+    const int K = (d->C1 + d->C2) * d->KH * d->KW;
+    const int bm = pick_bm(d->Cout);
+    if (d->Kpad != (K + BK - 1) / BK * BK || d->Mpad != (d->Cout + bm - 1) / bm * bm)
+        return IISEG_ERR_SHAPE;
+    // int32 index ranges used by the kernel
+    if ((int64_t)d->B * d->OH * d->OW >= (1ll << 31) - 512) return IISEG_ERR_SHAPE;
+    if ((int64_t)(d->C1 > d->C2 ? d->C1 : d->C2) * d->H * d->W >= (1ll << 30)) return IISEG_ERR_SHAPE;
+    if (d->C1 >= (1 << 24) || d->C2 >= (1 << 24)) return IISEG_ERR_SHAPE;
+    return IISEG_OK;
+}
+
+extern "C" int iiseg_conv_pack_f32(void* stream, const iiseg_conv_desc* d, const float* w,
+                                   int64_t stride_o, int64_t stride_c, float* wp, int32_t* ktab) {
+    int st = check_desc(d);
+    if (st) return st;
+    if (!w || !wp || !ktab) return IISEG_ERR_NULL;
+    if (((uintptr_t)wp & 15) || ((uintptr_t)ktab & 15)) return IISEG_ERR_ALIGN;
+    const int K = (d->C1 + d->C2) * d->KH * d->KW;
+    const int64_t n = (int64_t)d->Kpad * d->Mpad;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
+                       stride_c, wp, reinterpret_cast<int4*>(ktab), d->C1, d->C2, d->KH, d->KW,
+                       d->pad, d->dil, d->H, d->W, d->Cout, K, d->Kpad, d->Mpad);
+    return iiseg_check_launch();
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv(hipStream_t s, const ConvParams& cp, bool unpool) {
+    ConvParams p = cp;
+    p.n_ptiles = (p.P + BN - 1) / BN;
+    p.n_mtiles = p.Mpad / BM;
+    const int grid = p.n_ptiles * p.n_mtiles;
+    if (unpool)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(256), 0, s, p);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
+                              const float* x2, const float* pre, const float* pooled,
+                              const float* wp, const int32_t* ktab, const float* bias,
+                              const float* add, float* out) {
+    int st = check_desc(d);
+    if (st) return st;
+    if (!x1 || !wp || !ktab || !out) return IISEG_ERR_NULL;
+    if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    if (((uintptr_t)wp & 15) || ((uintptr_t)ktab & 15)) return IISEG_ERR_ALIGN;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if (unpool && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
+    if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
+        return IISEG_ERR_SHAPE;
+
+    ConvParams p;
+    p.x1 = x1; p.x2 = x2; p.pre = pre; p.pooled = pooled; p.wp = wp;
+    p.ktab = reinterpret_cast<const int4*>(ktab);
+    p.bias = bias; p.add = add; p.out = out;
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    p.Kpad = d->Kpad; p.Mpad = d->Mpad;
+    p.P = d->B * d->OH * d->OW;
+    p.n_ptiles = p.n_mtiles = 0;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+
+    hipStream_t s = (hipStream_t)stream;
+    switch (pick_bm(d->Cout)) {
+        case 128: return launch_conv<128, 128, 2, 2>(s, p, unpool);
+        case 64: return launch_conv<64, 256, 1, 4>(s, p, unpool);
+        default: return launch_conv<32, 256, 1, 4>(s, p, unpool);
+    }
+}

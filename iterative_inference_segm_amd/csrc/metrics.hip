@@ -1,0 +1,70 @@
+// Metrics accumulator: argmax confusion matrix (prediction x truth incl. void column) and the
+// void-masked squared error, one pixel per thread, LDS-binned counts, one global atomic per
+// bin per block.  Integer counts are exact and order-independent.
+// Replaces val_fn (reference iterative_inference.py:206-210): metrics.py:11-37 (jaccard's 121
+// masked reductions), :40-65 (accuracy), :144-156 (squared_error).
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 32;
+
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ y,
+                                                        const float* __restrict__ t,
+                                                        unsigned long long* __restrict__ cm,
+                                                        double* __restrict__ sums, int C, int HW) {
+    __shared__ unsigned int bins[MAXC * (MAXC + 1)];
+    __shared__ double red[2][4];
+    const int nb = C * (C + 1);
+    for (int i = threadIdx.x; i < nb; i += 256) bins[i] = 0;
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    double se = 0.0, mk = 0.0;
+    if (pix < HW) {
+        const float* yp = y + (size_t)b * C * HW + pix;
+        const float* tp = t + (size_t)b * (C + 1) * HW + pix;
+        // argmax returns the FIRST maximal index (T.argmax / np.argmax)
+        int ip = 0, it = 0;
+        float bp = yp[0], bt = tp[0];
+        float msum = 0.f, esum = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float yv = yp[(size_t)c * HW], tv = tp[(size_t)c * HW];
+            if (yv > bp) { bp = yv; ip = c; }
+            if (tv > bt) { bt = tv; it = c; }
+            msum += tv;                       // mask = y_true[:, :void].sum(1)   metrics.py:148
+            esum = fmaf(yv - tv, yv - tv, esum);
+        }
+        const float tvoid = tp[(size_t)C * HW];
+        if (tvoid > bt) it = C;
+        atomicAdd(&bins[ip * (C + 1) + it], 1u);
+        se = (double)(esum / (float)C) * (double)msum;  // .mean(axis=1) * mask   :147,153
+        mk = (double)msum;
+    }
+    se = wave_sum(se);
+    mk = wave_sum(mk);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = se;
+        red[1][threadIdx.x >> 6] = mk;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (bins[i]) atomicAdd(&cm[i], (unsigned long long)bins[i]);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        atomicAdd(&sums[1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
+}  // namespace
+
+extern "C" int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm,
+                                   double* sums, int32_t B, int32_t C, int32_t HW) {
+    if (!y || !t || !cm || !sums) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
+    if (C >= MAXC || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(confusion_kernel, dim3((HW + 255) / 256, B), dim3(256), 0,
+                       (hipStream_t)stream, y, t, reinterpret_cast<unsigned long long*>(cm), sums,
+                       C, HW);
+    return iiseg_check_launch();
+}

@@ -1,0 +1,71 @@
+// 2x2 max-pool (ignore_border) and the materialised equality-mask unpool.  HBM-bound
+// element-wise kernels: one output element per thread-iteration, lanes along x.
+// Replaces Pool2DLayer (reference models/fcn8.py:38-72, models/fcn_down.py:122) and
+// DePool2D.get_output_for (layers/mylayers.py:88-115); see include/iiseg.h.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x,
+                                                         float* __restrict__ out, int BC, int H,
+                                                         int W, int h, int w) {
+    const size_t n = (size_t)BC * h * w;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % w);
+        const size_t t = i / w;
+        const int oy = (int)(t % h);
+        const size_t bc = t / h;
+        const float* r0 = x + (bc * H + 2 * oy) * (size_t)W + 2 * ox;
+        const float* r1 = r0 + W;
+        out[i] = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r1[0], r1[1]));
+    }
+}
+
+__global__ __launch_bounds__(256) void unpool_eqmask_kernel(const float* __restrict__ up,
+                                                            const float* __restrict__ pre,
+                                                            const float* __restrict__ pooled,
+                                                            float* __restrict__ out, int BC,
+                                                            int H, int W, int h, int w) {
+    const size_t n = (size_t)BC * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t t = i / W;
+        const int y = (int)(t % H);
+        const size_t bc = t / H;
+        float v = 0.f;
+        if (y < 2 * h && x < 2 * w) {
+            const size_t j = (bc * h + (y >> 1)) * (size_t)w + (x >> 1);
+            v = (pre[i] == pooled[j]) ? up[j] : 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+inline int grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC,
+                                    int32_t H, int32_t W) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
+    const int h = H / 2, w = W / 2;
+    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for((size_t)BC * h * w)), dim3(256), 0,
+                       (hipStream_t)stream, x, out, BC, H, W, h, w);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_unpool_eqmask_f32(void* stream, const float* up, const float* pre,
+                                       const float* pooled, float* out, int32_t BC, int32_t H,
+                                       int32_t W) {
+    if (!up || !pre || !pooled || !out) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(unpool_eqmask_kernel, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
+                       (hipStream_t)stream, up, pre, pooled, out, BC, H, W, H / 2, W / 2);
+    return iiseg_check_launch();
+}

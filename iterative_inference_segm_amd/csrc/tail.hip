@@ -1,0 +1,157 @@
+// Channel-softmax tail kernels: crop + softmax (network outputs) and the fused refinement
+// step  r = softmax(score); de = y - r; y <- clip(y - step*de, 0, 1); sum ||de||_2.
+// HBM-bound: one pixel per thread, lanes along x, the C (<= 32) channel values of a pixel
+// live in registers; per-image norms are reduced wave -> block -> fixed-order finalize, so the
+// early-stop decision is deterministic (no float atomics).
+// Replaces: models/fcn8.py:115-130,187-191 and models/fcn_up.py:104-113,154-169 (crop +
+// softmax); iterative_inference.py:203-204,270-277 (update, clip, norm, early stop).
+#include "common.h"
+
+namespace {
+
+template <int CMAX>
+__device__ inline void load_softmax(const float* sp, size_t cstride, int C, float (&r)[CMAX]) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            r[c] = sp[(size_t)c * cstride];
+            m = fmaxf(m, r[c]);
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            r[c] = expf(r[c] - m);
+            s += r[c];
+        }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) r[c] *= inv;
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void crop_softmax_kernel(const float* __restrict__ score,
+                                                           const float* __restrict__ minuend,
+                                                           float* __restrict__ out, int C, int SH,
+                                                           int SW, int sy0, int sx0, int H, int W) {
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix - y * W;
+    const size_t SHW = (size_t)SH * SW;
+    const float* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+    float r[CMAX];
+    load_softmax<CMAX>(sp, SHW, C, r);
+    float* op = out + (size_t)b * C * HW + pix;
+    const float* mp = minuend ? minuend + (size_t)b * C * HW + pix : nullptr;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) op[(size_t)c * HW] = mp ? mp[(size_t)c * HW] - r[c] : r[c];
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void refine_update_kernel(const float* __restrict__ score,
+                                                            float* __restrict__ yio,
+                                                            const int* __restrict__ active,
+                                                            double* __restrict__ partial, int C,
+                                                            int SH, int SW, int sy0, int sx0, int H,
+                                                            int W, float step) {
+    __shared__ double red[4];
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const bool act = active[b] != 0;
+    float nrm = 0.f;
+    if (pix < HW) {
+        const int y = pix / W, x = pix - y * W;
+        const size_t SHW = (size_t)SH * SW;
+        const float* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+        float r[CMAX];
+        load_softmax<CMAX>(sp, SHW, C, r);
+        float* yp = yio + (size_t)b * C * HW + pix;
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) {
+                const float yv = yp[(size_t)c * HW];
+                const float de = yv - r[c];  // iterative_inference.py:203-204
+                ss = fmaf(de, de, ss);
+                if (act) {
+                    float yn = yv - step * de;  // :270
+                    yn = fminf(fmaxf(yn, 0.f), 1.f);  // :273
+                    yp[(size_t)c * HW] = yn;
+                }
+            }
+        nrm = sqrtf(ss);  // np.linalg.norm(grad, axis=1), :275
+    }
+    double d = wave_sum((double)nrm);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void refine_finalize_kernel(const double* __restrict__ partial, int* active, int* iters,
+                                       double* last_norm, int B, int nblk, int HW, double eps) {
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+        if (!active[b]) continue;
+        double s = 0.0;
+        for (int i = 0; i < nblk; ++i) s += partial[(size_t)b * nblk + i];
+        const double norm = s / (double)HW;  // .mean() over pixels, :275
+        iters[b] += 1;
+        last_norm[b] = norm;
+        if (norm < eps) active[b] = 0;  // :276-277, after the update was applied
+    }
+}
+
+}  // namespace
+
+extern "C" int iiseg_crop_softmax_f32(void* stream, const float* score, const float* minuend,
+                                      float* out, int32_t B, int32_t C, int32_t SH, int32_t SW,
+                                      int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+    if (!score || !out) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
+        return IISEG_ERR_SHAPE;
+    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    const dim3 grid((H * W + 255) / 256, B);
+    if (C <= 16)
+        hipLaunchKernelGGL(crop_softmax_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, score,
+                           minuend, out, C, SH, SW, sy0, sx0, H, W);
+    else
+        hipLaunchKernelGGL(crop_softmax_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, score,
+                           minuend, out, C, SH, SW, sy0, sx0, H, W);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_refine_partials(int32_t H, int32_t W) { return (H * W + 255) / 256; }
+
+extern "C" int iiseg_refine_update_f32(void* stream, const float* score, float* y,
+                                       const int32_t* active, double* partial, int32_t B, int32_t C,
+                                       int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
+                                       int32_t W, float step) {
+    if (!score || !y || !active || !partial) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
+        return IISEG_ERR_SHAPE;
+    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    const dim3 grid((H * W + 255) / 256, B);
+    if (C <= 16)
+        hipLaunchKernelGGL(refine_update_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, score,
+                           y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+    else
+        hipLaunchKernelGGL(refine_update_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, score,
+                           y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active,
+                                     int32_t* iters, double* last_norm, int32_t B, int32_t nblk,
+                                     int32_t HW, double eps) {
+    if (!partial || !active || !iters || !last_norm) return IISEG_ERR_NULL;
+    if (B <= 0 || nblk <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(refine_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0,
+                       (hipStream_t)stream, partial, active, iters, last_norm, B, nblk, HW, eps);
+    return iiseg_check_launch();
+}

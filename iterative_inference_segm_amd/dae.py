@@ -1,0 +1,165 @@
+"""Standard conditional DAE  r(y | h)  on the HIP kernels (mirror of reference
+models/DAE_h.py:12-63, models/fcn_down.py:9-138, models/fcn_up.py:11-172).
+
+The layer plan is static per (B, H, W): every launch is a fused kernel --
+  encoder level p :  conv3x3 (+bias +ReLU; two-source gather where h is concatenated) , maxpool
+  decoder level p :  conv3x3 whose input gather IS the DePool2D equality-mask unpool, with the
+                     skip sum (ElemwiseSumLayer) and the final center crop fused in the epilogue
+so the unpooled tensors, the concatenated tensor and the cropped score are never materialised.
+"""
+import torch
+
+from . import ops
+from .weights import load_param_list
+
+
+def _n_pool(concat_h, additional_pool):
+    n = int(concat_h[-1][-1]) if 'pool' in concat_h[-1] else 0   # DAE_h.py:37-40
+    return n, n + additional_pool
+
+
+def param_order(concat_h=('pool4',), conv_before_pool=1, additional_pool=2,
+                unpool_type='trackind'):
+    """get_all_param_values order of dae_model_best.npz, bn=0."""
+    _, total = _n_pool(list(concat_h), additional_pool)
+    names = ['conv%d_%d' % (p + 1, i) for p in range(total)
+             for i in range(1, conv_before_pool + 1)]
+    names += [('up%d' if unpool_type == 'standard' else 'up_conv%d') % p
+              for p in range(total, 0, -1)]
+    return names
+
+
+def _center(big, small):
+    return (big - small) // 2
+
+
+class StandardDAE:
+    """Callable with (h_1..h_k, y) like the compiled pred_dae_fn (iterative_inference.py:189-190)."""
+
+    def __init__(self, params, n_classes, concat_h=('pool4',), padding=100, n_filters=64,
+                 conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind', bn=0,
+                 device='cuda'):
+        concat_h = list(concat_h)
+        assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
+                   for el in concat_h)                                   # fcn_down.py:39-41
+        if concat_h[-1] == 'input' and additional_pool == 0:
+            raise ValueError('It seems your DAE will have no conv/pooling layers!')  # :71-72
+        if unpool_type not in ('standard', 'trackind', 'inverse'):
+            raise ValueError('Unkown unpool type')                       # fcn_up.py:114-115
+        if unpool_type == 'standard':
+            raise NotImplementedError("unpool_type='standard' (many-channel 4x4/2 transposed "
+                                      "conv) has no HIP kernel yet")
+        if bn:
+            raise NotImplementedError('bn=1 DAE has no HIP kernel yet')
+        self.concat_h, self.padding, self.skip = concat_h, padding, skip
+        self.conv_before_pool = conv_before_pool
+        self.n_classes = n_classes
+        self.n_pool, self.total = _n_pool(concat_h, additional_pool)
+        self.device = device
+        self.enc, self.dec = {}, {}
+        for p in range(self.total):
+            for i in range(1, conv_before_pool + 1):
+                # pad-100 rule of fcn_down.py:90-94
+                first_pad = (p == 0 and i == 1 and len(concat_h) == 1 and concat_h[-1] != 'input'
+                             and padding > 0)
+                name = 'conv%d_%d' % (p + 1, i)
+                self.enc[name] = ops.Conv(params[name][0], params[name][1],
+                                          pad=padding if first_pad else 1, relu=True,
+                                          device=device)                 # :102-104
+        for p in range(self.total, 0, -1):
+            name = 'up_conv%d' % p
+            self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
+                                      device=device)                     # fcn_up.py:83-86
+        self.conv_log = None
+
+    def conv_layers(self):
+        d = dict(self.enc)
+        d.update(self.dec)
+        return d
+
+    def scores(self, h_list, y):
+        """Runs the DAE up to the pre-softmax score map already cropped to y's size
+        (fused_up1 of fcn_up.py:104-113).  Returns score (B, n_classes, H, W)."""
+        h_list = list(h_list)
+        if len(h_list) != len(self.concat_h):
+            raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
+        pos = 0
+        pending_h = None
+        if self.concat_h[pos] == 'input':                # model_helpers.py:86-94 at the input
+            pending_h, pos = h_list[pos], pos + 1
+        t = y
+        pre, pool = {}, {0: y}
+        for p in range(self.total):                      # fcn_down.py:77-136
+            for i in range(1, self.conv_before_pool + 1):
+                name = 'conv%d_%d' % (p + 1, i)
+                conv = self.enc[name]
+                if pending_h is not None:                # h first, then features (P13)
+                    t = conv(pending_h, x2=t)
+                    pending_h = None
+                else:
+                    t = conv(t)
+                self._count(name, conv, t)
+            pre[p + 1] = t
+            pool[p + 1] = t = ops.maxpool2x2(t)          # :122
+            if p < self.n_pool and pos < len(self.concat_h) and \
+                    self.concat_h[pos] == 'pool%d' % (p + 1):   # :131-134
+                pending_h, pos = h_list[pos], pos + 1
+        if pending_h is not None:
+            raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
+                                      '(additional_pool=0); not shape-consistent in the reference')
+        for p in range(self.total, 0, -1):               # fcn_up.py:143-151, UnpoolNet
+            name = 'up_conv%d' % p
+            conv = self.dec[name]
+            ph, pw = pre[p].shape[2], pre[p].shape[3]    # up_conv 'same' keeps the pre-pool size
+            other = pool[p - 1]                          # pre-concat pool (or the input for p=1)
+            oh, ow = min(ph, other.shape[2]), min(pw, other.shape[3])
+            window = (_center(ph, oh), _center(pw, ow), oh, ow)
+            if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
+                t = conv(t, pre=pre[p], pooled=pool[p], add=other,
+                         add_off=(_center(other.shape[2], oh), _center(other.shape[3], ow)),
+                         window=window)
+            else:                                        # :104-113 CroppingLayer
+                t = conv(t, pre=pre[p], pooled=pool[p], window=window)
+            self._count(name, conv, t, full=(ph, pw))
+        return t
+
+    def _count(self, name, conv, out, full=None):
+        # (name, nominal FLOPs of the FULL layer output, FLOPs of the computed window)
+        if self.conv_log is not None:
+            oh, ow = full if full is not None else (out.shape[2], out.shape[3])
+            self.conv_log.append((name, conv.flops(out.shape[0], oh, ow),
+                                  conv.flops(out.shape[0], out.shape[2], out.shape[3])))
+
+    def __call__(self, *args):
+        """pred_dae_fn(h..., y) -> r  (softmax output, models/fcn_up.py:154-169)."""
+        h_list, y = args[:-1], args[-1]
+        score = self.scores(h_list, y)
+        return ops.crop_softmax(score, score.shape[2], score.shape[3], off=(0, 0))
+
+    def residual(self, *args):
+        """de_fn(h..., y) = -(r - y) = y - r  (iterative_inference.py:203-204)."""
+        h_list, y = args[:-1], args[-1]
+        score = self.scores(h_list, y)
+        return ops.crop_softmax(score, score.shape[2], score.shape[3], off=(0, 0), minuend=y)
+
+
+def buildDAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
+             nb_features_to_concat=None, padding=100, ae_h=False, void_labels=(),
+             path_weights=None, model_name='dae_model.npz', trainable=False, load_weights=False,
+             out_nonlin='softmax', concat_h=('input',), noise=0.1, n_filters=64,
+             conv_before_pool=1, additional_pool=0, dropout=0., skip=False,
+             unpool_type='standard', bn=0, params=None, device='cuda'):
+    """Mirror of models/DAE_h.py:12-20.  Inference only: `noise`, `dropout` are identities at
+    deterministic=True (P8, P9; masks are the deterministic ones); the symbolic
+    `input_*_var`, `trainable`, `ae_h`, `void_labels` are accepted and ignored."""
+    import os
+    if params is None:
+        if not (load_weights and path_weights):
+            raise ValueError('buildDAE needs `params` or `path_weights`')
+        order = param_order(concat_h, conv_before_pool, additional_pool, unpool_type)
+        params = load_param_list(os.path.join(path_weights, model_name), order)  # DAE_h.py:52-57
+    if out_nonlin not in ('softmax',):
+        raise NotImplementedError('inference uses out_nonlin=softmax (iterative_inference.py:158)')
+    return StandardDAE(params, n_classes, concat_h=concat_h, padding=padding, n_filters=n_filters,
+                       conv_before_pool=conv_before_pool, additional_pool=additional_pool,
+                       skip=skip, unpool_type=unpool_type, bn=bn, device=device)

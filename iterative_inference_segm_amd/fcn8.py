@@ -1,0 +1,119 @@
+"""FCN-8s segmentation network on the HIP kernels (mirror of reference models/fcn8.py).
+
+`buildFCN8(...)` keeps the reference's argument names (models/fcn8.py:16-23) where they make
+sense without Theano: there is no symbolic `input_var`; the returned object is called with
+the image batch and returns `[net[el] for el in layer]` (models/fcn8.py:200), i.e. it plays
+the role of the compiled `pred_fcn_fn` (iterative_inference.py:187-188).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .weights import load_param_list
+
+PARAM_ORDER = ['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2', 'conv3_3',
+               'conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3',
+               'fc6', 'fc7', 'score_fr', 'score2', 'score_pool4', 'score4', 'score_pool3',
+               'upsample']  # lasagne get_all_param_values order
+
+_BLOCKS = [('conv1_1', 'conv1_2'), ('conv2_1', 'conv2_2'), ('conv3_1', 'conv3_2', 'conv3_3'),
+           ('conv4_1', 'conv4_2', 'conv4_3'), ('conv5_1', 'conv5_2', 'conv5_3')]
+
+
+def _center(big, small):
+    return (big - small) // 2  # lasagne autocrop 'center' (P6)
+
+
+class FCN8:
+    def __init__(self, params, n_classes, layer=('probs_dimshuffle',), pad=100, temperature=1.0,
+                 device='cuda'):
+        self.layer = list(layer)
+        self.n_classes = n_classes
+        self.pad = pad
+        self.device = device
+        p = params
+        c = lambda name, pad_, relu=True: ops.Conv(p[name][0], p[name][1], pad=pad_, relu=relu,
+                                                   device=device)
+        self.convs = {}
+        for bi, names in enumerate(_BLOCKS):
+            for ni, name in enumerate(names):
+                # models/fcn8.py:34-35: pad=100 on conv1_1, 'same' elsewhere
+                self.convs[name] = c(name, pad if (bi == 0 and ni == 0) else 1)
+        self.convs['fc6'] = c('fc6', 0)            # :75-76 7x7 valid, default ReLU
+        self.convs['fc7'] = c('fc7', 0)            # :80-81
+        self.convs['score_fr'] = c('score_fr', 0)  # :84-85 default nonlinearity = ReLU (P2)
+        self.convs['score_pool4'] = c('score_pool4', 0)  # :92-93 1x1, ReLU (P2)
+        self.convs['score_pool3'] = c('score_pool3', 0)  # :102-103
+        self.score2 = ops.Deconv(p['score2'][0], p['score2'][1], 2, device=device)    # :90-91
+        self.score4 = ops.Deconv(p['score4'][0], p['score4'][1], 2, device=device)    # :100-101
+        Wu, bu = p['upsample']
+        # temperature divides upsample.W and upsample.b (:194-198)
+        self.upsample = ops.Deconv(np.asarray(Wu) / temperature, np.asarray(bu) / temperature, 8,
+                                   device=device)                                      # :109-110
+        self.conv_log = None  # optional list collecting (name, flops) per conv launch
+
+    def conv_layers(self):
+        return self.convs
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    def forward(self, x):
+        net = {'input': x}
+        t = x
+        for bi, names in enumerate(_BLOCKS):
+            for name in names:
+                t = self._conv(name, t)
+            net['pool%d' % (bi + 1)] = t = ops.maxpool2x2(t)     # :38,45,54,63,72
+        t = self._conv('fc6', t)       # dropout = identity at deterministic=True (P8)
+        t = self._conv('fc7', t)
+        t = self._conv('score_fr', t)
+        # score_fused = score2 + score_pool4, both center-cropped to the common size (:94-97)
+        t = self._deconv_sum(self.score2, t, 'score_pool4', net['pool4'])
+        # score_final = score4 + score_pool3 (:104-107)
+        t = self._deconv_sum(self.score4, t, 'score_pool3', net['pool3'])
+        # upsample, cropped to the input (:109-119); only the needed window is computed
+        H, W = x.shape[2], x.shape[3]
+        uh, uw = self.upsample.out_hw(t.shape[2], t.shape[3])
+        oh, ow = min(uh, H), min(uw, W)
+        score = self.upsample(t, window=(_center(uh, oh), _center(uw, ow), oh, ow))
+        net['score'] = score
+        net['probs_dimshuffle'] = ops.crop_softmax(score, oh, ow, off=(0, 0))  # :122-130,187-191
+        return [net[el] for el in self.layer]
+
+    def _conv(self, name, t, **kw):
+        conv = self.convs[name]
+        out = conv(t, **kw)
+        if self.conv_log is not None:
+            # (name, nominal FLOPs of the full layer, FLOPs of the computed window)
+            fh, fw = conv.out_hw(t.shape[2], t.shape[3])
+            self.conv_log.append((name, conv.flops(out.shape[0], fh, fw),
+                                  conv.flops(out.shape[0], out.shape[2], out.shape[3])))
+        return out
+
+    def _deconv_sum(self, deconv, t, score_name, pool):
+        dh, dw = deconv.out_hw(t.shape[2], t.shape[3])
+        sh, sw = pool.shape[2], pool.shape[3]          # 1x1 'valid'/'same' conv keeps the size
+        oh, ow = min(dh, sh), min(dw, sw)
+        side = self._conv(score_name, pool, window=(_center(sh, oh), _center(sw, ow), oh, ow))
+        return deconv(t, add=side, window=(_center(dh, oh), _center(dw, ow), oh, ow))
+
+
+def buildFCN8(nb_in_channels, input_var=None, path_weights=None, n_classes=21, load_weights=True,
+              void_labels=(), trainable=False, layer=('probs_dimshuffle',), pascal=False,
+              temperature=1.0, dropout=0.5, params=None, pad=100, device='cuda'):
+    """Mirror of models/fcn8.py:16-23.  Weights come from `params` (dict name -> (W, b)) or from
+    an `arr_%d` .npz at `path_weights` in get_all_param_values order (:178-180).  `input_var`,
+    `trainable`, `dropout` are accepted for signature compatibility (inference only: dropout is
+    the identity, P8).  pascal .mat import (:134-176) is not supported."""
+    if pascal:
+        raise NotImplementedError('pascal .mat weights are not supported')
+    if params is None:
+        if not (load_weights and path_weights):
+            raise ValueError('buildFCN8 needs `params` or `path_weights`')
+        params = load_param_list(path_weights, PARAM_ORDER)
+    w0 = params['conv1_1'][0]
+    if w0.shape[1] != nb_in_channels:
+        raise ValueError('conv1_1 expects %d input channels, nb_in_channels=%d'
+                         % (w0.shape[1], nb_in_channels))
+    return FCN8(params, n_classes, layer=layer, pad=pad, temperature=temperature, device=device)

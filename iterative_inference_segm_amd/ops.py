@@ -1,0 +1,240 @@
+"""Operator layer: torch tensors in, HIP kernels of libiiseg_hip.so out.
+
+torch is plumbing here (device memory + the current HIP stream); every arithmetic op is a
+call through the C ABI (include/iiseg.h).  All ops enqueue on torch's current stream and
+never synchronise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('iiseg ops need device tensors (got %s)' % t.device)
+    if t.dtype != dtype:
+        raise RuntimeError('expected %s, got %s' % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError('iiseg ops need C-contiguous NCHW tensors')
+    return C.c_void_p(t.data_ptr())
+
+
+class Conv:
+    """One convolution layer bound to its weights: packed-weight + gather-table cache per
+    input geometry.  Weight layouts: 'oihw' (Lasagne Conv2DLayer W[out,in,kh,kw], P1) or
+    'iohw' (DilatedConv2DLayer W[in,out,kh,kw], P11)."""
+
+    def __init__(self, W, b, pad, relu, dil=1, layout='oihw', device='cuda'):
+        self.lib = _lib.load()
+        self.W = torch.as_tensor(W, dtype=torch.float32).contiguous().to(device)
+        self.b = None if b is None else torch.as_tensor(b, dtype=torch.float32).contiguous().to(device)
+        if layout == 'oihw':
+            self.Cout, self.Cin, self.KH, self.KW = self.W.shape
+            self.so, self.sc = self.Cin * self.KH * self.KW, self.KH * self.KW
+        elif layout == 'iohw':
+            self.Cin, self.Cout, self.KH, self.KW = self.W.shape
+            self.so, self.sc = self.KH * self.KW, self.Cout * self.KH * self.KW
+        else:
+            raise ValueError(layout)
+        self.pad, self.dil, self.relu = int(pad), int(dil), bool(relu)
+        self._plans = {}
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.pad - self.dil * (self.KH - 1),
+                W + 2 * self.pad - self.dil * (self.KW - 1))
+
+    def flops(self, B, OH, OW):
+        """Nominal 2*Cin*Cout*k*k*OH*OW*B (SURVEY 6.2 convention)."""
+        return 2.0 * self.Cin * self.Cout * self.KH * self.KW * OH * OW * B
+
+    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool):
+        key = (B, C1, C2, H, W, window, add_geom, unpool)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        if C1 + C2 != self.Cin:
+            raise RuntimeError('conv expects %d input channels, got %d+%d' % (self.Cin, C1, C2))
+        fullH, fullW = self.out_hw(H, W)
+        oy0, ox0, OH, OW = window if window is not None else (0, 0, fullH, fullW)
+        d = ConvDesc()
+        d.B, d.C1, d.C2, d.H, d.W = B, C1, C2, H, W
+        d.Cout, d.KH, d.KW, d.pad, d.dil = self.Cout, self.KH, self.KW, self.pad, self.dil
+        d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
+        if add_geom is not None:
+            d.AH, d.AW, d.ay0, d.ax0 = add_geom
+        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0)
+        check(self.lib.iiseg_conv_plan(C.byref(d)), 'iiseg_conv_plan')
+        # weights depend on (C1, C2) only through the table; share one packed copy per Mpad
+        wp = torch.empty(d.Kpad * d.Mpad, dtype=torch.float32, device=self.W.device)
+        ktab = torch.empty(d.Kpad * 4, dtype=torch.int32, device=self.W.device)
+        check(self.lib.iiseg_conv_pack_f32(_stream(), C.byref(d), _ptr(self.W), self.so, self.sc,
+                                           _ptr(wp), _ptr(ktab, torch.int32)),
+              'iiseg_conv_pack_f32')
+        plan = (d, wp, ktab)
+        self._plans[key] = plan
+        return plan
+
+    def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
+                 window=None, out=None):
+        """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
+        the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
+        `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
+        `window` = (oy0, ox0, OH, OW) restricts the computed output region."""
+        unpool = pre is not None
+        B, C1 = x1.shape[0], x1.shape[1]
+        if unpool:
+            H, W = pre.shape[2], pre.shape[3]
+            if pooled.shape != x1.shape or pre.shape[:2] != x1.shape[:2] or \
+                    (H // 2, W // 2) != tuple(x1.shape[2:]):
+                raise RuntimeError('unpool shapes: up %s pre %s pooled %s'
+                                   % (tuple(x1.shape), tuple(pre.shape), tuple(pooled.shape)))
+        else:
+            H, W = x1.shape[2], x1.shape[3]
+        C2 = 0
+        if x2 is not None:
+            if x2.shape[0] != B or tuple(x2.shape[2:]) != (H, W):
+                raise RuntimeError('concat shapes %s vs %s' % (tuple(x1.shape), tuple(x2.shape)))
+            C2 = x2.shape[1]
+        add_geom = None
+        if add is not None:
+            add_geom = (add.shape[2], add.shape[3], add_off[0], add_off[1])
+            if add.shape[0] != B or add.shape[1] != self.Cout:
+                raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
+        d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool)
+        if out is None:
+            out = torch.empty((B, self.Cout, d.OH, d.OW), dtype=torch.float32, device=x1.device)
+        elif tuple(out.shape) != (B, self.Cout, d.OH, d.OW):
+            raise RuntimeError('out shape %s != %s' % (tuple(out.shape), (B, self.Cout, d.OH, d.OW)))
+        check(self.lib.iiseg_conv_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
+                                      _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
+                                      _ptr(self.b), _ptr(add), _ptr(out)), 'iiseg_conv_f32')
+        return out
+
+
+class Deconv:
+    """Small-channel transposed convolution (Lasagne Deconv2DLayer W[in,out,k,k], P3)."""
+
+    def __init__(self, W, b, stride, device='cuda'):
+        self.lib = _lib.load()
+        self.W = torch.as_tensor(W, dtype=torch.float32).contiguous().to(device)
+        self.b = None if b is None else torch.as_tensor(b, dtype=torch.float32).contiguous().to(device)
+        self.Cin, self.Cout, self.K, k2 = self.W.shape
+        if k2 != self.K:
+            raise RuntimeError('square kernels only')
+        self.stride = int(stride)
+
+    def out_hw(self, H, W):
+        return (H - 1) * self.stride + self.K, (W - 1) * self.stride + self.K
+
+    def __call__(self, x, add=None, add_off=(0, 0), window=None, out=None):
+        B, Cin, H, W = x.shape
+        if Cin != self.Cin:
+            raise RuntimeError('deconv expects %d channels, got %d' % (self.Cin, Cin))
+        fullH, fullW = self.out_hw(H, W)
+        oy0, ox0, OH, OW = window if window is not None else (0, 0, fullH, fullW)
+        d = DeconvDesc()
+        d.B, d.Cin, d.H, d.W, d.Cout, d.K, d.stride = B, Cin, H, W, self.Cout, self.K, self.stride
+        d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
+        if add is not None:
+            d.AH, d.AW, d.ay0, d.ax0 = add.shape[2], add.shape[3], add_off[0], add_off[1]
+            if add.shape[0] != B or add.shape[1] != self.Cout:
+                raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
+        if out is None:
+            out = torch.empty((B, self.Cout, OH, OW), dtype=torch.float32, device=x.device)
+        check(self.lib.iiseg_deconv_f32(_stream(), C.byref(d), _ptr(x), _ptr(self.W), _ptr(self.b),
+                                        _ptr(add), _ptr(out)), 'iiseg_deconv_f32')
+        return out
+
+
+def maxpool2x2(x, out=None):
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    check(_lib.load().iiseg_maxpool2x2_f32(_stream(), _ptr(x), _ptr(out), B * Cc, H, W),
+          'iiseg_maxpool2x2_f32')
+    return out
+
+
+def unpool_eqmask(up, pre, pooled, out=None):
+    B, Cc, H, W = pre.shape
+    if tuple(up.shape) != (B, Cc, H // 2, W // 2) or up.shape != pooled.shape:
+        raise RuntimeError('unpool shapes: up %s pre %s pooled %s'
+                           % (tuple(up.shape), tuple(pre.shape), tuple(pooled.shape)))
+    if out is None:
+        out = torch.empty_like(pre)
+    check(_lib.load().iiseg_unpool_eqmask_f32(_stream(), _ptr(up), _ptr(pre), _ptr(pooled),
+                                              _ptr(out), B * Cc, H, W), 'iiseg_unpool_eqmask_f32')
+    return out
+
+
+def crop_softmax(score, H, W, off=None, out=None, minuend=None):
+    """softmax over channels of the (H,W) window of score; `off` defaults to the center crop
+    offset (dim - target)//2 (P6).  With `minuend` returns minuend - softmax (de_fn)."""
+    B, Cc, SH, SW = score.shape
+    sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
+    if out is None:
+        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=score.device)
+    check(_lib.load().iiseg_crop_softmax_f32(_stream(), _ptr(score), _ptr(minuend), _ptr(out), B, Cc, SH, SW,
+                                             sy0, sx0, H, W), 'iiseg_crop_softmax_f32')
+    return out
+
+
+class RefineState:
+    """Device-side state of the batched refinement loop: per-image active flag, iteration
+    count, last norm and the per-block norm partials (reference loop state of
+    iterative_inference.py:258-284 for a whole batch)."""
+
+    def __init__(self, B, H, W, device):
+        lib = _lib.load()
+        self.B, self.H, self.W = B, H, W
+        self.nblk = lib.iiseg_refine_partials(H, W)
+        self.active = torch.ones(B, dtype=torch.int32, device=device)
+        self.iters = torch.zeros(B, dtype=torch.int32, device=device)
+        self.last_norm = torch.zeros(B, dtype=torch.float64, device=device)
+        self.partial = torch.zeros(B * self.nblk, dtype=torch.float64, device=device)
+
+    def reset(self):
+        self.active.fill_(1)
+        self.iters.zero_()
+        self.last_norm.zero_()
+
+
+def refine_update(score, y, state, step, off=None):
+    """One fused refinement step on y (in place) from the DAE's pre-softmax score map."""
+    B, Cc, SH, SW = score.shape
+    H, W = y.shape[2], y.shape[3]
+    sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
+    lib = _lib.load()
+    check(lib.iiseg_refine_update_f32(_stream(), _ptr(score), _ptr(y),
+                                      _ptr(state.active, torch.int32),
+                                      _ptr(state.partial, torch.float64), B, Cc, SH, SW, sy0, sx0,
+                                      H, W, float(step)), 'iiseg_refine_update_f32')
+
+
+def refine_finalize(state, eps):
+    lib = _lib.load()
+    check(lib.iiseg_refine_finalize(_stream(), _ptr(state.partial, torch.float64),
+                                    _ptr(state.active, torch.int32),
+                                    _ptr(state.iters, torch.int32),
+                                    _ptr(state.last_norm, torch.float64), state.B, state.nblk,
+                                    state.H * state.W, float(eps)), 'iiseg_refine_finalize')
+
+
+def confusion_accumulate(y, t, cm, sums):
+    """cm (C*(C+1)) int64 and sums (2) float64 are accumulated in place."""
+    B, Cc, H, W = y.shape
+    if tuple(t.shape) != (B, Cc + 1, H, W):
+        raise RuntimeError('target must be one-hot (B,C+1,H,W) with void last, got %s'
+                           % (tuple(t.shape),))
+    check(_lib.load().iiseg_confusion_f32(_stream(), _ptr(y), _ptr(t), _ptr(cm, torch.int64),
+                                          _ptr(sums, torch.float64), B, Cc, H * W),
+          'iiseg_confusion_f32')

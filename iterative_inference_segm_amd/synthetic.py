@@ -1,0 +1,138 @@
+"""Seeded synthetic weights, images and labels (no datasets / checkpoints are reachable).
+
+Shapes and value ranges follow the reference's data contract: images float32 RGB in [0,1]
+(`return_0_255=False`, iterative_inference.py:117-118), labels one-hot with the void channel
+LAST (`void = n_classes`, iterative_inference.py:122-125,234).  Weights use the reference's
+parameter layouts (Lasagne Conv2DLayer W[out,in,kh,kw]; Deconv2DLayer W[in,out,kh,kw]) so a
+real `arr_%d` checkpoint can replace them (see weights.py).
+"""
+import numpy as np
+
+FCN8_CONVS = [  # name, cin, cout, k   (models/fcn8.py:34-85)
+    ('conv1_1', None, 64, 3), ('conv1_2', 64, 64, 3),
+    ('conv2_1', 64, 128, 3), ('conv2_2', 128, 128, 3),
+    ('conv3_1', 128, 256, 3), ('conv3_2', 256, 256, 3), ('conv3_3', 256, 256, 3),
+    ('conv4_1', 256, 512, 3), ('conv4_2', 512, 512, 3), ('conv4_3', 512, 512, 3),
+    ('conv5_1', 512, 512, 3), ('conv5_2', 512, 512, 3), ('conv5_3', 512, 512, 3),
+]
+
+
+def _he_uniform(rng, shape, fan_in):
+    bound = np.sqrt(6.0 / fan_in)
+    return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+
+def _bias(rng, n):
+    # small positive biases so ReLU zeros / pooling ties are exercised but units stay alive
+    return rng.uniform(0.0, 0.1, size=(n,)).astype(np.float32)
+
+
+def bilinear_kernel(k):
+    """The usual FCN bilinear upsampling filter of size k (symmetric)."""
+    f = (k + 1) // 2
+    c = f - 1 if k % 2 == 1 else f - 0.5
+    og = np.ogrid[:k, :k]
+    return ((1 - abs(og[0] - c) / f) * (1 - abs(og[1] - c) / f)).astype(np.float32)
+
+
+def _deconv(rng, cin, cout, k, jitter):
+    """Per-class bilinear filter plus a seeded asymmetric perturbation (so that the P3
+    flip convention is observable in parity tests)."""
+    W = np.zeros((cin, cout, k, k), dtype=np.float32)
+    for c in range(min(cin, cout)):
+        W[c, c] = bilinear_kernel(k)
+    if jitter > 0:
+        W += rng.uniform(-jitter, jitter, size=W.shape).astype(np.float32)
+    return W
+
+
+def make_fcn8_params(nb_in_channels=3, n_classes=11, seed=1234, width_div=1, fc_channels=4096,
+                     deconv_jitter=0.02):
+    """FCN-8s parameters (models/fcn8.py:30-110).  `width_div` / `fc_channels` shrink the net
+    for fast tests (width_div=1, fc_channels=4096 is the real architecture)."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    cprev = nb_in_channels
+    for name, _, cout, k in FCN8_CONVS:
+        cout = max(cout // width_div, 4)
+        p[name] = (_he_uniform(rng, (cout, cprev, k, k), cprev * k * k), _bias(rng, cout))
+        cprev = cout
+    c3 = p['conv3_3'][0].shape[0]
+    c4 = p['conv4_3'][0].shape[0]
+    p['fc6'] = (_he_uniform(rng, (fc_channels, cprev, 7, 7), cprev * 49), _bias(rng, fc_channels))
+    p['fc7'] = (_he_uniform(rng, (fc_channels, fc_channels, 1, 1), fc_channels),
+                _bias(rng, fc_channels))
+    p['score_fr'] = (_he_uniform(rng, (n_classes, fc_channels, 1, 1), fc_channels),
+                     _bias(rng, n_classes))
+    p['score2'] = (_deconv(rng, n_classes, n_classes, 4, deconv_jitter), _bias(rng, n_classes))
+    p['score_pool4'] = (_he_uniform(rng, (n_classes, c4, 1, 1), c4), _bias(rng, n_classes))
+    p['score4'] = (_deconv(rng, n_classes, n_classes, 4, deconv_jitter), _bias(rng, n_classes))
+    p['score_pool3'] = (_he_uniform(rng, (n_classes, c3, 1, 1), c3), _bias(rng, n_classes))
+    p['upsample'] = (_deconv(rng, n_classes, n_classes, 16, deconv_jitter),
+                     _bias(rng, n_classes))
+    return p
+
+
+def make_dae_params(n_classes=11, h_channels=(512,), concat_h=('pool4',), n_filters=64,
+                    conv_before_pool=1, additional_pool=2, unpool_type='trackind', seed=4321,
+                    out_gain=4.0):
+    """Standard-DAE parameters (models/fcn_down.py:77-136, models/fcn_up.py:26-86).
+
+    Channel bookkeeping mirrors the builders: encoder conv p has n_filters*2^min(p,5) filters
+    (fcn_down.py:98-99); h is concatenated (h first) after `pool k` for each name in concat_h
+    (:131-134) or at the input; decoder up_conv p outputs the channels of conv p-1
+    (fcn_up.py:33-34), n_classes for p == 1 (:30-31).  `out_gain` scales up_conv1 so the
+    random-weight reconstruction is not a flat softmax.
+    """
+    rng = np.random.default_rng(seed)
+    concat_h = list(concat_h)
+    n_pool = int(concat_h[-1][-1]) if 'pool' in concat_h[-1] else 0
+    total = n_pool + additional_pool
+    hch = dict(zip(concat_h, h_channels))
+    p = {}
+    cprev = n_classes + hch.get('input', 0)
+    enc_out = []
+    for lvl in range(total):
+        f = n_filters * (2 ** min(lvl, 5))
+        for i in range(1, conv_before_pool + 1):
+            p['conv%d_%d' % (lvl + 1, i)] = (_he_uniform(rng, (f, cprev, 3, 3), cprev * 9),
+                                             _bias(rng, f))
+            cprev = f
+        enc_out.append(f)
+        if lvl < n_pool:
+            cprev += hch.get('pool%d' % (lvl + 1), 0)
+    # decoder input of level `total` is the (possibly concatenated) last pool
+    cin = cprev
+    for lvl in range(total, 0, -1):
+        cout = n_classes if lvl == 1 else enc_out[lvl - 2]
+        if unpool_type == 'standard':
+            W = _he_uniform(rng, (cin, cout, 4, 4), cin * 4)
+            p['up%d' % lvl] = (W, _bias(rng, cout))
+        else:
+            gain = out_gain if lvl == 1 else 1.0
+            p['up_conv%d' % lvl] = (gain * _he_uniform(rng, (cout, cin, 3, 3), cin * 9),
+                                    _bias(rng, cout))
+        cin = cout
+    return p
+
+
+def make_images(n, h=224, w=224, channels=3, seed=1234):
+    """Uniform [0,1) float32 RGB batch (N,C,H,W)."""
+    rng = np.random.default_rng(seed)
+    return rng.random((n, channels, h, w), dtype=np.float32)
+
+
+def make_labels(n, h=224, w=224, n_classes=11, void_frac=0.05, seed=99, block=16):
+    """Smooth blobby class maps in {0..n_classes} (n_classes == void), as one-hot float32
+    (N, n_classes+1, H, W) with the void channel last."""
+    rng = np.random.default_rng(seed)
+    gh, gw = (h + block - 1) // block, (w + block - 1) // block
+    low = rng.random((n, n_classes, gh, gw), dtype=np.float32)
+    cls = low.argmax(axis=1)
+    cls = np.repeat(np.repeat(cls, block, axis=1), block, axis=2)[:, :h, :w]
+    void = rng.random((n, gh, gw), dtype=np.float32) < void_frac
+    void = np.repeat(np.repeat(void, block, axis=1), block, axis=2)[:, :h, :w]
+    cls = np.where(void, n_classes, cls)
+    onehot = np.zeros((n, n_classes + 1, h, w), dtype=np.float32)
+    np.put_along_axis(onehot, cls[:, None, :, :], 1.0, axis=1)
+    return onehot

@@ -1,0 +1,217 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ctypes), against the float64 numpy
+oracle on the same seeded inputs.  Tolerances: fp32 kernels vs float64 oracle, |err| <=
+1e-5 * (1 + |ref|) scaled by the reduction depth for convolutions; integer/compare work
+(pool, unpool masks, confusion counts) is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+from oracle import metrics as ometrics
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops(built_lib):
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    from iterative_inference_segm_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def rnd(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+def conv_tol(ref, K):
+    return 2e-6 * np.sqrt(K) * (1.0 + np.abs(ref).max())
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, pad, dil, relu   (covers BM=32/64/128 variants, ragged tiles)
+    (2, 3, 17, 19, 11, 3, 1, 1, False),
+    (1, 11, 20, 20, 64, 3, 5, 1, True),     # big pad, BM=64
+    (3, 40, 13, 9, 130, 3, 1, 1, True),     # BM=128, 2 m-tiles, ragged Cout
+    (2, 16, 9, 9, 200, 7, 0, 1, True),      # 7x7 valid (fc6-like)
+    (2, 70, 7, 7, 33, 1, 0, 1, True),       # 1x1, BM=64
+    (1, 11, 40, 36, 11, 3, 0, 4, False),    # dilated, valid (contextmod-like)
+    (1, 5, 300, 7, 12, 3, 1, 1, False),     # many pixel tiles, tall image
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_matches_oracle(ops, case):
+    B, Cin, H, W, Cout, k, pad, dil, relu = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x, Wt, b = rnd(rng, B, Cin, H, W), rnd(rng, Cout, Cin, k, k) / np.sqrt(Cin * k * k), rnd(rng, Cout)
+    ref = onn.conv2d(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64),
+                     pad=pad, dilation=dil, relu=relu)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, dil=dil)
+    got = host(conv(dev(x)))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= conv_tol(ref, Cin * k * k)
+
+
+def test_conv_iohw_layout(ops):
+    """DilatedConv2DLayer weight layout W[in,out,kh,kw] (P11)."""
+    rng = np.random.default_rng(5)
+    x, Wio, b = rnd(rng, 1, 6, 12, 12), rnd(rng, 6, 9, 3, 3), rnd(rng, 9)
+    ref = onn.conv2d(x.astype(np.float64), np.transpose(Wio, (1, 0, 2, 3)).astype(np.float64),
+                     b.astype(np.float64), pad=0, dilation=2)
+    got = host(ops.Conv(Wio, b, pad=0, relu=False, dil=2, layout='iohw')(dev(x)))
+    assert np.abs(got - ref).max() <= conv_tol(ref, 54)
+
+
+def test_conv_two_source_concat(ops):
+    """h-first channel concat fused in the gather (model_helpers.py:93-94, P13)."""
+    rng = np.random.default_rng(7)
+    h, t = rnd(rng, 2, 24, 10, 11), rnd(rng, 2, 8, 10, 11)
+    Wt, b = rnd(rng, 40, 32, 3, 3) / 17, rnd(rng, 40)
+    ref = onn.conv2d(onn.concat_h_first(h.astype(np.float64), t.astype(np.float64)),
+                     Wt.astype(np.float64), b.astype(np.float64), pad=1, relu=True)
+    got = host(ops.Conv(Wt, b, pad=1, relu=True)(dev(h), x2=dev(t)))
+    assert np.abs(got - ref).max() <= conv_tol(ref, 288)
+
+
+def test_conv_window_and_add(ops):
+    """Output window (center crop) + epilogue add with its own crop offset (P6)."""
+    rng = np.random.default_rng(8)
+    x = rnd(rng, 2, 9, 14, 15)
+    Wt, b = rnd(rng, 11, 9, 3, 3) / 9, rnd(rng, 11)
+    other = rnd(rng, 2, 11, 10, 9)
+    full = onn.conv2d(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), pad=4)
+    ref = onn.crop_sum(full, other.astype(np.float64))          # (2, 11, 10, 9)
+    fh, fw = full.shape[2:]
+    got = host(ops.Conv(Wt, b, pad=4, relu=False)(
+        dev(x), add=dev(other), add_off=(0, 0),
+        window=((fh - 10) // 2, (fw - 9) // 2, 10, 9)))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= conv_tol(ref, 81)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 8, 8), (1, 3, 9, 7), (2, 70, 13, 13), (1, 1, 211, 5)])
+def test_conv_fused_unpool(ops, shape):
+    """DePool2D as the conv's input gather == oracle depool + conv; includes tie masks
+    (post-ReLU zeros) and odd sizes (trailing row/col zero)."""
+    B, C, H, W = shape
+    rng = np.random.default_rng(H * 100 + W)
+    pre = np.maximum(rnd(rng, B, C, H, W), 0)            # lots of exact-zero ties
+    pre[:, :, :2, :2] = 0.75                              # a constant (all-tie) window
+    pooled = onn.maxpool2(pre)
+    up = rnd(rng, *pooled.shape)
+    Cout = 12
+    Wt, b = rnd(rng, Cout, C, 3, 3) / np.sqrt(9 * C), rnd(rng, Cout)
+    un = onn.depool_eqmask(up.astype(np.float64), pre.astype(np.float64), pooled.astype(np.float64))
+    ref = onn.conv2d(un, Wt.astype(np.float64), b.astype(np.float64), pad=1)
+    got = host(ops.Conv(Wt, b, pad=1, relu=False)(dev(up), pre=dev(pre), pooled=dev(pooled)))
+    assert np.abs(got - ref).max() <= conv_tol(ref, 9 * C)
+    # and the materialised kernel is bit-exact
+    un_gpu = host(ops.unpool_eqmask(dev(up), dev(pre), dev(pooled)))
+    assert np.array_equal(un_gpu, un.astype(np.float32))
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 9, 7), (3, 2, 211, 13), (1, 1, 2, 2)])
+def test_maxpool_bit_exact(ops, shape):
+    rng = np.random.default_rng(11)
+    x = rnd(rng, *shape)
+    assert np.array_equal(host(ops.maxpool2x2(dev(x))), onn.maxpool2(x))
+
+
+@pytest.mark.parametrize('k,s,H,W', [(4, 2, 7, 7), (4, 2, 16, 9), (16, 8, 5, 6)])
+def test_deconv_flip_and_crop_add(ops, k, s, H, W):
+    """Asymmetric random kernels: checks the P3 flip convention, windows and the fused add."""
+    rng = np.random.default_rng(k * 10 + s)
+    x, Wt, b = rnd(rng, 2, 11, H, W), rnd(rng, 11, 11, k, k), rnd(rng, 11)
+    ref = onn.deconv2d(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), stride=s)
+    d = ops.Deconv(Wt, b, s)
+    got = host(d(dev(x)))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-5 * (1 + np.abs(ref).max())
+    # cropped window + add of a center-cropped bigger tensor
+    fh, fw = ref.shape[2:]
+    oh, ow = fh - 3, fw - 2
+    other = rnd(rng, 2, 11, fh + 4, fw + 1)
+    ref2 = onn.center_crop(ref, oh, ow) + onn.center_crop(other.astype(np.float64), oh, ow)
+    got2 = host(d(dev(x), add=dev(other), add_off=((fh + 4 - oh) // 2, (fw + 1 - ow) // 2),
+                  window=((fh - oh) // 2, (fw - ow) // 2, oh, ow)))
+    assert np.abs(got2 - ref2).max() <= 1e-5 * (1 + np.abs(ref2).max())
+
+
+def test_crop_softmax_and_residual(ops):
+    rng = np.random.default_rng(3)
+    score = 5 * rnd(rng, 2, 11, 30, 28)
+    y = rng.random((2, 11, 24, 20)).astype(np.float32)
+    ref = onn.softmax_channels(onn.center_crop(score.astype(np.float64), 24, 20))
+    got = host(ops.crop_softmax(dev(score), 24, 20))
+    assert np.abs(got - ref).max() <= 1e-6
+    assert np.abs(got.sum(1) - 1).max() <= 1e-6
+    de = host(ops.crop_softmax(dev(score), 24, 20, minuend=dev(y)))
+    assert np.abs(de - (y - ref)).max() <= 1e-6
+
+
+def test_refine_update_semantics(ops):
+    """One fused step == reference arithmetic; frozen images do not move; the early-stop test
+    is applied AFTER the update (iterative_inference.py:270-277)."""
+    rng = np.random.default_rng(4)
+    B, C, H, W = 3, 11, 19, 23
+    score = 3 * rnd(rng, B, C, H + 4, W + 2)
+    y0 = rng.random((B, C, H, W)).astype(np.float32)
+    r = onn.softmax_channels(onn.center_crop(score.astype(np.float64), H, W))
+    # image 2: y == r exactly representable? make score so that r ~ y: use y0[2] := r[2]
+    y0[2] = r[2].astype(np.float32)
+    step = 0.3
+    de = y0.astype(np.float64) - r
+    y_ref = np.clip(y0 - step * de, 0, 1)
+    norms = np.linalg.norm(de, axis=1).mean(axis=(1, 2))
+    y = dev(y0)
+    st = ops.RefineState(B, H, W, y.device)
+    st.active[1] = 0                                   # image 1 frozen beforehand
+    ops.refine_update(dev(score), y, st, step)
+    ops.refine_finalize(st, 1e-3)
+    got = host(y)
+    assert np.abs(got[0] - y_ref[0]).max() <= 1e-6
+    assert np.array_equal(got[1], y0[1])               # frozen image untouched
+    assert np.abs(got[2] - y_ref[2]).max() <= 1e-6     # updated in the iteration it converges
+    active, iters, last = host(st.active), host(st.iters), host(st.last_norm)
+    assert list(active) == [1, 0, 0] and list(iters) == [1, 0, 1]
+    assert abs(last[0] - norms[0]) <= 1e-6 and last[2] < 1e-3
+
+
+def test_confusion_matches_val_fn(ops):
+    rng = np.random.default_rng(6)
+    B, C, H, W = 2, 11, 16, 24
+    y = rng.random((B, C, H, W)).astype(np.float32)
+    y /= y.sum(1, keepdims=True)
+    y[0, :, 0, 0] = 1.0 / C                             # an all-tie pixel: argmax -> first index
+    labels = rng.integers(0, C + 1, size=(B, H, W))
+    t = np.zeros((B, C + 1, H, W), dtype=np.float32)
+    np.put_along_axis(t, labels[:, None], 1.0, axis=1)
+    acc_ref, jacc_ref, mse_ref = ometrics.val_fn(y.astype(np.float64), t.astype(np.float64), C, [C])
+    from iterative_inference_segm_amd.api import Metrics
+    m = Metrics(C, 'cuda')
+    ops.confusion_accumulate(dev(y), dev(t), m.cm, m.sums)
+    acc, jacc, mse = m.result()
+    assert np.array_equal(jacc, jacc_ref)               # integer counts: exact
+    assert abs(acc - acc_ref) <= 1e-12
+    assert abs(mse - mse_ref) <= 1e-6 * mse_ref
+
+
+def test_abi_rejects_bad_arguments(ops):
+    """Error behaviour: negative iiseg_status -> RuntimeError naming the cause."""
+    rng = np.random.default_rng(1)
+    conv = ops.Conv(rnd(rng, 4, 3, 3, 3), rnd(rng, 4), pad=1, relu=True)
+    with pytest.raises(RuntimeError, match='input channels'):
+        conv(dev(rnd(rng, 1, 5, 8, 8)))
+    with pytest.raises(RuntimeError, match='shape'):
+        conv(dev(rnd(rng, 1, 3, 8, 8)), window=(0, 0, 9, 9))      # window outside the output
+    with pytest.raises(RuntimeError, match='device tensors'):
+        conv(torch.zeros(1, 3, 8, 8))
