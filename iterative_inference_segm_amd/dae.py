@@ -71,15 +71,18 @@ class StandardDAE:
             self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
                                       device=device)                     # fcn_up.py:83-86
         self.conv_log = None
+        self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
 
     def conv_layers(self):
         d = dict(self.enc)
         d.update(self.dec)
         return d
 
-    def scores(self, h_list, y):
+    def scores(self, h_list, y, mask_override=None):
         """Runs the DAE up to the pre-softmax score map already cropped to y's size
-        (fused_up1 of fcn_up.py:104-113).  Returns score (B, n_classes, H, W)."""
+        (fused_up1 of fcn_up.py:104-113).  Returns score (B, n_classes, H, W).
+        `mask_override` {level: (pre, pooled)} substitutes the tensors whose equality defines
+        the DePool2D mask of that level (parity tests use it to inject reference masks)."""
         h_list = list(h_list)
         if len(h_list) != len(self.concat_h):
             raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
@@ -114,13 +117,21 @@ class StandardDAE:
             other = pool[p - 1]                          # pre-concat pool (or the input for p=1)
             oh, ow = min(ph, other.shape[2]), min(pw, other.shape[3])
             window = (_center(ph, oh), _center(pw, ow), oh, ow)
+            mpre, mpool = pre[p], pool[p]
+            if mask_override and p in mask_override:
+                mpre, mpool = mask_override[p]
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
-                t = conv(t, pre=pre[p], pooled=pool[p], add=other,
+                t = conv(t, pre=mpre, pooled=mpool, add=other,
                          add_off=(_center(other.shape[2], oh), _center(other.shape[3], ow)),
                          window=window)
             else:                                        # :104-113 CroppingLayer
-                t = conv(t, pre=pre[p], pooled=pool[p], window=window)
+                t = conv(t, pre=mpre, pooled=mpool, window=window)
             self._count(name, conv, t, full=(ph, pw))
+            if self.trace is not None:
+                self.trace['fused_up%d' % p] = t
+        if self.trace is not None:
+            self.trace.update({'pre%d' % k: v for k, v in pre.items()})
+            self.trace.update({'pool%d' % k: v for k, v in pool.items() if k > 0})
         return t
 
     def _count(self, name, conv, out, full=None):

@@ -81,6 +81,7 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
             if bn:
                 t = _bn_avg(t, params[name + '_bn'])         # :112-114
         pre[p + 1] = t
+        net['pre%d' % (p + 1)] = t
         net['pool%d' % (p + 1)] = t = nn.maxpool2(t)         # :122
         if p < n_pool:
             t, pos = maybe_concat('pool%d' % (p + 1), t, pos)  # :131-134

@@ -6,9 +6,24 @@ timed CPU baseline).  Pins Pn refer to SURVEY.md section 2.1.
 """
 import numpy as np
 
+from . import _cref
+
 
 def conv2d(x, W, b=None, pad=0, dilation=1, relu=False):
     """Lasagne Conv2DLayer with flip_filters=False (P1): stride-1 cross-correlation.
+
+    float64 inputs (the parity oracle) go through the plain-C fixed-order kernel of
+    oracle/conv_ref.c, which gives bit-equal outputs for equal patches (the DePool2D equality
+    masks need that, see the header of conv_ref.c); float32 inputs (the timed CPU baseline)
+    go through `conv2d_blas`.  Same arguments as `conv2d_blas`.
+    """
+    if x.dtype == np.float64:
+        return _cref.conv2d_f64(x, W, b, pad, dilation, relu)
+    return conv2d_blas(x, W, b, pad, dilation, relu)
+
+
+def conv2d_blas(x, W, b=None, pad=0, dilation=1, relu=False):
+    """Stride-1 cross-correlation via one BLAS matmul per filter tap (im2col-GEMM class).
 
     W[out, in, kh, kw], b[out]; pad = int zero padding on both spatial axes ('same' == k//2,
     pad=100 literal, 'valid' == 0).  Default Lasagne nonlinearity is ReLU, callers pass

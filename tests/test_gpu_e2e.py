@@ -84,9 +84,25 @@ def test_early_stop_freezes_per_image(built_lib):
     assert list(it_ref) == [1, 1]
 
 
+def _masks(pre, pool):
+    h2, w2 = pool.shape[2] * 2, pool.shape[3] * 2
+    return pre[:, :, :h2, :w2] == np.repeat(np.repeat(pool, 2, 2), 2, 3)
+
+
 def test_full_size_single_image(built_lib):
-    """BASELINE config 1/2 geometry: real FCN-8 + 64-filter DAE at 224x224, 11 classes, one
-    image, 3 refinement steps (the oracle needs ~25 s for this on the box's host cores)."""
+    """BASELINE config 1/2 geometry: real FCN-8 + 64-filter DAE at 224x224, 11 classes.
+
+    fp32 HIP vs float64 oracle.  The FCN-8 output must be within 1e-4.  The DAE contains the
+    DePool2D equality masks (layers/mylayers.py:111-114), a discontinuity: where the two largest
+    values of a pooling window differ by less than fp32 resolution, fp32 and float64 arithmetic
+    legitimately pick different maxima (a handful of the 17 M mask bits per forward) and the
+    outputs differ by O(1) around those pixels.  So the check is three-fold:
+      1. GPU masks == oracle masks except at such near-ties (every disagreement is verified to be
+         one: the oracle window's top-2 gap is < 1e-5 relative), and they are < 1e-5 of all bits;
+      2. with the oracle's masks injected, r(y|h) is within 1e-4 everywhere (arithmetic parity);
+      3. free-running, >= 90 % of the refined map is within 1e-4 after 2 steps and the argmax
+         segmentation agrees on >= 99 % of the pixels.
+    """
     concat_h = ['pool4']
     fp, dp = S.make_fcn8_params(), S.make_dae_params()
     ii = build(built_lib, fp, dp, concat_h, 64)
@@ -97,11 +113,49 @@ def test_full_size_single_image(built_lib):
                                       layer=concat_h + ['probs_dimshuffle'])
     assert np.abs(host(H[0]) - h_ref).max() <= 1e-4 * (1 + np.abs(h_ref).max())
     assert np.abs(host(Y) - y_ref).max() <= TOL
+
+    # one DAE forward from the SAME (GPU) h, y on both sides
     dp64 = to64(dp)
+    h64, y64 = host(H[0]).astype(np.float64), host(Y).astype(np.float64)
+    r_ref, net = odae.dae_forward(dp64, [h64], y64, return_net=True)
+    ii.dae.trace = {}
+    ii.dae.scores(H, Y)
+    tr = {k: host(v) for k, v in ii.dae.trace.items()}
+    ii.dae.trace = None
+    total_bits, flips, override = 0, 0, {}
+    for p in range(1, 7):
+        mg = _masks(tr['pre%d' % p], tr['pool%d' % p])
+        mo = _masks(net['pre%d' % p], net['pool%d' % p])
+        total_bits += mo.size
+        for (b, c, yy, xx) in np.argwhere(mg != mo):
+            win = np.sort(net['pre%d' % p][b, c, yy // 2 * 2:yy // 2 * 2 + 2,
+                                           xx // 2 * 2:xx // 2 * 2 + 2].ravel())
+            assert win[-1] - win[-2] <= 1e-5 * abs(win[-1]), \
+                'mask disagreement that is not a near-tie at level %d: %s' % (p, win)
+            flips += 1
+        # reference masks as tensors whose equality reproduces them exactly
+        full = np.zeros(net['pre%d' % p].shape, dtype=np.float32)
+        full[:, :, :mo.shape[2], :mo.shape[3]] = mo
+        override[p] = (torch.from_numpy(full).cuda(),
+                       torch.ones(net['pool%d' % p].shape, dtype=torch.float32, device='cuda'))
+    print('mask bits %d, near-tie flips %d' % (total_bits, flips))
+    assert flips <= 1e-5 * total_bits
+    from iterative_inference_segm_amd import ops
+    score = ii.dae.scores(H, Y, mask_override=override)
+    r_forced = host(ops.crop_softmax(score, 224, 224, off=(0, 0)))
+    err = np.abs(r_forced - r_ref).max()
+    print('teacher-forced-mask r(y|h) max-abs err %.3e' % err)
+    assert err <= TOL
+
+    # free-running refinement, 2 steps
     dae_fn = lambda hh, yy: odae.dae_forward(dp64, hh, yy)
-    yii_ref, it_ref = orefine.refine_batch(dae_fn, [h_ref], y_ref, 0.1, 3)
-    Yii, iters, _ = ii.refine(H, Y, 0.1, 3)
-    err = np.abs(host(Yii) - yii_ref)
-    print('full-size refine max-abs err %.3e, frac>1e-5 %.2e' % (err.max(), (err > 1e-5).mean()))
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, [h_ref], y_ref, 0.1, 2)
+    Yii, iters, _ = ii.refine(H, Y, 0.1, 2)
+    got = host(Yii)
+    e = np.abs(got - yii_ref)
+    frac_ok = float((e.max(axis=1) <= TOL).mean())
+    agree = float((got.argmax(1) == yii_ref.argmax(1)).mean())
+    print('free-running: pixels within 1e-4: %.4f, argmax agreement %.5f, max err %.3e'
+          % (frac_ok, agree, e.max()))
     assert list(host(iters)) == list(it_ref)
-    assert err.max() <= TOL
+    assert frac_ok >= 0.90 and agree >= 0.99
