@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: refined images/s of the iterative-inference hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): FCN-8 + standard DAE (n_filters=64, additional_pool=2,
+concat_h=['pool4'], trackind unpool, skip), 11 classes, synthetic random 224x224x3 images,
+batch 64 per GPU, 10 refinement steps (step 0.1, early stop disabled so the work is fixed),
+fp32 HIP kernels.  One "step" = one batch through pred_fcn_fn -> refine x10 -> val_fn.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     : the implicit-GEMM conv kernel, HIP-event timed per launch in an extra pass
+  cpu_baseline : the numpy/BLAS float32 restatement (oracle, "port") on the host cores, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from iterative_inference_segm_amd import dist as iidist  # noqa: E402
+from iterative_inference_segm_amd import synthetic as S  # noqa: E402
+
+N_CLASSES = 11
+GFLOP_PER_IMAGE = 872.3          # 119.24 (FCN-8) + 10 x 75.31 (DAE), nominal
+PEAK_TFLOPS_F32_MFMA = 157.3     # MI355X_MICROARCH.md, fp32 matrix peak
+
+
+def build_model(device, concat_h):
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp = S.make_fcn8_params(seed=1234)      # same seed on every rank: replicated weights
+    dp = S.make_dae_params(seed=4321)
+    fcn = FCN8(fp, N_CLASSES, layer=concat_h + ['probs_dimshuffle'], device=device)
+    dae = StandardDAE(dp, N_CLASSES, concat_h=concat_h, padding=100, n_filters=64,
+                      additional_pool=2, skip=True, unpool_type='trackind', device=device)
+    return IterativeInference(fcn, dae, N_CLASSES, [N_CLASSES], device=device), fp, dp
+
+
+def one_step(ii, X, T, num_iter, step_size):
+    """One batch of the hot path; returns the device-side metric accumulators."""
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    Yii, _, _ = ii.refine(H, Y, step_size, num_iter, early_stop=False)
+    return ii.val_device(Yii, T), ii.val_device(Y, T)
+
+
+def cpu_baseline(fp, dp, num_iter, step_size, concat_h):
+    """Times the oracle's float32 numpy/BLAS restatement (same loop, one image) on the host."""
+    from oracle import dae as odae, fcn8 as ofcn8, refine as orefine
+    x = S.make_images(1, 224, 224, seed=777)
+    to32 = lambda p: {k: tuple(np.asarray(a, np.float32) for a in v) for k, v in p.items()}
+    fp32, dp32 = to32(fp), to32(dp)
+    t0 = time.time()
+    h, y = ofcn8.fcn8_forward(fp32, x, layer=concat_h + ['probs_dimshuffle'])
+    orefine.refine_batch(lambda hh, yy: odae.dae_forward(dp32, hh, yy), [h], y, step_size,
+                         num_iter, eps=-1.0)
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 5), 'unit': 'images/s', 'cores': os.cpu_count(),
+            'kind': 'port',
+            'sample': '1 image 224x224, FCN-8 + %d DAE steps, numpy/BLAS float32 restatement '
+                      '(oracle), %.1f s' % (num_iter, dt)}
+
+
+def conv_roofline(ii, X, T, num_iter, step_size):
+    """Extra (untimed) pass with HIP events around every conv launch on the launch stream."""
+    from iterative_inference_segm_amd import ops
+    ops.CONV_PROFILE = prof = []
+    one_step(ii, X, T, num_iter, step_size)
+    torch.cuda.synchronize()
+    ops.CONV_PROFILE = None
+    flops = sum(f for f, _, _ in prof)
+    ms = sum(s.elapsed_time(e) for _, s, e in prof)
+    n = len(prof)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'conv_igemm_f32_kernel', 'achieved': round(achieved, 2),
+            'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_TFLOPS_F32_MFMA, 4), 'traffic': None,
+            'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
+            'gflop_per_launch': round(flops / n / 1e9, 3), 'conv_ms_per_step': round(ms, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
+    ap.add_argument('--num_iter', type=int, default=10)
+    ap.add_argument('--step_size', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, device = iidist.init_from_env('cuda')
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run '
+                         '--nproc-per-node %d' % (world, args.gpus, args.gpus))
+    concat_h = ['pool4']
+    ii, fp, dp = build_model(device, concat_h)
+    B = args.batch
+    # weak scaling: every rank refines its own shard of `B` synthetic images per step
+    X = torch.from_numpy(S.make_images(B, 224, 224, seed=1234 + rank)).to(device)
+    T = torch.from_numpy(S.make_labels(B, 224, 224, seed=99 + rank)).to(device)
+
+    for _ in range(args.warmup):
+        one_step(ii, X, T, args.num_iter, args.step_size)
+    torch.cuda.synchronize()
+    iidist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = []
+    for _ in range(args.steps):
+        results.append(one_step(ii, X, T, args.num_iter, args.step_size))
+    # the path's only collective: one all-reduce of the metric accumulator (RCCL over xGMI)
+    acc_ii = iidist.EvalAccumulator(N_CLASSES)
+    acc_fcn = iidist.EvalAccumulator(N_CLASSES)
+    for m_ii, m_fcn in results:
+        a, j, mse = m_ii.result()
+        acc_ii.add_batch(m_ii.cm.cpu().numpy(), a, mse)
+        a, j, mse = m_fcn.result()
+        acc_fcn.add_batch(m_fcn.cm.cpu().numpy(), a, mse)
+    acc_ii.all_reduce(device)
+    acc_fcn.all_reduce(device)
+    torch.cuda.synchronize()
+    iidist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    images = world * B * args.steps
+    value = images / dt
+    line = {
+        'metric': 'refined images/s (FCN-8 + standard DAE, 10-step iterative inference, 224x224, '
+                  '11 classes)',
+        'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic (seeded uniform images, blob labels, He-uniform random weights)',
+        'config': {'workload': 'BASELINE configs[1]: FCN-8 + standard DAE (f64c1p2, pool4, '
+                               'trackind, skip), 224x224x3, batch %d/GPU, %d steps, step %.2g, '
+                               'early stop off' % (B, args.num_iter, args.step_size),
+                   'global_batch': world * B, 'parallelism': 'dp%d' % world},
+        'nominal_tflops': round(value * GFLOP_PER_IMAGE / 1e3, 2),
+        'frac_of_f32_mfma_peak_nominal': round(value * GFLOP_PER_IMAGE / 1e3
+                                               / (PEAK_TFLOPS_F32_MFMA * world), 4),
+    }
+    loss, acc, miou, _, nb = acc_ii.results()
+    _, acc_f, miou_f, _, _ = acc_fcn.results()
+    line['miou'] = {'iterative_inference': round(miou, 5), 'fcn': round(miou_f, 5),
+                    'acc_ii': round(acc, 5), 'acc_fcn': round(acc_f, 5), 'batches': nb,
+                    'note': 'consistency metric (random weights), reduced over ranks'}
+    if not args.no_roofline:
+        rl = conv_roofline(ii, X, T, args.num_iter, args.step_size)
+        line['roofline'] = rl
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(fp, dp, args.num_iter, args.step_size, concat_h)
+        print(json.dumps(line), flush=True)
+    iidist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

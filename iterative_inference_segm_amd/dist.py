@@ -1,0 +1,87 @@
+"""Data-parallel evaluation over the GPUs of one node (absent from the reference, which is a
+single process).  Images are independent, so they shard over ranks with NO
+data-path collective; the only exchange is one all-reduce (RCCL over xGMI; gloo on CPU) of the
+metric accumulator at the end of an evaluation:
+
+    [ confusion counts C*(C+1) | sum of per-batch acc | sum of per-batch mse | n_batches ]
+
+as one float64 vector (counts stay exact below 2^53).  IoU is sum-then-divide and therefore
+shard-invariant; acc / mse stay "means of per-batch means" (reference helpers.py:175-176) as long
+as every reference batch lives on exactly one rank, which `shard_batches` guarantees.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type=None):
+    """One process per GPU; reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    Returns (rank, world, device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if device_type is None:
+        device_type = 'cuda' if torch.cuda.is_available() else 'cpu'
+    if device_type == 'cuda':
+        torch.cuda.set_device(local)
+        device = torch.device('cuda', local)
+    else:
+        device = torch.device('cpu')
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = 'nccl' if device_type == 'cuda' else 'gloo'   # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def shard_batches(n_batches, rank, world):
+    """Batch indices owned by `rank`: round-robin so every rank gets floor/ceil(n/world)."""
+    return list(range(rank, n_batches, world))
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+class EvalAccumulator:
+    """Running totals of one evaluation (the rec_tot/acc_tot/jacc_tot of
+    iterative_inference.py:216-224,288-290), reducible across ranks."""
+
+    def __init__(self, n_classes):
+        self.C = n_classes
+        self.vec = np.zeros(n_classes * (n_classes + 1) + 3, dtype=np.float64)
+
+    def add_batch(self, cm, acc, mse):
+        n = self.C * (self.C + 1)
+        self.vec[:n] += np.asarray(cm, dtype=np.float64).reshape(-1)
+        self.vec[n] += acc
+        self.vec[n + 1] += mse
+        self.vec[n + 2] += 1
+
+    def all_reduce(self, device):
+        """Sum over ranks (no-op for a single process).  One latency-bound collective."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.from_numpy(self.vec).to(device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self.vec = t.cpu().numpy()
+        return self
+
+    def results(self):
+        """(loss, acc, mean IoU, per-class IoU, n_batches) as print_results reports them."""
+        C = self.C
+        n = C * (C + 1)
+        cm = self.vec[:n].reshape(C, C + 1)[:, :C]
+        tp = np.diag(cm)
+        denom = cm.sum(1) + cm.sum(0) - tp
+        with np.errstate(invalid='ignore', divide='ignore'):
+            iou = tp / denom
+            miou = float(np.nanmean(iou))
+        nb = max(self.vec[n + 2], 1.0)
+        return self.vec[n + 1] / nb, self.vec[n] / nb, miou, iou, int(self.vec[n + 2])

@@ -12,6 +12,11 @@ from . import _lib
 from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, check
 
 
+# When set to a list, every conv launch appends (executed_flops, start_event, end_event):
+# HIP events recorded on the launch stream right around the kernel (bench.py's roofline leg).
+CONV_PROFILE = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -114,9 +119,16 @@ class Conv:
             out = torch.empty((B, self.Cout, d.OH, d.OW), dtype=torch.float32, device=x1.device)
         elif tuple(out.shape) != (B, self.Cout, d.OH, d.OW):
             raise RuntimeError('out shape %s != %s' % (tuple(out.shape), (B, self.Cout, d.OH, d.OW)))
+        prof = CONV_PROFILE
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         check(self.lib.iiseg_conv_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
                                       _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
                                       _ptr(self.b), _ptr(add), _ptr(out)), 'iiseg_conv_f32')
+        if prof is not None:
+            ev1.record()
+            prof.append((self.flops(B, d.OH, d.OW), ev0, ev1))
         return out
 
 
