@@ -14,6 +14,7 @@
 // models/fcn_down.py:102-104, models/fcn_up.py:83-86); see include/iiseg.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "iiseg.h"
 #include "common.h"
 
@@ -41,6 +42,7 @@ struct ConvParams {
     int P;            // B*OH*OW
     int n_ptiles, n_mtiles;
     int relu;
+    int debug_nogather;
 };
 
 // Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give
@@ -56,6 +58,40 @@ __device__ inline void tile_of_block(int bid, int nblocks, int n_p, int n_m, int
     const int gp = min(GP, n_p - g * GP);
     pt = g * GP + rr % gp;
     mt = rr / gp;
+}
+
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int V> struct ic { static constexpr int value = V; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// N x 64 bytes of the gather table (4 entries each) into SGPRs with wide scalar loads.  Inline
+// asm so that the loads stay wide, unconditional and ahead of the address arithmetic; the
+// wait is inside the statement (hipcc does not track asm loads).
+template <int N>
+__device__ __forceinline__ void load_ktab(const int4* tab, i32x16 (&t)[N]) {
+    static_assert(N == 2 || N == 4, "8 or 16 rows per wave");
+    if constexpr (N == 2)
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=s"(t[0]), "=s"(t[1]) : "s"(tab) : "memory");
+    else
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\t"
+                     "s_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=s"(t[0]), "=s"(t[1]), "=s"(t[2]), "=s"(t[3]) : "s"(tab) : "memory");
+}
+
+// scalar (wave-uniform) base + 32-bit unsigned per-lane byte offset: global_load saddr form
+__device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
 template <int BM, int BN, int WM, int WN, bool UNPOOL>
@@ -95,18 +131,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     goy += p.oy0;
     gox += p.ox0;
     const int pixoff = goy * p.W + gox;  // may address outside the image; guarded per tap
-    const float* xb1;
-    const float* xb2 = nullptr;
-    const float* preb = nullptr;
-    const float* poolb = nullptr;
+    // Addressing: one wave-uniform (SGPR) base per source = the tensor at the first image this
+    // tile touches, plus a 32-bit per-lane element offset (the tile spans few images, so the
+    // offset stays far below 2^31): global_load with scalar base + vector offset, one VALU add
+    // per gathered element.
+    const int b0 = __builtin_amdgcn_readfirstlane(p0 / OHW);  // first image of the tile
+    const int db = gb - b0;                        // 0..few
+    const float* sx1;
+    const float* sx2 = nullptr;
+    const float* spre = nullptr;
+    const float* spool = nullptr;
+    unsigned lo1, lo2 = 0;                         // per-lane BYTE offsets of this pixel's image
     if constexpr (UNPOOL) {
         const size_t hw2 = (size_t)p.h2 * p.w2;
-        xb1 = p.x1 + (size_t)gb * p.C1 * hw2;      // up
-        poolb = p.pooled + (size_t)gb * p.C1 * hw2;
-        preb = p.pre + (size_t)gb * p.C1 * HW;
+        sx1 = p.x1 + (size_t)b0 * p.C1 * hw2;      // up
+        spool = p.pooled + (size_t)b0 * p.C1 * hw2;
+        spre = p.pre + (size_t)b0 * p.C1 * HW;
+        lo1 = 4u * (unsigned)(db * p.C1 * HW + pixoff); // into pre
+        lo2 = 4u * (unsigned)(db * p.C1 * (p.h2 * p.w2));  // into up / pooled
     } else {
-        xb1 = p.x1 + (size_t)gb * p.C1 * HW;
-        xb2 = p.x2 ? p.x2 + (size_t)gb * p.C2 * HW : p.x1;
+        sx1 = p.x1 + (size_t)b0 * p.C1 * HW;
+        sx2 = p.x2 ? p.x2 + (size_t)b0 * p.C2 * HW : p.x1;
+        lo1 = 4u * (unsigned)(db * p.C1 * HW + pixoff);
+        lo2 = 4u * (unsigned)(db * p.C2 * HW + pixoff);
     }
 
     f32x16 acc[TM][TN];
@@ -117,84 +164,149 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Register staging of the next k-tile (global -> regs while the MFMAs of the current tile
+    // run, regs -> LDS afterwards).  Row group `rg` owns the XROWS consecutive k-rows
+    // [rg*XROWS, (rg+1)*XROWS) of a tile, so its gather-table entries are one contiguous,
+    // wave-uniform block (wide scalar loads).
     float xv[XROWS];
     float xq[UNPOOL ? XROWS : 1];  // pooled value (unpool mode)
     float xu[UNPOOL ? XROWS : 1];  // up value
-    float4 wv[WPT];
+    float4 wv0 = make_float4(0.f, 0.f, 0.f, 0.f), wv1 = wv0;
+    unsigned okmask = 0;  // bit j: gathered element j is inside the image
+    constexpr bool W_ALL = (WVEC % 256 == 0);  // every thread stages weights
+    const bool w_on = W_ALL || tid < WVEC;
+    const int wrow0 = tid / (BM / 4), wc4 = tid % (BM / 4);
+    const int wrow1 = (tid + 256) / (BM / 4);
+    const unsigned uH = (unsigned)p.H, uW = (unsigned)p.W;
+    const int pv = pvalid ? 1 : 0;
 
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int j = 0; j < XROWS; ++j) {
-            const int krow = rg + RG * j;
-            const int4 e = p.ktab[kt * BK + krow];  // wave-uniform -> scalar load
-            const int iy = goy + e.y, ix = gox + e.z;
-            bool ok = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            if constexpr (UNPOOL) {
-                // DePool2D (layers/mylayers.py:95-114): value of up where pre == pooled, inside
-                // the 2h x 2w region covered by pooling windows
-                ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
-                const int offp = (e.w & 0xFFFFFF) * (p.h2 * p.w2) + (iy >> 1) * p.w2 + (ix >> 1);
-                xv[j] = ok ? preb[pixoff + e.x] : 0.f;
-                xq[j] = ok ? poolb[offp] : 1.f;
-                xu[j] = ok ? xb1[offp] : 0.f;
-            } else {
-                const float* src = (e.w >> 30) ? xb2 : xb1;
-                xv[j] = ok ? src[pixoff + e.x] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int idx = tid + 256 * j;
-            if (WVEC % 256 == 0 || idx < WVEC) {
-                const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-                wv[j] = *reinterpret_cast<const float4*>(
-                    p.wp + (size_t)(kt * BK + row) * p.Mpad + m0 + c4 * 4);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < XROWS; ++j) {
-            float v = xv[j];
-            if constexpr (UNPOOL) v = (xv[j] == xq[j]) ? xu[j] : 0.f;
-            Xs[buf][rg + RG * j][lp] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int idx = tid + 256 * j;
-            if (WVEC % 256 == 0 || idx < WVEC) {
-                const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-                *reinterpret_cast<float4*>(&Ws[buf][row][c4 * 4]) = wv[j];
-            }
-        }
-    };
+    // Branch-free gather: out-of-image taps read element 0 of their tensor (always mapped) and
+    // are zeroed by a select when the tile is written to LDS.
+    //
+    // Schedule of one k-tile per wave (PMC showed the waves of co-resident workgroups fall into
+    // lockstep, so a separate "gather phase" leaves the matrix pipe idle a third of the time):
+    // the tile is cut into BK/2 chunks, chunk c = { gather GPC elements of the NEXT tile (address
+    // VALU + global_load), LDS-read the MFMA operands of k-step c+1, TM*TN MFMAs of k-step c },
+    // pinned in that order, so every piece of vector work issues in the shadow of an MFMA of the
+    // same wave.  Gathers are issued in the first half of the chunks, their LDS stores (into the
+    // idle buffer) in the second half, so only the barrier itself is left at the tile boundary.
+    i32x16 tb[XROWS / 4];
+#define IISEG_GATHER_ONE(J)                                                                     \
+    {                                                                                           \
+        constexpr int j = (J);                                                                  \
+        const int4 e = make_int4(tb[j / 4][(j % 4) * 4], tb[j / 4][(j % 4) * 4 + 1],            \
+                                 tb[j / 4][(j % 4) * 4 + 2], tb[j / 4][(j % 4) * 4 + 3]);       \
+        const int iy = goy + e.y, ix = gox + e.z;                                               \
+        int ok = pv & ((unsigned)iy < uH ? 1 : 0) & ((unsigned)ix < uW ? 1 : 0);                \
+        if constexpr (UNPOOL) {                                                                 \
+            /* DePool2D (layers/mylayers.py:95-114): up where pre == pooled, inside 2h x 2w */  \
+            ok &= (iy < 2 * p.h2 ? 1 : 0) & (ix < 2 * p.w2 ? 1 : 0);                            \
+            const unsigned offp = lo2 + 4u * (unsigned)((e.w & 0xFFFFFF) * (p.h2 * p.w2) +      \
+                                                        (iy >> 1) * p.w2 + (ix >> 1));          \
+            const unsigned msk = (unsigned)(-ok);                                               \
+            const unsigned o1 = (lo1 + 4u * (unsigned)e.x) & msk;                               \
+            const unsigned o2 = offp & msk;                                                     \
+            xv[j] = ld_off(spre, o1);                                                           \
+            xq[j] = ld_off(spool, o2);                                                          \
+            xu[j] = ld_off(sx1, o2);                                                            \
+        } else {                                                                                \
+            const bool s2 = (e.w >> 30) != 0; /* wave-uniform */                                \
+            const float* src = s2 ? sx2 : sx1;                                                  \
+            const unsigned o = ((s2 ? lo2 : lo1) + 4u * (unsigned)e.x) & (unsigned)(-ok);       \
+            xv[j] = ld_off(src, o);                                                             \
+        }                                                                                       \
+        okmask |= (unsigned)ok << j;                                                            \
+    }
+#define IISEG_LOAD_W(KT)                                                                        \
+    if (w_on) {                                                                                 \
+        wv0 = *reinterpret_cast<const float4*>(p.wp + (size_t)((KT) * BK + wrow0) * p.Mpad +    \
+                                               m0 + wc4 * 4);                                   \
+        if constexpr (WPT > 1)                                                                  \
+            wv1 = *reinterpret_cast<const float4*>(p.wp + (size_t)((KT) * BK + wrow1) * p.Mpad + \
+                                                   m0 + wc4 * 4);                               \
+    }
+#define IISEG_STORE_X(BUF, J)                                                                   \
+    {                                                                                           \
+        constexpr int j = (J);                                                                  \
+        const bool ok = (okmask >> j) & 1u;                                                     \
+        float v;                                                                                \
+        if constexpr (UNPOOL)                                                                   \
+            v = (ok && xv[j] == xq[j]) ? xu[j] : 0.f;                                           \
+        else                                                                                    \
+            v = ok ? xv[j] : 0.f;                                                               \
+        Xs[BUF][rg * XROWS + j][lp] = v;                                                        \
+    }
+#define IISEG_STORE_W(BUF)                                                                      \
+    if (w_on) {                                                                                 \
+        *reinterpret_cast<float4*>(&Ws[BUF][wrow0][wc4 * 4]) = wv0;                             \
+        if constexpr (WPT > 1) *reinterpret_cast<float4*>(&Ws[BUF][wrow1][wc4 * 4]) = wv1;      \
+    }
 
+    constexpr int NCH = BK / 2;                 // chunks = MFMA k-steps per tile
+    constexpr int GPC = XROWS / (NCH / 2);      // gathers per chunk, first half of the chunks
+    static_assert(GPC * (NCH / 2) == XROWS, "gather split");
     const int nkt = p.Kpad / BK;
-    load_tile(0);
-    store_tile(0);
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // prologue: tile 0 -> LDS buffer 0
+    load_ktab<XROWS / 4>(p.ktab + rg * XROWS, tb);
+    static_for<0, XROWS>([&](auto J) { IISEG_GATHER_ONE(decltype(J)::value) });
+    IISEG_LOAD_W(0)
+    static_for<0, XROWS>([&](auto J) { IISEG_STORE_X(0, decltype(J)::value) });
+    IISEG_STORE_W(0)
     __syncthreads();
 
-    const int l31 = lane & 31, lh = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
+        const bool more = (kt + 1 < nkt) && !p.debug_nogather;
+        float a[2][TM], b[2][TN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int kk = ks * 2 + lh;
-            float a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a[0][i] = Ws[buf][lh][wm * WTM + i * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ws[buf][kk][wm * WTM + i * 32 + l31];
+        for (int j = 0; j < TN; ++j) b[0][j] = Xs[buf][lh][wn * WTN + j * 32 + l31];
+        if (more) {
+            load_ktab<XROWS / 4>(p.ktab + (kt + 1) * BK + rg * XROWS, tb);
+            okmask = 0;
+        }
+        static_for<0, NCH>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            if (more) {
+                if constexpr (ch < NCH / 2)
+                    static_for<0, GPC>([&](auto G) {
+                        IISEG_GATHER_ONE(ch * GPC + decltype(G)::value)
+                    });
+                if constexpr (ch == 0) IISEG_LOAD_W(kt + 1)
+                // LDS stores of the next tile ride in the second half of the chunks: buffer
+                // buf^1 is idle during this tile (the barrier below fences its last readers)
+                if constexpr (ch >= NCH / 2)
+                    static_for<0, GPC>([&](auto G) {
+                        IISEG_STORE_X(buf ^ 1, (ch - NCH / 2) * GPC + decltype(G)::value)
+                    });
+                if constexpr (ch == NCH - 1) IISEG_STORE_W(buf ^ 1)
+            }
+            if constexpr (ch + 1 < NCH) {
+                const int kk = (ch + 1) * 2 + lh;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Xs[buf][kk][wn * WTN + j * 32 + l31];
+                for (int i = 0; i < TM; ++i)
+                    a[(ch + 1) & 1][i] = Ws[buf][kk][wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[(ch + 1) & 1][j] = Xs[buf][kk][wn * WTN + j * 32 + l31];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch & 1][i], b[ch & 1][j],
+                                                                     acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // pin the chunk order
+        });
         __syncthreads();
     }
+#undef IISEG_GATHER_ONE
+#undef IISEG_LOAD_W
+#undef IISEG_STORE_X
+#undef IISEG_STORE_W
 
     // ---- epilogue: bias, skip add, ReLU, NCHW store ------------------------------------
     // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -296,9 +408,12 @@ static int check_desc(const iiseg_conv_desc* d) {
     const int bm = pick_bm(d->Cout);
     if (d->Kpad != (K + BK - 1) / BK * BK || d->Mpad != (d->Cout + bm - 1) / bm * bm)
         return IISEG_ERR_SHAPE;
-    // int32 index ranges used by the kernel
+    // int32 index ranges used by the kernel: pixel index, and the per-tile relative BYTE offsets
+    // (a 256-pixel tile touches at most 256/(OH*OW) + 2 images)
     if ((int64_t)d->B * d->OH * d->OW >= (1ll << 31) - 512) return IISEG_ERR_SHAPE;
-    if ((int64_t)(d->C1 > d->C2 ? d->C1 : d->C2) * d->H * d->W >= (1ll << 30)) return IISEG_ERR_SHAPE;
+    const int64_t span = 256 / ((int64_t)d->OH * d->OW) + 2;
+    const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+    if (span * cmax * d->H * d->W * 4 >= (1ll << 32) - (1 << 20)) return IISEG_ERR_SHAPE;
     if (d->C1 >= (1 << 24) || d->C2 >= (1 << 24)) return IISEG_ERR_SHAPE;
     return IISEG_OK;
 }
@@ -324,10 +439,13 @@ static int launch_conv(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_ptiles = (p.P + BN - 1) / BN;
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
+    static const int dyn = getenv("IISEG_DEBUG_DYNLDS") ? atoi(getenv("IISEG_DEBUG_DYNLDS")) : 0;
+    static const int nog = getenv("IISEG_DEBUG_NOGATHER") ? 1 : 0;
+    p.debug_nogather = nog;
     if (unpool)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(256), dyn, s, p);
     else
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(256), dyn, s, p);
     return iiseg_check_launch();
 }
 
