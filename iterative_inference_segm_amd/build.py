@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libiiseg_hip.so')
-SOURCES = ['abi.hip', 'conv_igemm.hip', 'pool_unpool.hip', 'deconv.hip', 'tail.hip', 'metrics.hip']
+SOURCES = ['abi.hip', 'conv_igemm.hip', 'conv_taps.hip', 'pool_unpool.hip', 'deconv.hip', 'tail.hip', 'metrics.hip']
 ARCH = 'gfx950'
 
 
@@ -35,7 +35,8 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(INCLUDE, 'iiseg.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'),
+               os.path.join(INCLUDE, 'iiseg.h')]
     flags = ['-O3', '--offload-arch=' + ARCH, '-fPIC', '-std=c++17', '-I' + INCLUDE, '-I' + CSRC,
              '-Wall', '-Wno-unused-function']
 

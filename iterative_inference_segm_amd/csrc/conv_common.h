@@ -1,0 +1,100 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip: table-driven gather,
+// any filter; conv_taps.hip: static-tap buffer-load gather, 1x1 / 3x3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace iiseg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time unrolled loop: f(ic<I>) for I in [B, E)
+template <int V> struct ic { static constexpr int value = V; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+struct ConvParams {
+    const float* x1;
+    const float* x2;
+    const float* pre;
+    const float* pooled;
+    const float* wp;
+    const int4* ktab;
+    const float* bias;
+    const float* add;
+    float* out;
+    int B, C1, C2, H, W;
+    int h2, w2;  // pooled dims (unpool mode)
+    int Cout, OH, OW, oy0, ox0;
+    int AH, AW, ay0, ax0;
+    int Kpad, Mpad;
+    int pad, dil;
+    int P;  // B*OH*OW
+    int n_ptiles, n_mtiles;
+    int relu;
+    int debug_nogather;
+};
+
+// Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give
+// each XCD a contiguous run of tiles and, inside a run, walk groups of 8 pixel-tiles x all
+// channel-tiles so that co-resident blocks of one XCD share both X rows and W rows in its L2.
+__device__ inline void tile_of_block(int bid, int nblocks, int n_p, int n_m, int& pt, int& mt) {
+    const int q = nblocks / 8, r = nblocks % 8;
+    const int xcd = bid % 8, l = bid / 8;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + l;
+    constexpr int GP = 8;
+    const int gsize = GP * n_m;
+    const int g = v / gsize, rr = v % gsize;
+    const int gp = min(GP, n_p - g * GP);
+    pt = g * GP + rr % gp;
+    mt = rr / gp;
+}
+
+// Epilogue shared by both kernels: bias, skip add (center-cropped), ReLU, NCHW store.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p,
+                                              f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int p0,
+                                              int m0, int wm, int wn, int lane) {
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int OHW = p.OH * p.OW;
+    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pe = p0 + wn * WTN + j * 32 + l31;
+        if (pe >= p.P) continue;
+        const int eb = pe / OHW;
+        const int rem = pe - eb * OHW;
+        float* outp = p.out + (size_t)eb * p.Cout * OHW + rem;
+        const float* addp = nullptr;
+        size_t AHW = 0;
+        if (p.add) {
+            const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
+            AHW = (size_t)p.AH * p.AW;
+            addp = p.add + (size_t)eb * p.Cout * AHW + (size_t)(p.ay0 + eoy) * p.AW + p.ax0 + eox;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[co];
+                    if (addp) v += addp[(size_t)co * AHW];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    outp[(size_t)co * OHW] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace iiseg

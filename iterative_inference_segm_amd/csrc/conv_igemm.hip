@@ -17,60 +17,17 @@
 #include <stdlib.h>
 #include "iiseg.h"
 #include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+// conv_taps.hip
+int iiseg_taps_cpt(int KH, int KW);
+int iiseg_launch_conv_taps(hipStream_t s, const ConvParams& p, int KH, int KW, int bm, bool unpool);
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 constexpr int BK = 16;  // k-tile depth: 8 MFMA k-steps
-
-struct ConvParams {
-    const float* x1;
-    const float* x2;
-    const float* pre;
-    const float* pooled;
-    const float* wp;
-    const int4* ktab;
-    const float* bias;
-    const float* add;
-    float* out;
-    int B, C1, C2, H, W;
-    int h2, w2;  // pooled dims (unpool mode)
-    int Cout, OH, OW, oy0, ox0;
-    int AH, AW, ay0, ax0;
-    int Kpad, Mpad;
-    int P;            // B*OH*OW
-    int n_ptiles, n_mtiles;
-    int relu;
-    int debug_nogather;
-};
-
-// Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give
-// each XCD a contiguous run of tiles and, inside a run, walk groups of 8 pixel-tiles x all
-// channel-tiles so that co-resident blocks of one XCD share both X rows and W rows in its L2.
-__device__ inline void tile_of_block(int bid, int nblocks, int n_p, int n_m, int& pt, int& mt) {
-    const int q = nblocks / 8, r = nblocks % 8;
-    const int xcd = bid % 8, l = bid / 8;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + l;
-    constexpr int GP = 8;
-    const int gsize = GP * n_m;
-    const int g = v / gsize, rr = v % gsize;
-    const int gp = min(GP, n_p - g * GP);
-    pt = g * GP + rr % gp;
-    mt = rr / gp;
-}
-
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-
-// compile-time unrolled loop: f(std::integral_constant<int, I>) for I in [B, E)
-template <int V> struct ic { static constexpr int value = V; };
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (B < E) {
-        f(ic<B>{});
-        static_for<B + 1, E>(f);
-    }
-}
 
 // N x 64 bytes of the gather table (4 entries each) into SGPRs with wide scalar loads.  Inline
 // asm so that the loads stay wide, unconditional and ahead of the address arithmetic; the
@@ -250,9 +207,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 
     // prologue: tile 0 -> LDS buffer 0
     load_ktab<XROWS / 4>(p.ktab + rg * XROWS, tb);
-    static_for<0, XROWS>([&](auto J) { IISEG_GATHER_ONE(decltype(J)::value) });
+    static_for<0, XROWS>([&](auto J) __attribute__((always_inline)) { IISEG_GATHER_ONE(decltype(J)::value) });
     IISEG_LOAD_W(0)
-    static_for<0, XROWS>([&](auto J) { IISEG_STORE_X(0, decltype(J)::value) });
+    static_for<0, XROWS>([&](auto J) __attribute__((always_inline)) { IISEG_STORE_X(0, decltype(J)::value) });
     IISEG_STORE_W(0)
     __syncthreads();
 
@@ -268,18 +225,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             load_ktab<XROWS / 4>(p.ktab + (kt + 1) * BK + rg * XROWS, tb);
             okmask = 0;
         }
-        static_for<0, NCH>([&](auto CH) {
+        static_for<0, NCH>([&](auto CH) __attribute__((always_inline)) {
             constexpr int ch = decltype(CH)::value;
             if (more) {
                 if constexpr (ch < NCH / 2)
-                    static_for<0, GPC>([&](auto G) {
+                    static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
                         IISEG_GATHER_ONE(ch * GPC + decltype(G)::value)
                     });
                 if constexpr (ch == 0) IISEG_LOAD_W(kt + 1)
                 // LDS stores of the next tile ride in the second half of the chunks: buffer
                 // buf^1 is idle during this tile (the barrier below fences its last readers)
                 if constexpr (ch >= NCH / 2)
-                    static_for<0, GPC>([&](auto G) {
+                    static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
                         IISEG_STORE_X(buf ^ 1, (ch - NCH / 2) * GPC + decltype(G)::value)
                     });
                 if constexpr (ch == NCH - 1) IISEG_STORE_W(buf ^ 1)
@@ -308,37 +265,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 #undef IISEG_STORE_X
 #undef IISEG_STORE_W
 
-    // ---- epilogue: bias, skip add, ReLU, NCHW store ------------------------------------
-    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int pe = p0 + wn * WTN + j * 32 + l31;
-        if (pe >= p.P) continue;
-        const int eb = pe / OHW;
-        const int rem = pe - eb * OHW;
-        float* outp = p.out + (size_t)eb * p.Cout * OHW + rem;
-        const float* addp = nullptr;
-        size_t AHW = 0;
-        if (p.add) {
-            const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
-            AHW = (size_t)p.AH * p.AW;
-            addp = p.add + (size_t)eb * p.Cout * AHW + (size_t)(p.ay0 + eoy) * p.AW + p.ax0 + eox;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.Cout) {
-                    float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[co];
-                    if (addp) v += addp[(size_t)co * AHW];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    outp[(size_t)co * OHW] = v;
-                }
-            }
-        }
-    }
+    conv_epilogue<BM, BN, WM, WN>(p, acc, p0, m0, wm, wn, lane);
 }
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, int64_t so, int64_t sc, float* wp,
@@ -380,14 +307,22 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int64_t so, int64_
 
 int pick_bm(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
+// k extent of the packed weights: whole channel groups for the static-tap kernel (1x1, 3x3),
+// multiples of BK for the table-driven one.
+int kpad_for(const iiseg_conv_desc* d) {
+    const int C = d->C1 + d->C2, T = d->KH * d->KW;
+    const int cpt = iiseg_taps_cpt(d->KH, d->KW);
+    if (cpt > 0) return (C + cpt - 1) / cpt * cpt * T;
+    return (C * T + BK - 1) / BK * BK;
+}
+
 }  // namespace
 
 extern "C" int iiseg_conv_plan(iiseg_conv_desc* d) {
     if (!d) return IISEG_ERR_NULL;
     if (d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->C1 <= 0 || d->C2 < 0) return IISEG_ERR_SHAPE;
-    const int K = (d->C1 + d->C2) * d->KH * d->KW;
     const int bm = pick_bm(d->Cout);
-    d->Kpad = (K + BK - 1) / BK * BK;
+    d->Kpad = kpad_for(d);
     d->Mpad = (d->Cout + bm - 1) / bm * bm;
     return IISEG_OK;
 }
@@ -404,10 +339,8 @@ static int check_desc(const iiseg_conv_desc* d) {
     const int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
     if (fullH <= 0 || fullW <= 0 || d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW)
         return IISEG_ERR_SHAPE;
-    const int K = (d->C1 + d->C2) * d->KH * d->KW;
     const int bm = pick_bm(d->Cout);
-    if (d->Kpad != (K + BK - 1) / BK * BK || d->Mpad != (d->Cout + bm - 1) / bm * bm)
-        return IISEG_ERR_SHAPE;
+    if (d->Kpad != kpad_for(d) || d->Mpad != (d->Cout + bm - 1) / bm * bm) return IISEG_ERR_SHAPE;
     // int32 index ranges used by the kernel: pixel index, and the per-tile relative BYTE offsets
     // (a 256-pixel tile touches at most 256/(OH*OW) + 2 images)
     if ((int64_t)d->B * d->OH * d->OW >= (1ll << 31) - 512) return IISEG_ERR_SHAPE;
@@ -473,11 +406,15 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0;
     p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
     p.Kpad = d->Kpad; p.Mpad = d->Mpad;
+    p.pad = d->pad; p.dil = d->dil;
+    p.debug_nogather = 0;
     p.P = d->B * d->OH * d->OW;
     p.n_ptiles = p.n_mtiles = 0;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
 
     hipStream_t s = (hipStream_t)stream;
+    if (iiseg_taps_cpt(d->KH, d->KW) > 0)
+        return iiseg_launch_conv_taps(s, p, d->KH, d->KW, pick_bm(d->Cout), unpool);
     switch (pick_bm(d->Cout)) {
         case 128: return launch_conv<128, 128, 2, 2>(s, p, unpool);
         case 64: return launch_conv<64, 256, 1, 4>(s, p, unpool);
