@@ -18,6 +18,9 @@ CONV_PROFILE = None
 
 
 def _stream():
+    if not torch.cuda.is_available():
+        raise RuntimeError('iiseg ops need device tensors on a HIP GPU; none is available and '
+                           'there is no CPU fallback')
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

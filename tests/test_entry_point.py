@@ -1,0 +1,103 @@
+"""The drop-in entry point: same function / flag names as reference iterative_inference.py and
+the same error behaviour; on the GPU a whole synthetic evaluation runs through it."""
+import inspect
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_signature_and_flags_match_the_reference(monkeypatch, capsys):
+    import iterative_inference as ii
+    params = list(inspect.signature(ii.inference).parameters)
+    # reference iterative_inference.py:56-59, in order
+    assert params[:13] == ['dataset', 'segm_net', 'learn_step', 'num_iter', 'dae_dict_updates',
+                           'training_dict', 'data_augmentation', 'which_set', 'ae_h', 'full_im_ft',
+                           'savepath', 'loadpath', 'test_from_0_255']
+    sig = inspect.signature(ii.inference)
+    assert sig.parameters['learn_step'].default == 0.005 and sig.parameters['num_iter'].default == 500
+    assert ii._EPSILON == 1e-3
+    monkeypatch.setattr(sys, 'argv', ['iterative_inference.py', '-h'])
+    with pytest.raises(SystemExit):
+        ii.main()
+    helptext = capsys.readouterr().out
+    for flag in ['-dataset', '-segmentation_net', '-step', '--num_iter', '-ne', '-which_set',
+                 '-dae_dict', '-training_dict', '-full_im_ft', '-ae_h', '-data_augmentation',
+                 '-test_from_0_255']:
+        assert flag in helptext
+
+
+def test_error_behaviour_without_gpu(tmp_path):
+    import iterative_inference as ii
+    with pytest.raises(ValueError, match='saving directory'):
+        ii.inference('camvid', 'fcn8', savepath=None)                       # :88-89
+    kw = dict(savepath=str(tmp_path / 's'), loadpath=str(tmp_path / 'l'), synthetic=True,
+              verbose=False, n_images=2)
+    with pytest.raises(ValueError):
+        ii.inference('camvid', 'nonsense_net', **kw)                        # :146-147
+    with pytest.raises(NotImplementedError):
+        ii.inference('camvid', 'fcn_fcresnet', **kw)                        # :144-145
+    with pytest.raises(ValueError, match='Unknown dataset'):
+        ii.inference('imagenet', 'fcn8', **kw)
+
+
+@pytest.mark.gpu
+def test_synthetic_evaluation_end_to_end(built_lib, tmp_path):
+    """2 batches of 2 images (64x48), reduced DAE width, 3 steps: summary numbers agree with the
+    float64 oracle run of the same evaluation; files of the reference are written."""
+    import torch
+    import iterative_inference as ii
+    from oracle import dae as odae, fcn8 as ofcn8, metrics as ometrics, refine as orefine
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.data_loader import load_data
+    dd = {'kind': 'standard', 'unpool_type': 'trackind', 'n_filters': 4, 'additional_pool': 2,
+          'concat_h': ['pool4'], 'skip': True, 'from_gt': False}
+    # small FCN weights on disk in the reference's arr_%d layout, DAE weights synthetic
+    from iterative_inference_segm_amd import weights, fcn8 as pfcn8
+    fp = S.make_fcn8_params(width_div=16, fc_channels=32, seed=1234)
+    wdir = tmp_path / 'w' / 'camvid'
+    wdir.mkdir(parents=True)
+    weights.save_param_list(str(wdir / 'fcn8_model.npz'), fp, pfcn8.PARAM_ORDER)
+    # h_channels table of the entry point assumes real VGG widths; patch the synthetic DAE maker
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=4, seed=4321)
+    exp = ii.build_experiment_name('fcn8', data_aug=False, ae_h=False, **dict(
+        {'kind': 'fcn8', 'dropout': 0.0, 'skip': True, 'unpool_type': 'standard', 'n_filters': 64,
+         'conv_before_pool': 1, 'additional_pool': 0, 'concat_h': ['input'], 'noise': 0.0,
+         'from_gt': True, 'temperature': 1.0, 'layer': 'probs_dimshuffle', 'exp_name': '',
+         'bn': 0}, **dd))
+    ldir = tmp_path / 'l' / 'camvid' / exp
+    ldir.mkdir(parents=True)
+    from iterative_inference_segm_amd import dae as pdae
+    weights.save_param_list(str(ldir / 'dae_model_best.npz'), dp, pdae.param_order())
+    out = ii.inference('camvid', 'fcn8', 0.1, 3, dae_dict_updates=dd, savepath=str(tmp_path / 's'),
+                       loadpath=str(tmp_path / 'l'), weights_path=str(tmp_path / 'w'),
+                       synthetic=True, n_images=4, image_size=(64, 48), batch_size=2,
+                       verbose=False)
+    sdir = tmp_path / 's' / 'camvid' / exp / 'img_plots' / 'test'
+    assert (sdir / 'config.txt').exists() and (sdir / 'batch0.npz').exists()
+    with np.load(str(sdir / 'batch1.npz')) as f:
+        assert sorted(f.files) == ['L', 'X', 'Y_fcn', 'Y_ii'] and f['Y_ii'].shape == (2, 11, 64, 48)
+    assert (ldir / 'img_plots' / 'test' / 'batch0.npz').exists()           # copy_tree (:324-326)
+
+    # oracle evaluation of the same two batches
+    it = load_data('camvid', {}, one_hot=True, batch_size=[2, 5, 2], which_set='test',
+                   synthetic=True, n_images=4, image_size=(64, 48))
+    to64 = lambda p: {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in p.items()}
+    fp64, dp64 = to64(fp), to64(dp)
+    rec = acc = 0.0
+    jacc = np.zeros((2, 11))
+    for i in range(2):
+        X, L = it.batch(i)
+        h, y = ofcn8.fcn8_forward(fp64, X.astype(np.float64), layer=['pool4', 'probs_dimshuffle'])
+        yii, _ = orefine.refine_batch(lambda hh, yy: odae.dae_forward(dp64, hh, yy, n_filters=4),
+                                      [h], y, 0.1, 3)
+        a, j, m = ometrics.val_fn(yii, L.astype(np.float64), 11, [11])
+        rec += m; acc += a; jacc += j
+    loss_r, acc_r, miou_r = ometrics.summarize(rec, acc, jacc, 2)
+    assert out['ii']['batches'] == 2
+    assert abs(out['ii']['jaccard'] - miou_r) <= 0.05            # north_star: mIoU within +-0.05
+    assert abs(out['ii']['acc'] - acc_r) <= 1e-3 and abs(out['ii']['loss'] - loss_r) <= 1e-4

@@ -1,0 +1,181 @@
+"""CPU: hand-computed known-answer tests pinning the oracle to the Lasagne/Theano semantics the
+hot path relies on (SURVEY.md 2.1 pins P1-P15, facts F1/F3/F4).  The reference ships no
+fixtures for this path, so these KATs (numbers derived by hand, written out below) plus the
+name-builder golden string are what the oracle is pinned by."""
+import numpy as np
+import pytest
+
+from oracle import dae as odae
+from oracle import fcn8 as ofcn8
+from oracle import metrics as ometrics
+from oracle import nn, refine
+from iterative_inference_segm_amd import synthetic as S
+
+
+def test_conv_is_cross_correlation_not_convolution():
+    """P1: flip_filters=False -> out[y,x] = sum w[ky,kx] * in[y+ky, x+kx]."""
+    x = np.arange(16, dtype=np.float64).reshape(1, 1, 4, 4)
+    w = np.zeros((1, 1, 3, 3)); w[0, 0, 0, 0] = 1.0; w[0, 0, 2, 1] = 10.0
+    out = nn.conv2d(x, w, np.array([0.5]), pad=0)
+    # out[0,0] = in[0,0] + 10*in[2,1] + .5 = 0 + 90 + .5 ; out[1,1] = in[1,1] + 10*in[3,2] + .5
+    assert out.shape == (1, 1, 2, 2)
+    assert out[0, 0, 0, 0] == 90.5 and out[0, 0, 1, 1] == 5 + 140 + 0.5
+
+
+def test_conv_pad_same_and_relu_default():
+    x = -np.ones((1, 1, 3, 3))
+    w = np.ones((2, 1, 3, 3)); w[1] *= -1
+    out = nn.conv2d(x, w, None, pad=1, relu=True)
+    assert out.shape == (1, 2, 3, 3)
+    assert np.all(out[0, 0] == 0)                    # negative sums are rectified
+    assert out[0, 1, 1, 1] == 9 and out[0, 1, 0, 0] == 4 and out[0, 1, 0, 1] == 6
+
+
+def test_c_conv_equals_blas_conv_and_is_translation_exact():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 5, 11, 13)); w = rng.standard_normal((7, 5, 3, 3)); b = rng.standard_normal(7)
+    a = nn.conv2d(x, w, b, pad=2, relu=True)
+    c = nn.conv2d_blas(x, w, b, pad=2, relu=True)
+    assert np.abs(a - c).max() < 1e-12
+    # equal patches -> bit-equal outputs wherever they sit (needed by the equality masks)
+    xc = np.full((1, 5, 40, 40), 0.37); xc[0, :, 20:, 20:] = rng.standard_normal((5, 20, 20))
+    o = nn.conv2d(xc, w, b, pad=1)
+    const_region = o[0, :, 1:18, 1:18]
+    assert np.all(const_region == const_region[:, :1, :1])
+
+
+def test_deconv_is_flipped_transposed_conv():
+    """P3: out[c, i*s+a, j*s+b] += x[o,i,j] * W[o,c,K-1-a,K-1-b]; a single 1 at (0,0) paints the
+    FLIPPED kernel."""
+    x = np.zeros((1, 1, 2, 2)); x[0, 0, 0, 0] = 1.0
+    w = np.arange(16, dtype=np.float64).reshape(1, 1, 4, 4)
+    out = nn.deconv2d(x, w, None, stride=2)
+    assert out.shape == (1, 1, 6, 6)
+    assert np.array_equal(out[0, 0, :4, :4], w[0, 0, ::-1, ::-1])
+    assert np.all(out[0, 0, 4:, :] == 0)
+    x[0, 0, 1, 1] = 2.0                                   # second impulse lands at (2,2), overlaps
+    out = nn.deconv2d(x, w, np.array([1.0]), stride=2)
+    assert out[0, 0, 2, 2] == w[0, 0, 1, 1] + 2 * w[0, 0, 3, 3] + 1.0
+
+
+def test_maxpool_ignore_border():
+    x = np.arange(25, dtype=np.float64).reshape(1, 1, 5, 5)
+    out = nn.maxpool2(x)
+    assert np.array_equal(out[0, 0], [[6, 8], [16, 18]])   # trailing row/col dropped (P4)
+
+
+def test_depool_is_an_equality_mask_with_all_ties():
+    """F4/P5: every position equal to the window max gets the value; odd trailing row/col = 0."""
+    pre = np.array([[[[1, 1, 0, 2, 9],
+                      [1, 0, 3, 2, 9],
+                      [5, 4, 0, 0, 9],
+                      [4, 5, 0, 0, 9],
+                      [7, 7, 7, 7, 9]]]], dtype=np.float64)
+    pooled = nn.maxpool2(pre)                              # [[1,3],[5,0]]
+    assert np.array_equal(pooled[0, 0], [[1, 3], [5, 0]])
+    up = np.array([[[[10, 20], [30, 40]]]], dtype=np.float64)
+    out = nn.depool_eqmask(up, pre, pooled)
+    expect = np.array([[10, 10, 0, 0, 0],
+                       [10, 0, 20, 0, 0],
+                       [30, 0, 40, 40, 0],
+                       [0, 30, 40, 40, 0],
+                       [0, 0, 0, 0, 0]], dtype=np.float64)
+    assert np.array_equal(out[0, 0], expect)
+
+
+def test_center_crop_offsets_of_the_fcn8_geometry():
+    """P6 + SURVEY 3.3: offsets (dim - target)//2: 5 (26->16), 9 (52->34), 28 (280->224), 99."""
+    for big, small, off in [(26, 16, 5), (52, 34, 9), (280, 224, 28), (422, 224, 99), (7, 4, 1)]:
+        x = np.arange(big, dtype=np.float64)[None, None, :, None] * np.ones((1, 1, big, big))
+        assert nn.center_crop(x, small, small)[0, 0, 0, 0] == off
+    a = np.ones((1, 1, 4, 6)); b = 2 * np.ones((1, 1, 6, 4))
+    assert nn.crop_sum(a, b).shape == (1, 1, 4, 4) and np.all(nn.crop_sum(a, b) == 3)
+    assert nn.crop_like(np.zeros((1, 1, 3, 3)), np.arange(25.).reshape(1, 1, 5, 5))[0, 0, 0, 0] == 6
+
+
+def test_softmax_and_concat_order():
+    x = np.log(np.array([1.0, 2.0, 5.0]))[None, :, None, None] * np.ones((1, 3, 2, 2))
+    p = nn.softmax_channels(x)
+    assert np.allclose(p[0, :, 0, 0], [0.125, 0.25, 0.625])
+    h = np.zeros((1, 2, 1, 1)); t = np.ones((1, 3, 1, 1))
+    assert list(nn.concat_h_first(h, t)[0, :, 0, 0]) == [0, 0, 1, 1, 1]      # h FIRST (P13)
+
+
+def test_fcn8_shapes_and_relu_on_scores():
+    """SURVEY 3.3 shape arithmetic at 224^2 on a narrow net, and P2 (ReLU on the score convs:
+    with all-negative score weights the class scores collapse to exact zeros -> uniform 1/C)."""
+    p = S.make_fcn8_params(width_div=32, fc_channels=8, seed=3)
+    x = S.make_images(1, 224, 224, seed=1).astype(np.float64)
+    p64 = {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in p.items()}
+    outs = ofcn8.fcn8_forward(p64, x, layer=['input', 'pool1', 'pool3', 'pool4', 'pool5',
+                                              'probs_dimshuffle'])
+    assert [o.shape[2] for o in outs] == [224, 211, 52, 26, 13, 224]
+    assert np.allclose(outs[-1].sum(1), 1.0)
+    for name in ('score_fr', 'score_pool4', 'score_pool3'):
+        W, b = p64[name]
+        p64[name] = (-np.abs(W), -np.abs(b))
+    p64['score2'] = (p64['score2'][0], 0 * p64['score2'][1])
+    p64['score4'] = (p64['score4'][0], 0 * p64['score4'][1])
+    p64['upsample'] = (p64['upsample'][0], 0 * p64['upsample'][1])
+    y = ofcn8.fcn8_forward(p64, x)[0]
+    assert np.allclose(y, 1.0 / 11)
+
+
+def test_dae_structure_and_param_order():
+    """6 pools for concat_h=['pool4'] + additional_pool=2; decoder channel
+    counts come from the encoder (fcn_up.py:30-34); h is concatenated after pool4 only."""
+    assert odae.param_order() == ['conv1_1', 'conv2_1', 'conv3_1', 'conv4_1', 'conv5_1', 'conv6_1',
+                                  'up_conv6', 'up_conv5', 'up_conv4', 'up_conv3', 'up_conv2',
+                                  'up_conv1']
+    dp = S.make_dae_params(n_filters=2, h_channels=(5,))
+    shapes = {k: v[0].shape for k, v in dp.items()}
+    assert shapes['conv5_1'] == (32, 16 + 5, 3, 3)          # h(5) + pool4(16)
+    assert shapes['conv6_1'] == (64, 32, 3, 3)
+    assert shapes['up_conv6'] == (32, 64, 3, 3) and shapes['up_conv5'] == (16, 32, 3, 3)
+    assert shapes['up_conv1'] == (11, 2, 3, 3)
+    y = np.random.default_rng(0).random((1, 11, 32, 32)); y /= y.sum(1, keepdims=True)
+    h = np.random.default_rng(1).random((1, 5, 14, 14))     # (32+198)/16 = 14
+    r, net = odae.dae_forward({k: tuple(np.asarray(a, np.float64) for a in v) for k, v in dp.items()},
+                              [h], y, n_filters=2, return_net=True)
+    assert r.shape == y.shape and np.allclose(r.sum(1), 1)
+    assert net['pool1'].shape[2:] == (115, 115) and net['pool6'].shape[2:] == (3, 3)
+    assert net['fused_up1'].shape == (1, 11, 32, 32)
+
+
+def test_refine_loop_update_then_test_early_stop():
+    """F1 + F3: y <- clip(y + step*(r - y)); the norm test happens AFTER the update of the same
+    iteration; with r == const the norms are hand-computable."""
+    target = np.zeros((1, 2, 1, 2)); target[0, 0] = 1.0                    # r = (1, 0) everywhere
+    y0 = np.full((1, 2, 1, 2), 0.5)
+    trace = []
+    y, iters = refine.refine_image(lambda h, y: target, [], y0, step=0.5, num_iter=10, eps=0.2,
+                                   trace=trace)
+    # grad_k = y_k - r; |y - r| per channel halves each step: 0.5, 0.25, 0.125, ...
+    # norm_k = sqrt(2)*0.5^(k+1): 0.707, 0.354, 0.177 (< 0.2 -> stop AFTER 3rd update)
+    assert iters == 3 and np.allclose(trace, [np.sqrt(2) * 0.5 ** (k + 1) for k in range(3)])
+    assert np.allclose(y[0, 0], 1 - 0.5 ** 4) and np.allclose(y[0, 1], 0.5 ** 4)
+    big = refine.refine_image(lambda h, y: 5 * target - 2, [], y0, step=1.0, num_iter=1)[0]
+    assert big.max() == 1.0 and big.min() == 0.0                           # clip to [0, 1]
+    Y, it = refine.refine_batch(lambda h, y: target[:1], [], np.concatenate([y0, target]), 0.5, 10,
+                                eps=0.2)
+    assert list(it) == [3, 1] and np.array_equal(Y[1], target[0])          # per-image stop
+
+
+def test_metrics_orientation_void_and_mse():
+    """metrics.py: rows = prediction, cols = truth; void-truth pixels never counted; acc masked;
+    mse = sum(mean_c((y-t)^2) * mask) / sum(mask)."""
+    C = 3
+    # 4 pixels: (pred, true) = (0,0) (1,0) (2,2) (1,void)
+    pred = [0, 1, 2, 1]; true = [0, 0, 2, 3]
+    y = np.zeros((1, C, 1, 4)); t = np.zeros((1, C + 1, 1, 4))
+    for i, (p, q) in enumerate(zip(pred, true)):
+        y[0, p, 0, i] = 1.0
+        t[0, q, 0, i] = 1.0
+    acc, jacc, mse = ometrics.val_fn(y, t, C, [C])
+    assert acc == pytest.approx(2 / 3)
+    # class0: TP 1, FP 0, FN 1 ; class1: TP 0, FP 1 (void-truth pixel NOT counted), FN 0 ; class2: 1
+    assert np.array_equal(jacc, [[1, 0, 1], [2, 1, 1]])
+    # per-pixel mean over 3 channels: 0, 2/3, 0, (void: masked out) -> (2/3) / 3 non-void pixels
+    assert mse == pytest.approx((2 / 3) / 3)
+    loss, a, j = ometrics.summarize(mse * 2, acc * 2, jacc * 2, 2)
+    assert (loss, a) == (pytest.approx(mse), pytest.approx(acc)) and j == pytest.approx((0.5 + 0 + 1) / 3)
