@@ -131,9 +131,33 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
                        additional_pool=dae_dict['additional_pool'], dropout=dae_dict['dropout'],
                        skip=dae_dict['skip'], unpool_type=dae_dict['unpool_type'],
                        bn=dae_dict['bn'], params=dae_params, device=device)
-    elif dae_dict['kind'] in ('fcn8', 'contextmod'):
-        raise NotImplementedError("dae kind '%s' has no HIP path yet (SURVEY 8a A8/A9)"
-                                  % dae_dict['kind'])
+    elif dae_dict['kind'] == 'fcn8':                             # :165-170
+        from iterative_inference_segm_amd.fcn8 import buildFCN8_DAE
+        dae_weights = os.path.join(loadpath, 'dae_model_best.npz')
+        dae_params = None
+        if not os.path.exists(dae_weights):
+            if not synthetic:
+                raise IOError('DAE weights not found: %s (use --synthetic)' % dae_weights)
+            dae_params = S.make_fcn8_dae_params(
+                n_classes, dae_dict['concat_h'],
+                tuple(h_channels[c] for c in dae_dict['concat_h']), seed=555)
+        dae = buildFCN8_DAE(n_classes=n_classes, nb_in_channels=n_classes, path_weights=loadpath,
+                            model_name='dae_model_best.npz', trainable=True, load_weights=True,
+                            concat_h=dae_dict['concat_h'], noise=dae_dict['noise'],
+                            params=dae_params, device=device)
+    elif dae_dict['kind'] == 'contextmod':                       # :171-177
+        from iterative_inference_segm_amd.contextmod import buildDAE_contextmod
+        dae_weights = os.path.join(loadpath, 'dae_model_best.npz')
+        dae_params = None
+        if not os.path.exists(dae_weights):
+            if not synthetic:
+                raise IOError('DAE weights not found: %s (use --synthetic)' % dae_weights)
+            dae_params = S.make_contextmod_params(n_classes, nb_in_channels, seed=777)
+        dae = buildDAE_contextmod(n_classes=n_classes, path_weights=loadpath,
+                                  model_name='dae_model_best.npz', trainable=True,
+                                  load_weights=True, out_nonlin='softmax',
+                                  noise=dae_dict['noise'], concat_h=dae_dict['concat_h'],
+                                  params=dae_params, device=device)
     else:
         raise ValueError('Unknown dae kind')                     # :178-179
 

@@ -1,0 +1,64 @@
+"""Context-module DAE on the HIP kernels (mirror of reference models/contextmod_dae.py:19-138):
+conv3x3(+ReLU) on [h=image, y] -> pad 32 -> six dilated 3x3 convs (dilation 1,2,4,8,16,1, ReLU)
+-> 1x1 linear -> softmax, 11 channels throughout.  The PadLayer is the `pad` of the first dilated
+conv; the concat is the two-source gather; everything runs on `conv_taps` (3x3 with dilation,
+DilatedConv2DLayer weight layout W[in,out,k,k], P11).  HBM/latency-bound (11 channels)."""
+import os
+
+from . import ops
+from .weights import load_param_list
+
+PARAM_ORDER = ['conv1'] + ['dilconv%d' % i for i in range(1, 8)]   # get_all_param_values (P14)
+DILATIONS = [1, 2, 4, 8, 16, 1]                                     # contextmod_dae.py:78-101
+
+
+class ContextModDAE:
+    def __init__(self, params, n_classes, concat_h=('input',), device='cuda'):
+        assert all(el in ['input'] for el in concat_h)               # contextmod_dae.py:42
+        if len(concat_h) != 1:
+            raise NotImplementedError('one h (the image) is concatenated at the input')
+        self.concat_h = list(concat_h)
+        self.conv1 = ops.Conv(params['conv1'][0], params['conv1'][1], pad=1, relu=True,
+                              device=device)                         # :74-76
+        self.dil = []
+        pad = 32                                                     # PadLayer(width=32), :77
+        for i, d in enumerate(DILATIONS):
+            W, b = params['dilconv%d' % (i + 1)]
+            self.dil.append(ops.Conv(W, b, pad=pad, relu=True, dil=d, layout='iohw', device=device))
+            pad = 0
+        W, b = params['dilconv7']
+        self.last = ops.Conv(W, b, pad=0, relu=False, layout='iohw', device=device)  # :102-105
+
+    def conv_layers(self):
+        d = {'conv1': self.conv1, 'dilconv7': self.last}
+        d.update({'dilconv%d' % (i + 1): c for i, c in enumerate(self.dil)})
+        return d
+
+    def scores(self, h_list, y, mask_override=None):
+        if len(h_list) != 1:
+            raise ValueError('expected 1 h tensor, got %d' % len(h_list))
+        t = self.conv1(h_list[0], x2=y)                              # h first (P13)
+        for conv in self.dil:
+            t = conv(t)
+        return self.last(t)
+
+    def __call__(self, *args):
+        score = self.scores(args[:-1], args[-1])
+        return ops.crop_softmax(score, score.shape[2], score.shape[3], off=(0, 0))
+
+    def residual(self, *args):
+        score = self.scores(args[:-1], args[-1])
+        return ops.crop_softmax(score, score.shape[2], score.shape[3], off=(0, 0),
+                                minuend=args[-1])
+
+
+def buildDAE_contextmod(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
+                        path_weights=None, model_name='dae_model.npz', trainable=False,
+                        load_weights=False, out_nonlin='softmax', concat_h=('input',), noise=0.1,
+                        params=None, device='cuda'):
+    """Mirror of models/contextmod_dae.py:19-23 (inference only: noise is the identity)."""
+    if params is None:
+        if not (load_weights and path_weights):
+            raise ValueError('buildDAE_contextmod needs `params` or `path_weights`')
+        params = load_param_list(os.path.join(path_weights, model_name), PARAM_ORDER)  # :127-132
+    return ContextModDAE(params, n_classes, concat_h=concat_h, device=device)

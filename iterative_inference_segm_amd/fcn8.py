@@ -58,14 +58,27 @@ class FCN8:
     def __call__(self, x):
         return self.forward(x)
 
-    def forward(self, x):
+    def forward(self, x, hs=None):
+        """hs: optional {concat point: h tensor} -- the buildFCN8_DAE wiring
+        (models/fcn8_dae.py:52-54,63-65,...): h is concatenated FIRST in front of the conv that
+        follows the concat point; fused as a two-source gather, never materialised."""
+        hs = hs or {}
         net = {'input': x}
         t = x
+        pending = hs.get('input')
         for bi, names in enumerate(_BLOCKS):
             for name in names:
-                t = self._conv(name, t)
+                if pending is not None:
+                    t = self._conv(name, pending, x2=t)
+                    pending = None
+                else:
+                    t = self._conv(name, t)
             net['pool%d' % (bi + 1)] = t = ops.maxpool2x2(t)     # :38,45,54,63,72
-        t = self._conv('fc6', t)       # dropout = identity at deterministic=True (P8)
+            pending = hs.get('pool%d' % (bi + 1))
+        if pending is not None:          # concat after pool5 feeds fc6 (7x7: table kernel)
+            t = self._conv('fc6', pending, x2=t)
+        else:
+            t = self._conv('fc6', t)   # dropout = identity at deterministic=True (P8)
         t = self._conv('fc7', t)
         t = self._conv('score_fr', t)
         # score_fused = score2 + score_pool4, both center-cropped to the common size (:94-97)
@@ -97,6 +110,47 @@ class FCN8:
         oh, ow = min(dh, sh), min(dw, sw)
         side = self._conv(score_name, pool, window=(_center(sh, oh), _center(sw, ow), oh, ow))
         return deconv(t, add=side, window=(_center(dh, oh), _center(dw, ow), oh, ow))
+
+
+class FCN8DAE:
+    """dae kind 'fcn8' (models/fcn8_dae.py:19-171): an FCN-8 on y with h concatenated at
+    `concat_h`.  Callable like pred_dae_fn(h..., y); `scores` gives the pre-softmax map."""
+
+    def __init__(self, params, n_classes, concat_h=('input',), pad=100, device='cuda'):
+        assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input'] for el in concat_h)  # :33-34
+        self.concat_h = list(concat_h)
+        self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device)
+
+    def conv_layers(self):
+        return self.net.convs
+
+    def scores(self, h_list, y, mask_override=None):
+        if len(h_list) != len(self.concat_h):
+            raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
+        return self.net.forward(y, hs=dict(zip(self.concat_h, h_list)))[0]
+
+    def __call__(self, *args):
+        score = self.scores(args[:-1], args[-1])
+        return ops.crop_softmax(score, score.shape[2], score.shape[3], off=(0, 0))
+
+    def residual(self, *args):
+        score = self.scores(args[:-1], args[-1])
+        return ops.crop_softmax(score, score.shape[2], score.shape[3], off=(0, 0),
+                                minuend=args[-1])
+
+
+def buildFCN8_DAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11, nb_in_channels=3,
+                  path_weights=None, model_name='fcn8_model.npz', trainable=False,
+                  load_weights=False, pretrained=False, freeze=False, pretrained_path=None,
+                  pascal=False, return_layer='probs_dimshuffle', concat_h=('input',), noise=0.1,
+                  dropout=0.5, params=None, device='cuda'):
+    """Mirror of models/fcn8_dae.py:19-26 (inference only: noise / dropout are identities)."""
+    import os
+    if params is None:
+        if not (load_weights and path_weights):
+            raise ValueError('buildFCN8_DAE needs `params` or `path_weights`')
+        params = load_param_list(os.path.join(path_weights, model_name), PARAM_ORDER)  # :174-178
+    return FCN8DAE(params, n_classes, concat_h=concat_h, device=device)
 
 
 def buildFCN8(nb_in_channels, input_var=None, path_weights=None, n_classes=21, load_weights=True,

@@ -116,6 +116,41 @@ def make_dae_params(n_classes=11, h_channels=(512,), concat_h=('pool4',), n_filt
     return p
 
 
+def make_contextmod_params(n_classes=11, h_channels=3, seed=777, jitter=0.05):
+    """Context-module parameters (models/contextmod_dae.py:61-105): identity-initialised
+    (IdentityInit, :61-72) plus a seeded perturbation so every tap matters.  conv1 is a
+    Conv2DLayer W[out,in,3,3]; dilconv* are DilatedConv2DLayer W[in,out,k,k] (P11)."""
+    rng = np.random.default_rng(seed)
+    p = {}
+    cin = n_classes + h_channels
+    p['conv1'] = (_he_uniform(rng, (n_classes, cin, 3, 3), cin * 9), _bias(rng, n_classes))
+    for i in range(1, 8):
+        k = 1 if i == 7 else 3
+        W = np.zeros((n_classes, n_classes, k, k), dtype=np.float32)
+        for c in range(n_classes):
+            W[c, c, k // 2, k // 2] = 1.0
+        W += rng.uniform(-jitter, jitter, size=W.shape).astype(np.float32)
+        p['dilconv%d' % i] = (W, _bias(rng, n_classes))
+    return p
+
+
+def make_fcn8_dae_params(n_classes=11, concat_h=('input',), h_channels=(3,), seed=555,
+                         width_div=1, fc_channels=4096):
+    """FCN-8-shaped DAE parameters (models/fcn8_dae.py:56-160): an FCN-8 on y (n_classes
+    channels) whose conv after each concat point takes h channels first."""
+    hch = dict(zip(concat_h, h_channels))
+    p = make_fcn8_params(n_classes + hch.get('input', 0), n_classes, seed=seed,
+                         width_div=width_div, fc_channels=fc_channels)
+    rng = np.random.default_rng(seed + 1)
+    nxt = {'pool1': 'conv2_1', 'pool2': 'conv3_1', 'pool3': 'conv4_1', 'pool4': 'conv5_1'}
+    for pool, conv in nxt.items():
+        if pool in hch:
+            W, b = p[conv]
+            cin = W.shape[1] + hch[pool]
+            p[conv] = (_he_uniform(rng, (W.shape[0], cin, 3, 3), cin * 9), b)
+    return p
+
+
 def make_images(n, h=224, w=224, channels=3, seed=1234):
     """Uniform [0,1) float32 RGB batch (N,C,H,W)."""
     rng = np.random.default_rng(seed)

@@ -19,4 +19,4 @@ product package `iterative_inference_segm_amd` must not import it (tests/test_bo
 greps for that).
 """
 
-from . import nn, fcn8, dae, refine, metrics, naming  # noqa: F401
+from . import nn, fcn8, dae, contextmod, refine, metrics, naming  # noqa: F401

@@ -166,3 +166,55 @@ def test_full_size_single_image(built_lib):
           % (frac_ok, agree, e.max()))
     assert list(host(iters)) == list(it_ref)
     assert agree >= 0.99 and e.mean() <= 1e-3
+
+
+def test_contextmod_dae_refine(built_lib):
+    """dae kind 'contextmod' (models/contextmod_dae.py): h = the image, pad-32 + dilated convs
+    (DilatedConv2DLayer layout), 5 refinement steps at 40x36, batch 2.  No pooling masks here, so
+    strict 1e-4 holds end to end."""
+    from oracle import contextmod as octx
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.contextmod import ContextModDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp = S.make_fcn8_params(width_div=16, fc_channels=32, seed=31)
+    cp = S.make_contextmod_params(seed=32)
+    ii = IterativeInference(FCN8(fp, 11, layer=['input', 'probs_dimshuffle']),
+                            ContextModDAE(cp, 11), 11, [11])
+    X = S.make_images(2, 40, 36, seed=33)
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    assert np.array_equal(host(H[0]), X)                       # h = net['input']
+    cp64 = to64(cp)
+    dae_fn = lambda hh, yy: octx.contextmod_forward(cp64, hh, yy)
+    h64, y64 = [X.astype(np.float64)], host(Y).astype(np.float64)
+    assert np.abs(host(ii.pred_dae_fn(*(H + [Y]))) - dae_fn(h64, y64)).max() <= TOL
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, h64, y64, 0.5, 5)
+    Yii, iters, _ = ii.refine(H, Y, 0.5, 5)
+    assert list(host(iters)) == list(it_ref)
+    assert np.abs(host(Yii) - yii_ref).max() <= TOL
+
+
+def test_fcn8_kind_dae(built_lib):
+    """dae kind 'fcn8' (models/fcn8_dae.py): FCN-8 on y with h concatenated at the input and
+    after pool3 (two-source gathers); r and 2 refinement steps vs the oracle."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.fcn8 import FCN8, FCN8DAE
+    concat_h = ['input', 'pool3']
+    fp = S.make_fcn8_params(width_div=16, fc_channels=32, seed=41)
+    c3 = fp['conv3_3'][0].shape[0]
+    dp = S.make_fcn8_dae_params(concat_h=concat_h, h_channels=(3, c3), seed=42, width_div=16,
+                                fc_channels=32)
+    ii = IterativeInference(FCN8(fp, 11, layer=concat_h + ['probs_dimshuffle']),
+                            FCN8DAE(dp, 11, concat_h=concat_h), 11, [11])
+    X = S.make_images(2, 32, 40, seed=43)
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    dp64 = to64(dp)
+    dae_fn = lambda hh, yy: ofcn8.fcn8_forward(dp64, yy, concat_h=concat_h, h_list=hh)[0]
+    h64 = [host(h).astype(np.float64) for h in H]
+    y64 = host(Y).astype(np.float64)
+    assert np.abs(host(ii.pred_dae_fn(*(H + [Y]))) - dae_fn(h64, y64)).max() <= TOL
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, h64, y64, 0.2, 2)
+    Yii, iters, _ = ii.refine(H, Y, 0.2, 2)
+    assert list(host(iters)) == list(it_ref)
+    assert np.abs(host(Yii) - yii_ref).max() <= TOL
