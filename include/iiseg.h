@@ -155,6 +155,39 @@ int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, 
 int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm, double* sums,
                         int32_t B, int32_t C, int32_t HW);
 
+/* ---------------------------------------------------------------------------------------
+ * float64 variants (strict-parity mode).  The reference's CPU path computes in float64 (Theano
+ * floatX default) and DePool2D compares activations for exact equality, so only
+ * float64 arithmetic reproduces its mask decisions at near-tied pooling windows.
+ * Same semantics and argument meaning as the _f32 entry points; tensors are float64.
+ * iiseg_conv_*_f64 cover 1x1 and 3x3 filters (v_mfma_f64_16x16x4_f64); other filter shapes go
+ * through iiseg_im2col_f64 + a 1x1 convolution (fc6 of models/fcn8.py:75-76), whose weight matrix
+ * is the reference W[out][in*KH*KW] as it lies in memory.  No gather table is needed.
+ * ------------------------------------------------------------------------------------- */
+int iiseg_conv_plan_f64(iiseg_conv_desc* d);
+int iiseg_conv_pack_f64(void* stream, const iiseg_conv_desc* d, const double* w, int64_t stride_o,
+                        int64_t stride_c, double* wp);
+int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const double* x1, const double* x2,
+                   const double* pre, const double* pooled, const double* wp, const double* bias,
+                   const double* add, double* out);
+/* x (B,C,H,W) -> out (B, C*KH*KW, H-KH+1, W-KW+1), channel index c*KH*KW + ky*KW + kx */
+int iiseg_im2col_f64(void* stream, const double* x, double* out, int32_t B, int32_t C, int32_t H,
+                     int32_t W, int32_t KH, int32_t KW);
+int iiseg_maxpool2x2_f64(void* stream, const double* x, double* out, int32_t BC, int32_t H,
+                         int32_t W);
+int iiseg_unpool_eqmask_f64(void* stream, const double* up, const double* pre,
+                            const double* pooled, double* out, int32_t BC, int32_t H, int32_t W);
+int iiseg_deconv_f64(void* stream, const iiseg_deconv_desc* d, const double* x, const double* w,
+                     const double* bias, const double* add, double* out);
+int iiseg_crop_softmax_f64(void* stream, const double* score, const double* minuend, double* out,
+                           int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0,
+                           int32_t sx0, int32_t H, int32_t W);
+int iiseg_refine_update_f64(void* stream, const double* score, double* y, const int32_t* active,
+                            double* partial, int32_t B, int32_t C, int32_t SH, int32_t SW,
+                            int32_t sy0, int32_t sx0, int32_t H, int32_t W, double step);
+int iiseg_confusion_f64(void* stream, const double* y, const double* t, int64_t* cm, double* sums,
+                        int32_t B, int32_t C, int32_t HW);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,17 @@ SIGNATURES = {
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
     'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    # float64 (strict-parity) variants
+    'iiseg_conv_plan_f64': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_pack_f64': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
+    'iiseg_conv_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 8),
+    'iiseg_im2col_f64': (C.c_int, [_vp, _vp, _vp] + [_i32] * 6),
+    'iiseg_maxpool2x2_f64': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
+    'iiseg_unpool_eqmask_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]),
+    'iiseg_deconv_f64': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),
+    'iiseg_crop_softmax_f64': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8),
+    'iiseg_refine_update_f64': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f64]),
+    'iiseg_confusion_f64': (C.c_int, [_vp] * 5 + [_i32] * 3),
 }
 
 _lib = None

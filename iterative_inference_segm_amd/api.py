@@ -48,8 +48,12 @@ class Metrics:
 class IterativeInference:
     """Bundles a segmentation net and a DAE and exposes the reference's four functions."""
 
-    def __init__(self, fcn, dae, n_classes, void_labels=(11,), device='cuda'):
+    def __init__(self, fcn, dae, n_classes, void_labels=(11,), device='cuda',
+                 dtype=torch.float32):
+        """dtype: torch.float32 (throughput path) or torch.float64 (strict-parity path, the
+        reference's CPU numerics); must match the dtype the nets were built with."""
         self.fcn, self.dae = fcn, dae
+        self.dtype = dtype
         self.n_classes = n_classes
         self.void_labels = list(void_labels)
         # the metrics kernel implements the one-hot/void-last contract of the reference's
@@ -105,8 +109,8 @@ class IterativeInference:
             t = a
         else:
             t = torch.from_numpy(np.ascontiguousarray(a))
-        if t.dtype != torch.float32:
-            t = t.to(torch.float32)
+        if t.dtype != self.dtype:
+            t = t.to(self.dtype)
         if not t.is_cuda:
             t = t.to(self.device, non_blocking=True)
         return t.contiguous()

@@ -5,6 +5,8 @@ conv; the concat is the two-source gather; everything runs on `conv_taps` (3x3 w
 DilatedConv2DLayer weight layout W[in,out,k,k], P11).  HBM/latency-bound (11 channels)."""
 import os
 
+import torch
+
 from . import ops
 from .weights import load_param_list
 
@@ -13,21 +15,24 @@ DILATIONS = [1, 2, 4, 8, 16, 1]                                     # contextmod
 
 
 class ContextModDAE:
-    def __init__(self, params, n_classes, concat_h=('input',), device='cuda'):
+    def __init__(self, params, n_classes, concat_h=('input',), device='cuda',
+                 dtype=torch.float32):
         assert all(el in ['input'] for el in concat_h)               # contextmod_dae.py:42
         if len(concat_h) != 1:
             raise NotImplementedError('one h (the image) is concatenated at the input')
         self.concat_h = list(concat_h)
         self.conv1 = ops.Conv(params['conv1'][0], params['conv1'][1], pad=1, relu=True,
-                              device=device)                         # :74-76
+                              device=device, dtype=dtype)                         # :74-76
         self.dil = []
         pad = 32                                                     # PadLayer(width=32), :77
         for i, d in enumerate(DILATIONS):
             W, b = params['dilconv%d' % (i + 1)]
-            self.dil.append(ops.Conv(W, b, pad=pad, relu=True, dil=d, layout='iohw', device=device))
+            self.dil.append(ops.Conv(W, b, pad=pad, relu=True, dil=d, layout='iohw', device=device,
+                                     dtype=dtype))
             pad = 0
         W, b = params['dilconv7']
-        self.last = ops.Conv(W, b, pad=0, relu=False, layout='iohw', device=device)  # :102-105
+        self.last = ops.Conv(W, b, pad=0, relu=False, layout='iohw', device=device,
+                             dtype=dtype)                                # :102-105
 
     def conv_layers(self):
         d = {'conv1': self.conv1, 'dilconv7': self.last}
@@ -55,10 +60,10 @@ class ContextModDAE:
 def buildDAE_contextmod(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
                         path_weights=None, model_name='dae_model.npz', trainable=False,
                         load_weights=False, out_nonlin='softmax', concat_h=('input',), noise=0.1,
-                        params=None, device='cuda'):
+                        params=None, device='cuda', dtype=torch.float32):
     """Mirror of models/contextmod_dae.py:19-23 (inference only: noise is the identity)."""
     if params is None:
         if not (load_weights and path_weights):
             raise ValueError('buildDAE_contextmod needs `params` or `path_weights`')
         params = load_param_list(os.path.join(path_weights, model_name), PARAM_ORDER)  # :127-132
-    return ContextModDAE(params, n_classes, concat_h=concat_h, device=device)
+    return ContextModDAE(params, n_classes, concat_h=concat_h, device=device, dtype=dtype)

@@ -11,18 +11,20 @@ namespace {
 
 constexpr int MAXC = 16;
 
+template <typename T>
 struct DeconvParams {
-    const float* x;
-    const float* w;
-    const float* bias;
-    const float* add;
-    float* out;
+    const T* x;
+    const T* w;
+    const T* bias;
+    const T* add;
+    T* out;
     int B, Cin, H, W, Cout, K, s;
     int oy0, ox0, OH, OW;
     int AH, AW, ay0, ax0;
 };
 
-__global__ __launch_bounds__(256) void deconv_gather_kernel(const DeconvParams p) {
+template <typename T>
+__global__ __launch_bounds__(256) void deconv_gather_kernel(const DeconvParams<T> p) {
     const int OHW = p.OH * p.OW;
     const size_t n = (size_t)p.B * OHW;
     const int KK = p.K * p.K;
@@ -32,10 +34,10 @@ __global__ __launch_bounds__(256) void deconv_gather_kernel(const DeconvParams p
         const int rem = (int)(i - (size_t)b * OHW);
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
         const int Y = p.oy0 + oy, X = p.ox0 + ox;
-        float acc[MAXC];
+        T acc[MAXC];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) acc[c] = (p.bias && c < p.Cout) ? p.bias[c] : 0.f;
-        const float* xb = p.x + (size_t)b * p.Cin * p.H * p.W;
+        for (int c = 0; c < MAXC; ++c) acc[c] = (p.bias && c < p.Cout) ? p.bias[c] : (T)0;
+        const T* xb = p.x + (size_t)b * p.Cin * p.H * p.W;
         for (int a = Y % p.s; a < p.K; a += p.s) {
             const int iy = (Y - a) / p.s;
             if (Y - a < 0 || iy >= p.H) continue;
@@ -44,16 +46,16 @@ __global__ __launch_bounds__(256) void deconv_gather_kernel(const DeconvParams p
                 if (X - bb < 0 || ix >= p.W) continue;
                 const int tap = (p.K - 1 - a) * p.K + (p.K - 1 - bb);
                 for (int o = 0; o < p.Cin; ++o) {
-                    const float xv = xb[((size_t)o * p.H + iy) * p.W + ix];
-                    const float* wr = p.w + (size_t)o * p.Cout * KK + tap;
+                    const T xv = xb[((size_t)o * p.H + iy) * p.W + ix];
+                    const T* wr = p.w + (size_t)o * p.Cout * KK + tap;
 #pragma unroll
                     for (int c = 0; c < MAXC; ++c)
-                        if (c < p.Cout) acc[c] = fmaf(xv, wr[(size_t)c * KK], acc[c]);
+                        if (c < p.Cout) acc[c] = fma(xv, wr[(size_t)c * KK], acc[c]);
                 }
             }
         }
-        float* op = p.out + (size_t)b * p.Cout * OHW + rem;
-        const float* ap = nullptr;
+        T* op = p.out + (size_t)b * p.Cout * OHW + rem;
+        const T* ap = nullptr;
         size_t AHW = 0;
         if (p.add) {
             AHW = (size_t)p.AH * p.AW;
@@ -62,17 +64,16 @@ __global__ __launch_bounds__(256) void deconv_gather_kernel(const DeconvParams p
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
             if (c < p.Cout) {
-                float v = acc[c];
+                T v = acc[c];
                 if (ap) v += ap[(size_t)c * AHW];
                 op[(size_t)c * OHW] = v;
             }
     }
 }
 
-}  // namespace
-
-extern "C" int iiseg_deconv_f32(void* stream, const iiseg_deconv_desc* d, const float* x,
-                                const float* w, const float* bias, const float* add, float* out) {
+template <typename T>
+int deconv(void* stream, const iiseg_deconv_desc* d, const T* x, const T* w, const T* bias,
+           const T* add, T* out) {
     if (!d || !x || !w || !out) return IISEG_ERR_NULL;
     if (d->B <= 0 || d->Cin <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->K <= 0 ||
         d->stride <= 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
@@ -82,7 +83,7 @@ extern "C" int iiseg_deconv_f32(void* stream, const iiseg_deconv_desc* d, const 
     if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
     if (add && (d->ay0 < 0 || d->ax0 < 0 || d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW))
         return IISEG_ERR_SHAPE;
-    DeconvParams p;
+    DeconvParams<T> p;
     p.x = x; p.w = w; p.bias = bias; p.add = add; p.out = out;
     p.B = d->B; p.Cin = d->Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.K = d->K;
     p.s = d->stride; p.oy0 = d->oy0; p.ox0 = d->ox0; p.OH = d->OH; p.OW = d->OW;
@@ -90,6 +91,18 @@ extern "C" int iiseg_deconv_f32(void* stream, const iiseg_deconv_desc* d, const 
     const size_t n = (size_t)d->B * d->OH * d->OW;
     size_t g = (n + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(deconv_gather_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(deconv_gather_kernel<T>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p);
     return iiseg_check_launch();
+}
+
+}  // namespace
+
+extern "C" int iiseg_deconv_f32(void* stream, const iiseg_deconv_desc* d, const float* x,
+                                const float* w, const float* bias, const float* add, float* out) {
+    return deconv<float>(stream, d, x, w, bias, add, out);
+}
+extern "C" int iiseg_deconv_f64(void* stream, const iiseg_deconv_desc* d, const double* x,
+                                const double* w, const double* bias, const double* add,
+                                double* out) {
+    return deconv<double>(stream, d, x, w, bias, add, out);
 }

@@ -9,8 +9,9 @@ namespace {
 
 constexpr int MAXC = 32;
 
-__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ y,
-                                                        const float* __restrict__ t,
+template <typename T>
+__global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
+                                                        const T* __restrict__ t,
                                                         unsigned long long* __restrict__ cm,
                                                         double* __restrict__ sums, int C, int HW) {
     __shared__ unsigned int bins[MAXC * (MAXC + 1)];
@@ -22,23 +23,23 @@ __global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict_
     const int b = blockIdx.y;
     double se = 0.0, mk = 0.0;
     if (pix < HW) {
-        const float* yp = y + (size_t)b * C * HW + pix;
-        const float* tp = t + (size_t)b * (C + 1) * HW + pix;
+        const T* yp = y + (size_t)b * C * HW + pix;
+        const T* tp = t + (size_t)b * (C + 1) * HW + pix;
         // argmax returns the FIRST maximal index (T.argmax / np.argmax)
         int ip = 0, it = 0;
-        float bp = yp[0], bt = tp[0];
-        float msum = 0.f, esum = 0.f;
+        T bp = yp[0], bt = tp[0];
+        T msum = 0, esum = 0;
         for (int c = 0; c < C; ++c) {
-            const float yv = yp[(size_t)c * HW], tv = tp[(size_t)c * HW];
+            const T yv = yp[(size_t)c * HW], tv = tp[(size_t)c * HW];
             if (yv > bp) { bp = yv; ip = c; }
             if (tv > bt) { bt = tv; it = c; }
             msum += tv;                       // mask = y_true[:, :void].sum(1)   metrics.py:148
-            esum = fmaf(yv - tv, yv - tv, esum);
+            esum = fma(yv - tv, yv - tv, esum);
         }
-        const float tvoid = tp[(size_t)C * HW];
+        const T tvoid = tp[(size_t)C * HW];
         if (tvoid > bt) it = C;
         atomicAdd(&bins[ip * (C + 1) + it], 1u);
-        se = (double)(esum / (float)C) * (double)msum;  // .mean(axis=1) * mask   :147,153
+        se = (double)(esum / (T)C) * (double)msum;  // .mean(axis=1) * mask   :147,153
         mk = (double)msum;
     }
     se = wave_sum(se);
@@ -56,15 +57,25 @@ __global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict_
     }
 }
 
+template <typename T>
+int confusion(void* stream, const T* y, const T* t, int64_t* cm, double* sums, int32_t B, int32_t C,
+              int32_t HW) {
+    if (!y || !t || !cm || !sums) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
+    if (C >= MAXC || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(confusion_kernel<T>, dim3((HW + 255) / 256, B), dim3(256), 0,
+                       (hipStream_t)stream, y, t, reinterpret_cast<unsigned long long*>(cm), sums,
+                       C, HW);
+    return iiseg_check_launch();
+}
+
 }  // namespace
 
 extern "C" int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm,
                                    double* sums, int32_t B, int32_t C, int32_t HW) {
-    if (!y || !t || !cm || !sums) return IISEG_ERR_NULL;
-    if (B <= 0 || C <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
-    if (C >= MAXC || B > 65535) return IISEG_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(confusion_kernel, dim3((HW + 255) / 256, B), dim3(256), 0,
-                       (hipStream_t)stream, y, t, reinterpret_cast<unsigned long long*>(cm), sums,
-                       C, HW);
-    return iiseg_check_launch();
+    return confusion<float>(stream, y, t, cm, sums, B, C, HW);
+}
+extern "C" int iiseg_confusion_f64(void* stream, const double* y, const double* t, int64_t* cm,
+                                   double* sums, int32_t B, int32_t C, int32_t HW) {
+    return confusion<double>(stream, y, t, cm, sums, B, C, HW);
 }

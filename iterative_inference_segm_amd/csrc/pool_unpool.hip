@@ -1,13 +1,14 @@
-// 2x2 max-pool (ignore_border) and the materialised equality-mask unpool.  HBM-bound
-// element-wise kernels: one output element per thread-iteration, lanes along x.
+// 2x2 max-pool (ignore_border) and the materialised equality-mask unpool, float32 and float64.
+// HBM-bound element-wise kernels: one output element per thread-iteration, lanes along x.
 // Replaces Pool2DLayer (reference models/fcn8.py:38-72, models/fcn_down.py:122) and
 // DePool2D.get_output_for (layers/mylayers.py:88-115); see include/iiseg.h.
 #include "common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x,
-                                                         float* __restrict__ out, int BC, int H,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const T* __restrict__ x,
+                                                         T* __restrict__ out, int BC, int H,
                                                          int W, int h, int w) {
     const size_t n = (size_t)BC * h * w;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
@@ -16,17 +17,20 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
         const size_t t = i / w;
         const int oy = (int)(t % h);
         const size_t bc = t / h;
-        const float* r0 = x + (bc * H + 2 * oy) * (size_t)W + 2 * ox;
-        const float* r1 = r0 + W;
-        out[i] = fmaxf(fmaxf(r0[0], r0[1]), fmaxf(r1[0], r1[1]));
+        const T* r0 = x + (bc * H + 2 * oy) * (size_t)W + 2 * ox;
+        const T* r1 = r0 + W;
+        const T a = r0[0] > r0[1] ? r0[0] : r0[1];
+        const T b = r1[0] > r1[1] ? r1[0] : r1[1];
+        out[i] = a > b ? a : b;
     }
 }
 
-__global__ __launch_bounds__(256) void unpool_eqmask_kernel(const float* __restrict__ up,
-                                                            const float* __restrict__ pre,
-                                                            const float* __restrict__ pooled,
-                                                            float* __restrict__ out, int BC,
-                                                            int H, int W, int h, int w) {
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_eqmask_kernel(const T* __restrict__ up,
+                                                            const T* __restrict__ pre,
+                                                            const T* __restrict__ pooled,
+                                                            T* __restrict__ out, int BC, int H,
+                                                            int W, int h, int w) {
     const size_t n = (size_t)BC * H * W;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -34,10 +38,10 @@ __global__ __launch_bounds__(256) void unpool_eqmask_kernel(const float* __restr
         const size_t t = i / W;
         const int y = (int)(t % H);
         const size_t bc = t / H;
-        float v = 0.f;
+        T v = 0;
         if (y < 2 * h && x < 2 * w) {
             const size_t j = (bc * h + (y >> 1)) * (size_t)w + (x >> 1);
-            v = (pre[i] == pooled[j]) ? up[j] : 0.f;
+            v = (pre[i] == pooled[j]) ? up[j] : (T)0;
         }
         out[i] = v;
     }
@@ -48,24 +52,43 @@ inline int grid_for(size_t n) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
-}  // namespace
-
-extern "C" int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC,
-                                    int32_t H, int32_t W) {
+template <typename T>
+int maxpool(void* stream, const T* x, T* out, int32_t BC, int32_t H, int32_t W) {
     if (!x || !out) return IISEG_ERR_NULL;
     if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
     const int h = H / 2, w = W / 2;
-    hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for((size_t)BC * h * w)), dim3(256), 0,
+    hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid_for((size_t)BC * h * w)), dim3(256), 0,
                        (hipStream_t)stream, x, out, BC, H, W, h, w);
     return iiseg_check_launch();
 }
 
+template <typename T>
+int unpool(void* stream, const T* up, const T* pre, const T* pooled, T* out, int32_t BC, int32_t H,
+           int32_t W) {
+    if (!up || !pre || !pooled || !out) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(unpool_eqmask_kernel<T>, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
+                       (hipStream_t)stream, up, pre, pooled, out, BC, H, W, H / 2, W / 2);
+    return iiseg_check_launch();
+}
+
+}  // namespace
+
+extern "C" int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC,
+                                    int32_t H, int32_t W) {
+    return maxpool<float>(stream, x, out, BC, H, W);
+}
+extern "C" int iiseg_maxpool2x2_f64(void* stream, const double* x, double* out, int32_t BC,
+                                    int32_t H, int32_t W) {
+    return maxpool<double>(stream, x, out, BC, H, W);
+}
 extern "C" int iiseg_unpool_eqmask_f32(void* stream, const float* up, const float* pre,
                                        const float* pooled, float* out, int32_t BC, int32_t H,
                                        int32_t W) {
-    if (!up || !pre || !pooled || !out) return IISEG_ERR_NULL;
-    if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(unpool_eqmask_kernel, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
-                       (hipStream_t)stream, up, pre, pooled, out, BC, H, W, H / 2, W / 2);
-    return iiseg_check_launch();
+    return unpool<float>(stream, up, pre, pooled, out, BC, H, W);
+}
+extern "C" int iiseg_unpool_eqmask_f64(void* stream, const double* up, const double* pre,
+                                       const double* pooled, double* out, int32_t BC, int32_t H,
+                                       int32_t W) {
+    return unpool<double>(stream, up, pre, pooled, out, BC, H, W);
 }

@@ -9,32 +9,37 @@
 
 namespace {
 
-template <int CMAX>
-__device__ inline void load_softmax(const float* sp, size_t cstride, int C, float (&r)[CMAX]) {
-    float m = -INFINITY;
+__device__ inline float exp_t(float x) { return expf(x); }
+__device__ inline double exp_t(double x) { return exp(x); }
+__device__ inline float sqrt_t(float x) { return sqrtf(x); }
+__device__ inline double sqrt_t(double x) { return sqrt(x); }
+
+template <int CMAX, typename T>
+__device__ inline void load_softmax(const T* sp, size_t cstride, int C, T (&r)[CMAX]) {
+    T m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) {
             r[c] = sp[(size_t)c * cstride];
-            m = fmaxf(m, r[c]);
+            m = r[c] > m ? r[c] : m;
         }
-    float s = 0.f;
+    T s = 0;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) {
-            r[c] = expf(r[c] - m);
+            r[c] = exp_t(r[c] - m);
             s += r[c];
         }
-    const float inv = 1.f / s;
+    const T inv = (T)1 / s;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) r[c] *= inv;
 }
 
-template <int CMAX>
-__global__ __launch_bounds__(256) void crop_softmax_kernel(const float* __restrict__ score,
-                                                           const float* __restrict__ minuend,
-                                                           float* __restrict__ out, int C, int SH,
+template <int CMAX, typename T>
+__global__ __launch_bounds__(256) void crop_softmax_kernel(const T* __restrict__ score,
+                                                           const T* __restrict__ minuend,
+                                                           T* __restrict__ out, int C, int SH,
                                                            int SW, int sy0, int sx0, int H, int W) {
     const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -42,50 +47,50 @@ __global__ __launch_bounds__(256) void crop_softmax_kernel(const float* __restri
     if (pix >= HW) return;
     const int y = pix / W, x = pix - y * W;
     const size_t SHW = (size_t)SH * SW;
-    const float* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
-    float r[CMAX];
-    load_softmax<CMAX>(sp, SHW, C, r);
-    float* op = out + (size_t)b * C * HW + pix;
-    const float* mp = minuend ? minuend + (size_t)b * C * HW + pix : nullptr;
+    const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+    T r[CMAX];
+    load_softmax<CMAX, T>(sp, SHW, C, r);
+    T* op = out + (size_t)b * C * HW + pix;
+    const T* mp = minuend ? minuend + (size_t)b * C * HW + pix : nullptr;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) op[(size_t)c * HW] = mp ? mp[(size_t)c * HW] - r[c] : r[c];
 }
 
-template <int CMAX>
-__global__ __launch_bounds__(256) void refine_update_kernel(const float* __restrict__ score,
-                                                            float* __restrict__ yio,
+template <int CMAX, typename T>
+__global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict__ score,
+                                                            T* __restrict__ yio,
                                                             const int* __restrict__ active,
                                                             double* __restrict__ partial, int C,
                                                             int SH, int SW, int sy0, int sx0, int H,
-                                                            int W, float step) {
+                                                            int W, T step) {
     __shared__ double red[4];
     const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     const bool act = active[b] != 0;
-    float nrm = 0.f;
+    T nrm = 0;
     if (pix < HW) {
         const int y = pix / W, x = pix - y * W;
         const size_t SHW = (size_t)SH * SW;
-        const float* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
-        float r[CMAX];
-        load_softmax<CMAX>(sp, SHW, C, r);
-        float* yp = yio + (size_t)b * C * HW + pix;
-        float ss = 0.f;
+        const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+        T r[CMAX];
+        load_softmax<CMAX, T>(sp, SHW, C, r);
+        T* yp = yio + (size_t)b * C * HW + pix;
+        T ss = 0;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
             if (c < C) {
-                const float yv = yp[(size_t)c * HW];
-                const float de = yv - r[c];  // iterative_inference.py:203-204
-                ss = fmaf(de, de, ss);
+                const T yv = yp[(size_t)c * HW];
+                const T de = yv - r[c];  // iterative_inference.py:203-204
+                ss = fma(de, de, ss);
                 if (act) {
-                    float yn = yv - step * de;  // :270
-                    yn = fminf(fmaxf(yn, 0.f), 1.f);  // :273
+                    T yn = yv - step * de;  // :270
+                    yn = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);  // :273
                     yp[(size_t)c * HW] = yn;
                 }
             }
-        nrm = sqrtf(ss);  // np.linalg.norm(grad, axis=1), :275
+        nrm = sqrt_t(ss);  // np.linalg.norm(grad, axis=1), :275
     }
     double d = wave_sum((double)nrm);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
@@ -107,23 +112,52 @@ __global__ void refine_finalize_kernel(const double* __restrict__ partial, int* 
     }
 }
 
-}  // namespace
-
-extern "C" int iiseg_crop_softmax_f32(void* stream, const float* score, const float* minuend,
-                                      float* out, int32_t B, int32_t C, int32_t SH, int32_t SW,
-                                      int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+template <typename T>
+int crop_softmax(void* stream, const T* score, const T* minuend, T* out, int32_t B, int32_t C,
+                 int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
     if (!score || !out) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
         return IISEG_ERR_SHAPE;
     if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
-        hipLaunchKernelGGL(crop_softmax_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, score,
-                           minuend, out, C, SH, SW, sy0, sx0, H, W);
+        hipLaunchKernelGGL((crop_softmax_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
+                           score, minuend, out, C, SH, SW, sy0, sx0, H, W);
     else
-        hipLaunchKernelGGL(crop_softmax_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, score,
-                           minuend, out, C, SH, SW, sy0, sx0, H, W);
+        hipLaunchKernelGGL((crop_softmax_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
+                           score, minuend, out, C, SH, SW, sy0, sx0, H, W);
     return iiseg_check_launch();
+}
+
+template <typename T>
+int refine_update(void* stream, const T* score, T* y, const int32_t* active, double* partial,
+                  int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
+                  int32_t W, T step) {
+    if (!score || !y || !active || !partial) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
+        return IISEG_ERR_SHAPE;
+    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    const dim3 grid((H * W + 255) / 256, B);
+    if (C <= 16)
+        hipLaunchKernelGGL((refine_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
+                           score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+    else
+        hipLaunchKernelGGL((refine_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
+                           score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+    return iiseg_check_launch();
+}
+
+}  // namespace
+
+extern "C" int iiseg_crop_softmax_f32(void* stream, const float* score, const float* minuend,
+                                      float* out, int32_t B, int32_t C, int32_t SH, int32_t SW,
+                                      int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+    return crop_softmax<float>(stream, score, minuend, out, B, C, SH, SW, sy0, sx0, H, W);
+}
+extern "C" int iiseg_crop_softmax_f64(void* stream, const double* score, const double* minuend,
+                                      double* out, int32_t B, int32_t C, int32_t SH, int32_t SW,
+                                      int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+    return crop_softmax<double>(stream, score, minuend, out, B, C, SH, SW, sy0, sx0, H, W);
 }
 
 extern "C" int iiseg_refine_partials(int32_t H, int32_t W) { return (H * W + 255) / 256; }
@@ -132,18 +166,13 @@ extern "C" int iiseg_refine_update_f32(void* stream, const float* score, float* 
                                        const int32_t* active, double* partial, int32_t B, int32_t C,
                                        int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
                                        int32_t W, float step) {
-    if (!score || !y || !active || !partial) return IISEG_ERR_NULL;
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
-        return IISEG_ERR_SHAPE;
-    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
-    const dim3 grid((H * W + 255) / 256, B);
-    if (C <= 16)
-        hipLaunchKernelGGL(refine_update_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, score,
-                           y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
-    else
-        hipLaunchKernelGGL(refine_update_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, score,
-                           y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
-    return iiseg_check_launch();
+    return refine_update<float>(stream, score, y, active, partial, B, C, SH, SW, sy0, sx0, H, W, step);
+}
+extern "C" int iiseg_refine_update_f64(void* stream, const double* score, double* y,
+                                       const int32_t* active, double* partial, int32_t B, int32_t C,
+                                       int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
+                                       int32_t W, double step) {
+    return refine_update<double>(stream, score, y, active, partial, B, C, SH, SW, sy0, sx0, H, W, step);
 }
 
 extern "C" int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active,

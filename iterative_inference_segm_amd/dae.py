@@ -38,7 +38,7 @@ class StandardDAE:
 
     def __init__(self, params, n_classes, concat_h=('pool4',), padding=100, n_filters=64,
                  conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind', bn=0,
-                 device='cuda'):
+                 device='cuda', dtype=torch.float32):
         concat_h = list(concat_h)
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
                    for el in concat_h)                                   # fcn_down.py:39-41
@@ -65,11 +65,11 @@ class StandardDAE:
                 name = 'conv%d_%d' % (p + 1, i)
                 self.enc[name] = ops.Conv(params[name][0], params[name][1],
                                           pad=padding if first_pad else 1, relu=True,
-                                          device=device)                 # :102-104
+                                          device=device, dtype=dtype)                 # :102-104
         for p in range(self.total, 0, -1):
             name = 'up_conv%d' % p
             self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
-                                      device=device)                     # fcn_up.py:83-86
+                                      device=device, dtype=dtype)                     # fcn_up.py:83-86
         self.conv_log = None
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
 
@@ -159,7 +159,7 @@ def buildDAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
              path_weights=None, model_name='dae_model.npz', trainable=False, load_weights=False,
              out_nonlin='softmax', concat_h=('input',), noise=0.1, n_filters=64,
              conv_before_pool=1, additional_pool=0, dropout=0., skip=False,
-             unpool_type='standard', bn=0, params=None, device='cuda'):
+             unpool_type='standard', bn=0, params=None, device='cuda', dtype=torch.float32):
     """Mirror of models/DAE_h.py:12-20.  Inference only: `noise`, `dropout` are identities at
     deterministic=True (P8, P9; masks are the deterministic ones); the symbolic
     `input_*_var`, `trainable`, `ae_h`, `void_labels` are accepted and ignored."""
@@ -173,4 +173,4 @@ def buildDAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
         raise NotImplementedError('inference uses out_nonlin=softmax (iterative_inference.py:158)')
     return StandardDAE(params, n_classes, concat_h=concat_h, padding=padding, n_filters=n_filters,
                        conv_before_pool=conv_before_pool, additional_pool=additional_pool,
-                       skip=skip, unpool_type=unpool_type, bn=bn, device=device)
+                       skip=skip, unpool_type=unpool_type, bn=bn, device=device, dtype=dtype)

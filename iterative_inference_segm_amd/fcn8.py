@@ -26,14 +26,15 @@ def _center(big, small):
 
 class FCN8:
     def __init__(self, params, n_classes, layer=('probs_dimshuffle',), pad=100, temperature=1.0,
-                 device='cuda'):
+                 device='cuda', dtype=torch.float32):
         self.layer = list(layer)
         self.n_classes = n_classes
         self.pad = pad
         self.device = device
+        self.dtype = dtype
         p = params
         c = lambda name, pad_, relu=True: ops.Conv(p[name][0], p[name][1], pad=pad_, relu=relu,
-                                                   device=device)
+                                                   device=device, dtype=dtype)
         self.convs = {}
         for bi, names in enumerate(_BLOCKS):
             for ni, name in enumerate(names):
@@ -44,12 +45,12 @@ class FCN8:
         self.convs['score_fr'] = c('score_fr', 0)  # :84-85 default nonlinearity = ReLU (P2)
         self.convs['score_pool4'] = c('score_pool4', 0)  # :92-93 1x1, ReLU (P2)
         self.convs['score_pool3'] = c('score_pool3', 0)  # :102-103
-        self.score2 = ops.Deconv(p['score2'][0], p['score2'][1], 2, device=device)    # :90-91
-        self.score4 = ops.Deconv(p['score4'][0], p['score4'][1], 2, device=device)    # :100-101
+        self.score2 = ops.Deconv(p['score2'][0], p['score2'][1], 2, device=device, dtype=dtype)    # :90-91
+        self.score4 = ops.Deconv(p['score4'][0], p['score4'][1], 2, device=device, dtype=dtype)    # :100-101
         Wu, bu = p['upsample']
         # temperature divides upsample.W and upsample.b (:194-198)
         self.upsample = ops.Deconv(np.asarray(Wu) / temperature, np.asarray(bu) / temperature, 8,
-                                   device=device)                                      # :109-110
+                                   device=device, dtype=dtype)                                      # :109-110
         self.conv_log = None  # optional list collecting (name, flops) per conv launch
 
     def conv_layers(self):
@@ -116,10 +117,11 @@ class FCN8DAE:
     """dae kind 'fcn8' (models/fcn8_dae.py:19-171): an FCN-8 on y with h concatenated at
     `concat_h`.  Callable like pred_dae_fn(h..., y); `scores` gives the pre-softmax map."""
 
-    def __init__(self, params, n_classes, concat_h=('input',), pad=100, device='cuda'):
+    def __init__(self, params, n_classes, concat_h=('input',), pad=100, device='cuda',
+                 dtype=torch.float32):
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input'] for el in concat_h)  # :33-34
         self.concat_h = list(concat_h)
-        self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device)
+        self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype)
 
     def conv_layers(self):
         return self.net.convs
@@ -143,19 +145,20 @@ def buildFCN8_DAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11, n
                   path_weights=None, model_name='fcn8_model.npz', trainable=False,
                   load_weights=False, pretrained=False, freeze=False, pretrained_path=None,
                   pascal=False, return_layer='probs_dimshuffle', concat_h=('input',), noise=0.1,
-                  dropout=0.5, params=None, device='cuda'):
+                  dropout=0.5, params=None, device='cuda', dtype=torch.float32):
     """Mirror of models/fcn8_dae.py:19-26 (inference only: noise / dropout are identities)."""
     import os
     if params is None:
         if not (load_weights and path_weights):
             raise ValueError('buildFCN8_DAE needs `params` or `path_weights`')
         params = load_param_list(os.path.join(path_weights, model_name), PARAM_ORDER)  # :174-178
-    return FCN8DAE(params, n_classes, concat_h=concat_h, device=device)
+    return FCN8DAE(params, n_classes, concat_h=concat_h, device=device, dtype=dtype)
 
 
 def buildFCN8(nb_in_channels, input_var=None, path_weights=None, n_classes=21, load_weights=True,
               void_labels=(), trainable=False, layer=('probs_dimshuffle',), pascal=False,
-              temperature=1.0, dropout=0.5, params=None, pad=100, device='cuda'):
+              temperature=1.0, dropout=0.5, params=None, pad=100, device='cuda',
+              dtype=torch.float32):
     """Mirror of models/fcn8.py:16-23.  Weights come from `params` (dict name -> (W, b)) or from
     an `arr_%d` .npz at `path_weights` in get_all_param_values order (:178-180).  `input_var`,
     `trainable`, `dropout` are accepted for signature compatibility (inference only: dropout is
@@ -170,4 +173,5 @@ def buildFCN8(nb_in_channels, input_var=None, path_weights=None, n_classes=21, l
     if w0.shape[1] != nb_in_channels:
         raise ValueError('conv1_1 expects %d input channels, nb_in_channels=%d'
                          % (w0.shape[1], nb_in_channels))
-    return FCN8(params, n_classes, layer=layer, pad=pad, temperature=temperature, device=device)
+    return FCN8(params, n_classes, layer=layer, pad=pad, temperature=temperature, device=device,
+                dtype=dtype)

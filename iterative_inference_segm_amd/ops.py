@@ -2,7 +2,8 @@
 
 torch is plumbing here (device memory + the current HIP stream); every arithmetic op is a
 call through the C ABI (include/iiseg.h).  All ops enqueue on torch's current stream and
-never synchronise.
+never synchronise.  Two arithmetic modes: float32 (throughput path) and float64 (strict-parity
+path: the reference's CPU numerics), selected by the tensors' dtype.
 """
 import ctypes as C
 
@@ -11,10 +12,11 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, check
 
-
-# When set to a list, every conv launch appends (executed_flops, start_event, end_event):
+# When set to a list, every conv launch appends (kernel, executed_flops, start_event, end_event):
 # HIP events recorded on the launch stream right around the kernel (bench.py's roofline leg).
 CONV_PROFILE = None
+
+_SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
 
 
 def _stream():
@@ -36,15 +38,23 @@ def _ptr(t, dtype=torch.float32):
     return C.c_void_p(t.data_ptr())
 
 
+def _fn(name, dtype):
+    """C entry point `iiseg_<name>_<f32|f64>` for a tensor dtype."""
+    if dtype not in _SUFFIX:
+        raise RuntimeError('iiseg ops support float32 and float64, not %s' % dtype)
+    return getattr(_lib.load(), 'iiseg_%s_%s' % (name, _SUFFIX[dtype]))
+
+
 class Conv:
-    """One convolution layer bound to its weights: packed-weight + gather-table cache per
+    """One convolution layer bound to its weights: packed-weight (+ gather-table) cache per
     input geometry.  Weight layouts: 'oihw' (Lasagne Conv2DLayer W[out,in,kh,kw], P1) or
     'iohw' (DilatedConv2DLayer W[in,out,kh,kw], P11)."""
 
-    def __init__(self, W, b, pad, relu, dil=1, layout='oihw', device='cuda'):
+    def __init__(self, W, b, pad, relu, dil=1, layout='oihw', device='cuda', dtype=torch.float32):
         self.lib = _lib.load()
-        self.W = torch.as_tensor(W, dtype=torch.float32).contiguous().to(device)
-        self.b = None if b is None else torch.as_tensor(b, dtype=torch.float32).contiguous().to(device)
+        self.dtype = dtype
+        self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
+        self.b = None if b is None else torch.as_tensor(b).to(dtype).contiguous().to(device)
         if layout == 'oihw':
             self.Cout, self.Cin, self.KH, self.KW = self.W.shape
             self.so, self.sc = self.Cin * self.KH * self.KW, self.KH * self.KW
@@ -54,6 +64,18 @@ class Conv:
         else:
             raise ValueError(layout)
         self.pad, self.dil, self.relu = int(pad), int(dil), bool(relu)
+        taps = (self.KH, self.KW) in ((1, 1), (3, 3))
+        # which kernel family the C ABI dispatches this filter shape to
+        if dtype == torch.float64:
+            self.kernel = 'conv_taps_f64_kernel'
+            # other filter shapes (7x7 fc6): im2col + the same weights as a 1x1 convolution
+            self.via_im2col = not taps
+            if self.via_im2col and (layout != 'oihw' or self.pad != 0 or self.dil != 1):
+                raise NotImplementedError('float64 path: only valid, undilated oihw KxK filters '
+                                          'go through im2col')
+        else:
+            self.kernel = 'conv_taps_f32_kernel' if taps else 'conv_igemm_f32_kernel'
+            self.via_im2col = False
         self._plans = {}
 
     def out_hw(self, H, W):
@@ -80,13 +102,25 @@ class Conv:
         if add_geom is not None:
             d.AH, d.AW, d.ay0, d.ax0 = add_geom
         d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0)
-        check(self.lib.iiseg_conv_plan(C.byref(d)), 'iiseg_conv_plan')
-        # weights depend on (C1, C2) only through the table; share one packed copy per Mpad
-        wp = torch.empty(d.Kpad * d.Mpad, dtype=torch.float32, device=self.W.device)
-        ktab = torch.empty(d.Kpad * 4, dtype=torch.int32, device=self.W.device)
-        check(self.lib.iiseg_conv_pack_f32(_stream(), C.byref(d), _ptr(self.W), self.so, self.sc,
-                                           _ptr(wp), _ptr(ktab, torch.int32)),
-              'iiseg_conv_pack_f32')
+        so, sc = self.so, self.sc
+        if self.via_im2col:
+            # logical layer: 1x1 over C*KH*KW channels of the im2col'd tensor (OH x OW)
+            d.C1, d.C2, d.H, d.W = C1 * self.KH * self.KW, 0, fullH, fullW
+            d.KH = d.KW = 1
+            so, sc = self.Cin * self.KH * self.KW, 1
+        if self.dtype == torch.float64:
+            check(self.lib.iiseg_conv_plan_f64(C.byref(d)), 'iiseg_conv_plan_f64')
+            wp = torch.empty(d.Kpad * d.Mpad, dtype=self.dtype, device=self.W.device)
+            ktab = None
+            check(self.lib.iiseg_conv_pack_f64(_stream(), C.byref(d), _ptr(self.W, self.dtype), so,
+                                               sc, _ptr(wp, self.dtype)), 'iiseg_conv_pack_f64')
+        else:
+            check(self.lib.iiseg_conv_plan(C.byref(d)), 'iiseg_conv_plan')
+            wp = torch.empty(d.Kpad * d.Mpad, dtype=self.dtype, device=self.W.device)
+            ktab = torch.empty(d.Kpad * 4, dtype=torch.int32, device=self.W.device)
+            check(self.lib.iiseg_conv_pack_f32(_stream(), C.byref(d), _ptr(self.W), so, sc,
+                                               _ptr(wp), _ptr(ktab, torch.int32)),
+                  'iiseg_conv_pack_f32')
         plan = (d, wp, ktab)
         self._plans[key] = plan
         return plan
@@ -97,6 +131,7 @@ class Conv:
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
         `window` = (oy0, ox0, OH, OW) restricts the computed output region."""
+        dt = self.dtype
         unpool = pre is not None
         B, C1 = x1.shape[0], x1.shape[1]
         if unpool:
@@ -117,31 +152,47 @@ class Conv:
             add_geom = (add.shape[2], add.shape[3], add_off[0], add_off[1])
             if add.shape[0] != B or add.shape[1] != self.Cout:
                 raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
-        d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool)
+        if self.via_im2col:
+            if x2 is not None or unpool or window is not None:
+                raise NotImplementedError('float64 im2col path: plain single-source conv only')
+            fullH, fullW = self.out_hw(H, W)
+            cols = torch.empty((B, C1 * self.KH * self.KW, fullH, fullW), dtype=dt, device=x1.device)
+            check(self.lib.iiseg_im2col_f64(_stream(), _ptr(x1, dt), _ptr(cols, dt), B, C1, H, W,
+                                            self.KH, self.KW), 'iiseg_im2col_f64')
+            d, wp, ktab = self._plan(B, C1, 0, H, W, None, add_geom, False)
+            x1 = cols
+        else:
+            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool)
         if out is None:
-            out = torch.empty((B, self.Cout, d.OH, d.OW), dtype=torch.float32, device=x1.device)
-        elif tuple(out.shape) != (B, self.Cout, d.OH, d.OW):
+            out = torch.empty((B, self.Cout, d.OH, d.OW), dtype=dt, device=x1.device)
+        elif tuple(out.shape) != (B, self.Cout, d.OH, d.OW) or out.dtype != dt:
             raise RuntimeError('out shape %s != %s' % (tuple(out.shape), (B, self.Cout, d.OH, d.OW)))
         prof = CONV_PROFILE
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        check(self.lib.iiseg_conv_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
-                                      _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
-                                      _ptr(self.b), _ptr(add), _ptr(out)), 'iiseg_conv_f32')
+        if dt == torch.float64:
+            check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
+                                          _ptr(pre, dt), _ptr(pooled, dt), _ptr(wp, dt),
+                                          _ptr(self.b, dt), _ptr(add, dt), _ptr(out, dt)),
+                  'iiseg_conv_f64')
+        else:
+            check(self.lib.iiseg_conv_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
+                                          _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
+                                          _ptr(self.b), _ptr(add), _ptr(out)), 'iiseg_conv_f32')
         if prof is not None:
             ev1.record()
-            prof.append((self.flops(B, d.OH, d.OW), ev0, ev1))
+            prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
         return out
 
 
 class Deconv:
     """Small-channel transposed convolution (Lasagne Deconv2DLayer W[in,out,k,k], P3)."""
 
-    def __init__(self, W, b, stride, device='cuda'):
-        self.lib = _lib.load()
-        self.W = torch.as_tensor(W, dtype=torch.float32).contiguous().to(device)
-        self.b = None if b is None else torch.as_tensor(b, dtype=torch.float32).contiguous().to(device)
+    def __init__(self, W, b, stride, device='cuda', dtype=torch.float32):
+        self.dtype = dtype
+        self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
+        self.b = None if b is None else torch.as_tensor(b).to(dtype).contiguous().to(device)
         self.Cin, self.Cout, self.K, k2 = self.W.shape
         if k2 != self.K:
             raise RuntimeError('square kernels only')
@@ -151,6 +202,7 @@ class Deconv:
         return (H - 1) * self.stride + self.K, (W - 1) * self.stride + self.K
 
     def __call__(self, x, add=None, add_off=(0, 0), window=None, out=None):
+        dt = self.dtype
         B, Cin, H, W = x.shape
         if Cin != self.Cin:
             raise RuntimeError('deconv expects %d channels, got %d' % (self.Cin, Cin))
@@ -164,18 +216,18 @@ class Deconv:
             if add.shape[0] != B or add.shape[1] != self.Cout:
                 raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
         if out is None:
-            out = torch.empty((B, self.Cout, OH, OW), dtype=torch.float32, device=x.device)
-        check(self.lib.iiseg_deconv_f32(_stream(), C.byref(d), _ptr(x), _ptr(self.W), _ptr(self.b),
-                                        _ptr(add), _ptr(out)), 'iiseg_deconv_f32')
+            out = torch.empty((B, self.Cout, OH, OW), dtype=dt, device=x.device)
+        check(_fn('deconv', dt)(_stream(), C.byref(d), _ptr(x, dt), _ptr(self.W, dt),
+                                _ptr(self.b, dt), _ptr(add, dt), _ptr(out, dt)), 'iiseg_deconv')
         return out
 
 
 def maxpool2x2(x, out=None):
     B, Cc, H, W = x.shape
     if out is None:
-        out = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=x.device)
-    check(_lib.load().iiseg_maxpool2x2_f32(_stream(), _ptr(x), _ptr(out), B * Cc, H, W),
-          'iiseg_maxpool2x2_f32')
+        out = torch.empty((B, Cc, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    check(_fn('maxpool2x2', x.dtype)(_stream(), _ptr(x, x.dtype), _ptr(out, x.dtype), B * Cc, H, W),
+          'iiseg_maxpool2x2')
     return out
 
 
@@ -186,8 +238,9 @@ def unpool_eqmask(up, pre, pooled, out=None):
                            % (tuple(up.shape), tuple(pre.shape), tuple(pooled.shape)))
     if out is None:
         out = torch.empty_like(pre)
-    check(_lib.load().iiseg_unpool_eqmask_f32(_stream(), _ptr(up), _ptr(pre), _ptr(pooled),
-                                              _ptr(out), B * Cc, H, W), 'iiseg_unpool_eqmask_f32')
+    dt = pre.dtype
+    check(_fn('unpool_eqmask', dt)(_stream(), _ptr(up, dt), _ptr(pre, dt), _ptr(pooled, dt),
+                                   _ptr(out, dt), B * Cc, H, W), 'iiseg_unpool_eqmask')
     return out
 
 
@@ -196,10 +249,11 @@ def crop_softmax(score, H, W, off=None, out=None, minuend=None):
     offset (dim - target)//2 (P6).  With `minuend` returns minuend - softmax (de_fn)."""
     B, Cc, SH, SW = score.shape
     sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
+    dt = score.dtype
     if out is None:
-        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=score.device)
-    check(_lib.load().iiseg_crop_softmax_f32(_stream(), _ptr(score), _ptr(minuend), _ptr(out), B, Cc, SH, SW,
-                                             sy0, sx0, H, W), 'iiseg_crop_softmax_f32')
+        out = torch.empty((B, Cc, H, W), dtype=dt, device=score.device)
+    check(_fn('crop_softmax', dt)(_stream(), _ptr(score, dt), _ptr(minuend, dt), _ptr(out, dt), B,
+                                  Cc, SH, SW, sy0, sx0, H, W), 'iiseg_crop_softmax')
     return out
 
 
@@ -228,11 +282,11 @@ def refine_update(score, y, state, step, off=None):
     B, Cc, SH, SW = score.shape
     H, W = y.shape[2], y.shape[3]
     sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
-    lib = _lib.load()
-    check(lib.iiseg_refine_update_f32(_stream(), _ptr(score), _ptr(y),
-                                      _ptr(state.active, torch.int32),
-                                      _ptr(state.partial, torch.float64), B, Cc, SH, SW, sy0, sx0,
-                                      H, W, float(step)), 'iiseg_refine_update_f32')
+    dt = y.dtype
+    check(_fn('refine_update', dt)(_stream(), _ptr(score, dt), _ptr(y, dt),
+                                   _ptr(state.active, torch.int32),
+                                   _ptr(state.partial, torch.float64), B, Cc, SH, SW, sy0, sx0,
+                                   H, W, float(step)), 'iiseg_refine_update')
 
 
 def refine_finalize(state, eps):
@@ -250,6 +304,6 @@ def confusion_accumulate(y, t, cm, sums):
     if tuple(t.shape) != (B, Cc + 1, H, W):
         raise RuntimeError('target must be one-hot (B,C+1,H,W) with void last, got %s'
                            % (tuple(t.shape),))
-    check(_lib.load().iiseg_confusion_f32(_stream(), _ptr(y), _ptr(t), _ptr(cm, torch.int64),
-                                          _ptr(sums, torch.float64), B, Cc, H * W),
-          'iiseg_confusion_f32')
+    dt = y.dtype
+    check(_fn('confusion', dt)(_stream(), _ptr(y, dt), _ptr(t, dt), _ptr(cm, torch.int64),
+                               _ptr(sums, torch.float64), B, Cc, H * W), 'iiseg_confusion')

@@ -1,0 +1,121 @@
+"""GPU parity of the float64 (strict-parity) path: the reference's CPU numerics (floatX=float64,
+SURVEY P15).  With float64 arithmetic the HIP path takes the same DePool2D mask decisions as the
+oracle, so the 1e-4 bound of north_star holds END TO END at full size (measured: ~1e-12)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dae as odae, fcn8 as ofcn8, nn as onn, refine as orefine, metrics as ometrics
+from iterative_inference_segm_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def to64(p):
+    return {k: tuple(np.asarray(a, dtype=np.float64) for a in v) for k, v in p.items()}
+
+
+@pytest.fixture(scope='module')
+def ops(built_lib):
+    from iterative_inference_segm_amd import ops as _ops
+    return _ops
+
+
+CASES = [(2, 3, 17, 19, 11, 3, 1, 1, False), (1, 11, 20, 20, 64, 3, 5, 1, True),
+         (3, 40, 13, 9, 130, 3, 1, 1, True), (2, 70, 7, 7, 33, 1, 0, 1, True),
+         (1, 11, 40, 36, 11, 3, 0, 4, False), (2, 16, 9, 9, 200, 7, 0, 1, True)]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_f64(ops, case):
+    B, Cin, H, W, Cout, k, pad, dil, relu = case
+    rng = np.random.default_rng(sum(case))
+    x, Wt, b = rng.standard_normal((B, Cin, H, W)), rng.standard_normal((Cout, Cin, k, k)), \
+        rng.standard_normal(Cout)
+    ref = onn.conv2d(x, Wt, b, pad=pad, dilation=dil, relu=relu)
+    got = host(ops.Conv(Wt, b, pad=pad, relu=relu, dil=dil, dtype=F64)(dev(x)))
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
+
+
+def test_conv_f64_concat_unpool_window_add(ops):
+    rng = np.random.default_rng(9)
+    h, t = rng.standard_normal((2, 24, 10, 11)), rng.standard_normal((2, 8, 10, 11))
+    Wt, b = rng.standard_normal((40, 32, 3, 3)), rng.standard_normal(40)
+    ref = onn.conv2d(onn.concat_h_first(h, t), Wt, b, pad=1, relu=True)
+    got = host(ops.Conv(Wt, b, pad=1, relu=True, dtype=F64)(dev(h), x2=dev(t)))
+    assert np.abs(got - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
+    pre = np.maximum(rng.standard_normal((2, 70, 13, 13)), 0)
+    pooled = onn.maxpool2(pre)
+    up = rng.standard_normal(pooled.shape)
+    Wt, b = rng.standard_normal((12, 70, 3, 3)), rng.standard_normal(12)
+    other = rng.standard_normal((2, 12, 15, 14))
+    full = onn.conv2d(onn.depool_eqmask(up, pre, pooled), Wt, b, pad=1)
+    ref = onn.crop_sum(full[:, :, 1:12, 2:12], onn.center_crop(other, 11, 10))
+    got = host(ops.Conv(Wt, b, pad=1, relu=False, dtype=F64)(
+        dev(up), pre=dev(pre), pooled=dev(pooled), add=dev(other), add_off=(2, 2),
+        window=(1, 2, 11, 10)))
+    assert np.abs(got - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
+    assert np.array_equal(host(ops.maxpool2x2(dev(pre))), pooled)
+    assert np.array_equal(host(ops.unpool_eqmask(dev(up), dev(pre), dev(pooled))),
+                          onn.depool_eqmask(up, pre, pooled))
+
+
+def test_tail_deconv_metrics_f64(ops):
+    rng = np.random.default_rng(10)
+    x, Wt, b = rng.standard_normal((2, 11, 5, 6)), rng.standard_normal((11, 11, 16, 16)), \
+        rng.standard_normal(11)
+    ref = onn.deconv2d(x, Wt, b, stride=8)
+    assert np.abs(host(ops.Deconv(Wt, b, 8, dtype=F64)(dev(x))) - ref).max() <= 1e-12 * 50
+    score = 5 * rng.standard_normal((2, 11, 30, 28))
+    y0 = rng.random((2, 11, 24, 20))
+    r = onn.softmax_channels(onn.center_crop(score, 24, 20))
+    assert np.abs(host(ops.crop_softmax(dev(score), 24, 20)) - r).max() <= 1e-14
+    y = dev(y0)
+    st = ops.RefineState(2, 24, 20, y.device)
+    ops.refine_update(dev(score), y, st, 0.3)
+    ops.refine_finalize(st, 1e-3)
+    de = y0 - r
+    assert np.abs(host(y) - np.clip(y0 - 0.3 * de, 0, 1)).max() <= 1e-14
+    assert np.abs(host(st.last_norm) - np.linalg.norm(de, axis=1).mean(axis=(1, 2))).max() <= 1e-12
+    labels = rng.integers(0, 12, size=(2, 24, 20))
+    t = np.zeros((2, 12, 24, 20)); np.put_along_axis(t, labels[:, None], 1.0, axis=1)
+    from iterative_inference_segm_amd.api import Metrics
+    m = Metrics(11, 'cuda')
+    ops.confusion_accumulate(dev(y0), dev(t), m.cm, m.sums)
+    acc, jacc, mse = m.result()
+    acc_r, jacc_r, mse_r = ometrics.val_fn(y0, t, 11, [11])
+    assert np.array_equal(jacc, jacc_r) and abs(acc - acc_r) < 1e-12 and abs(mse - mse_r) < 1e-12
+
+
+def test_full_size_end_to_end_strict(built_lib):
+    """BASELINE config-1/2 network, one 224x224 image, 3 refinement steps, float64 on the GPU vs
+    the float64 oracle: identical masks, refined map within 1e-4 (north_star) -- in fact ~1e-11."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, dp = S.make_fcn8_params(), S.make_dae_params()
+    ii = IterativeInference(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=F64),
+                            StandardDAE(dp, 11, dtype=F64), 11, [11], dtype=F64)
+    X = S.make_images(1, 224, 224, seed=1234)
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    h_ref, y_ref = ofcn8.fcn8_forward(to64(fp), X.astype(np.float64), layer=['pool4', 'probs_dimshuffle'])
+    assert np.abs(host(Y) - y_ref).max() <= 1e-10
+    dp64 = to64(dp)
+    dae_fn = lambda hh, yy: odae.dae_forward(dp64, hh, yy)
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, [h_ref], y_ref, 0.1, 3)
+    Yii, iters, _ = ii.refine(H, Y, 0.1, 3)
+    err = np.abs(host(Yii) - yii_ref).max()
+    print('float64 end-to-end max-abs err after 3 steps: %.3e' % err)
+    assert list(host(iters)) == list(it_ref)
+    assert err <= 1e-4
