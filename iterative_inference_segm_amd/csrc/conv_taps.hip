@@ -42,7 +42,7 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 
 template <int BM, int BN, int WM, int WN, int KH, int KW, int CPT, bool UNPOOL>
-__global__ __launch_bounds__(256) void conv_taps_f32_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f32_kernel(const ConvParams p) {
     constexpr int T = KH * KW;                   // taps
     constexpr int BK = CPT * T;                  // k-tile depth (whole channels)
     constexpr int NCH = BK / 2;                  // MFMA k-steps per tile

@@ -7,6 +7,8 @@ The layer plan is static per (B, H, W): every launch is a fused kernel --
                      skip sum (ElemwiseSumLayer) and the final center crop fused in the epilogue
 so the unpooled tensors, the concatenated tensor and the cropped score are never materialised.
 """
+import os
+
 import torch
 
 from . import ops
@@ -71,6 +73,8 @@ class StandardDAE:
             self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
                                       device=device, dtype=dtype)                     # fcn_up.py:83-86
         self.conv_log = None
+        # DePool2D fused into the conv's gather (3 loads per element) or materialised first
+        self.fuse_unpool = os.environ.get('IISEG_FUSE_UNPOOL', '0') != '0'
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
 
     def conv_layers(self):
@@ -120,6 +124,10 @@ class StandardDAE:
             mpre, mpool = pre[p], pool[p]
             if mask_override and p in mask_override:
                 mpre, mpool = mask_override[p]
+            if not self.fuse_unpool:
+                # materialise DePool2D with the HBM-bound kernel, then a plain conv
+                t = ops.unpool_eqmask(t, mpre, mpool)
+                mpre = mpool = None
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
                 t = conv(t, pre=mpre, pooled=mpool, add=other,
                          add_off=(_center(other.shape[2], oh), _center(other.shape[3], ow)),
