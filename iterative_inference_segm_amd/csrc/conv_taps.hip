@@ -41,7 +41,7 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff,
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
-template <int BM, int BN, int WM, int WN, int KH, int KW, int CPT, bool UNPOOL>
+template <int BM, int BN, int WM, int WN, int KH, int KW, int CPT, bool UNPOOL, bool DMA>
 __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f32_kernel(const ConvParams p) {
     constexpr int T = KH * KW;                   // taps
     constexpr int BK = CPT * T;                  // k-tile depth (whole channels)
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     constexpr int WPT = (WVEC + 255) / 256;
     static_assert(WM * WN == 4 && BK % 2 == 0 && CPT % RG == 0, "tile config");
     static_assert(WPT <= 3, "weight staging registers");
+    static_assert(!(DMA && UNPOOL), "LDS-DMA staging is for the plain gather");
 
     __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Xs[2][BK][BN];
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     // ---- staging setup: this thread's pixel, its T tap offsets --------------------------
     const int lp = tid % BN;
     const int rg = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int lp0 = __builtin_amdgcn_readfirstlane(lp & ~63);  // first pixel column of this wave
     const int pg = p0 + lp;
     const bool pvalid = pg < p.P;
     int gb = 0, goy = 0, gox = 0;
@@ -159,8 +161,17 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
         } else {                                                                                \
             const bool s1 = c < C1; /* wave-uniform */                                          \
             const unsigned so = (unsigned)((s1 ? c : c - C1) * HW) * 4u;                        \
-            xv[j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), s1 ? voff[t] : voff2[t],  \
-                           so);                                                                 \
+            if constexpr (DMA) {                                                                \
+                /* buffer_load_dword ... lds: global -> LDS without touching VGPRs; the LDS   */ \
+                /* address is M0 (wave-uniform row base) + lane*4, i.e. this wave's 64 pixels */ \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                       \
+                    mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2),                                  \
+                    (__attribute__((address_space(3))) void*)&Xs[DMABUF][rg * XE + j][lp0],     \
+                    4, (int)(s1 ? voff[t] : voff2[t]), (int)so, 0, 0);                          \
+            } else {                                                                            \
+                xv[j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2),                       \
+                               s1 ? voff[t] : voff2[t], so);                                    \
+            }                                                                                   \
         }                                                                                       \
     }
 #define IISEG_W_ON(j) ((j) < WPT && (((j) + 1) * 256 <= WVEC || tid + 256 * (j) < WVEC))
@@ -174,13 +185,14 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     }
 #define IISEG_STORE_TILE(BUF)                                                                   \
     {                                                                                           \
-        static_for<0, XE>([&](auto JJ) __attribute__((always_inline)) {                         \
-            constexpr int j = decltype(JJ)::value;                                              \
-            float v = xv[j];                                                                    \
-            /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */       \
-            if constexpr (UNPOOL) v = (xv[j] == xq[j]) ? xu[j] : 0.f;                           \
-            Xs[BUF][rg * XE + j][lp] = v;                                                       \
-        });                                                                                     \
+        if constexpr (!DMA)                                                                     \
+            static_for<0, XE>([&](auto JJ) __attribute__((always_inline)) {                     \
+                constexpr int j = decltype(JJ)::value;                                          \
+                float v = xv[j];                                                                \
+                /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */   \
+                if constexpr (UNPOOL) v = (xv[j] == xq[j]) ? xu[j] : 0.f;                       \
+                Xs[BUF][rg * XE + j][lp] = v;                                                   \
+            });                                                                                 \
         if (IISEG_W_ON(0)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0][wc4 * 4]) = wv0;          \
         if (IISEG_W_ON(1)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + RPJ][wc4 * 4]) = wv1;    \
         if (IISEG_W_ON(2)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 2 * RPJ][wc4 * 4]) = wv2; \
@@ -189,9 +201,13 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     const int nkt = p.Kpad / BK;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    static_for<0, XE>([&](auto J) __attribute__((always_inline)) { IISEG_GATHER(0, decltype(J)::value) });
+    {
+        constexpr int DMABUF = 0;
+        static_for<0, XE>([&](auto J) __attribute__((always_inline)) { IISEG_GATHER(0, decltype(J)::value) });
+    }
     IISEG_LOAD_W(0)
     IISEG_STORE_TILE(0)
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Per k-tile: NCH chunks = { stage part of the NEXT tile, LDS-read operands of k-step c+1,
@@ -203,6 +219,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
         const int buf = kt & 1;
         const bool more = (kt + 1 < nkt) && !(p.debug_nogather & 1);
         const bool dbg_ld = !(p.debug_nogather & 2), dbg_st = !(p.debug_nogather & 4);
+        const int DMABUF = buf ^ 1;
         float a[2][TM], b[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[0][i] = Ws[buf][lh][wm * WTM + i * 32 + l31];
@@ -227,15 +244,18 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
                                                                      acc[i][j], 0, 0, 0);
             // staging loads of the next tile go right BEHIND this chunk's MFMAs
             if (more && dbg_ld) {
-                if constexpr (ch == 0) IISEG_LOAD_W(kt + 1)
-                static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
-                    constexpr int ge = ch * GPC + decltype(G)::value;
-                    if constexpr (ch < GCH && ge < XE) IISEG_GATHER(kt + 1, ge)
-                });
+                if constexpr (ch == 0)
+                    if (!(p.debug_nogather & 16)) IISEG_LOAD_W(kt + 1)
+                if (!(p.debug_nogather & 8))
+                    static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
+                        constexpr int ge = ch * GPC + decltype(G)::value;
+                        if constexpr (ch < GCH && ge < XE) IISEG_GATHER(kt + 1, ge)
+                    });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         if (more && dbg_st) IISEG_STORE_TILE(buf ^ 1)
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 #undef IISEG_GATHER
@@ -255,12 +275,16 @@ int launch_taps(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_ptiles = (p.P + BN - 1) / BN;
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
+    static const int dma = getenv("IISEG_CONV_DMA") ? atoi(getenv("IISEG_CONV_DMA")) : 1;
     if (unpool)
-        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, true>), dim3(grid),
-                           dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, true, false>),
+                           dim3(grid), dim3(256), 0, s, p);
+    else if (dma)
+        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, true>),
+                           dim3(grid), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false>), dim3(grid),
-                           dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, false>),
+                           dim3(grid), dim3(256), 0, s, p);
     return iiseg_check_launch();
 }
 

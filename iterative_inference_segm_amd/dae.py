@@ -124,8 +124,11 @@ class StandardDAE:
             mpre, mpool = pre[p], pool[p]
             if mask_override and p in mask_override:
                 mpre, mpool = mask_override[p]
-            if not self.fuse_unpool:
-                # materialise DePool2D with the HBM-bound kernel, then a plain conv
+            if not (self.fuse_unpool or conv.Cout <= 32):
+                # Measured on MI355X: the fused gather needs 3 loads per element and the conv is
+                # limited by its vector-memory instructions, so for wide layers it is faster to
+                # materialise DePool2D with the HBM-bound kernel and run the plain conv; the
+                # narrow last layer (Cout = 11, HBM-bound itself) keeps the fused form.
                 t = ops.unpool_eqmask(t, mpre, mpool)
                 mpre = mpool = None
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
