@@ -50,6 +50,11 @@ const char* iiseg_target_arch(void);
 
 #define IISEG_CONV_RELU 1u   /* out = max(out, 0)                                   */
 #define IISEG_CONV_UNPOOL 2u /* logical input = eq-mask unpool(up=x1, pre, pooled)  */
+/* 3x3 stride-2 TRANSPOSED convolution, crop='valid' (Deconv2DLayer of FC-DenseNet's TransitionUp,
+ * models/FCDenseNet.py:119 via FC_DenseNet.layers): logical output (2H+1, 2W+1); w is the
+ * reference layout W[in][out][3][3] (pass stride_o = 9, stride_c = Cout*9), the spatial flip of
+ * Lasagne's gradient form is applied while packing; pad/dil are ignored. */
+#define IISEG_CONV_TRANSPOSED2 4u
 
 typedef struct iiseg_conv_desc {
     /* logical input (after concat / unpool): (B, C1 + C2, H, W) */
@@ -64,6 +69,10 @@ typedef struct iiseg_conv_desc {
     uint32_t flags;
     /* packed-weight geometry produced by iiseg_conv_pack_f32 */
     int32_t Kpad, Mpad;
+    /* destination as a channel slice of a wider tensor (B, out_ctot, OH, OW), first channel
+     * out_c0 -- lets dense blocks grow a preallocated stack without concat copies
+     * (ConcatLayer([stack, l]), models/FCDenseNet.py:92).  out_ctot == 0: dense (B, Cout, OH, OW). */
+    int32_t out_ctot, out_c0;
 } iiseg_conv_desc;
 
 /* Number of int32x4 entries of the gather table for `d` (== d->Kpad). */
@@ -154,6 +163,25 @@ int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, 
  * ------------------------------------------------------------------------------------- */
 int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm, double* sums,
                         int32_t B, int32_t C, int32_t HW);
+
+/* ---------------------------------------------------------------------------------------
+ * Batch-statistics BatchNorm (+ReLU).  Replaces lasagne BatchNormLayer under
+ * batch_norm_use_averages=False (iterative_inference.py:187) followed by the rectify
+ * NonlinearityLayer of FC-DenseNet's BN_ReLU_Conv (models/FCDenseNet.py:12,90,109,123).
+ * x is (B, >=C, H, W) with `bstride` elements between images (a channel-slice view of a stack).
+ *   stats : mean[c], inv_std[c] = 1/sqrt(biased_var + eps) over (B,H,W) for c < C
+ *   apply : out[b,c] = max((x[b,c] - mean[c]) * (gamma[c] * inv_std[c]) + beta[c], 0), out dense
+ * ------------------------------------------------------------------------------------- */
+int iiseg_bn_stats_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
+                       int32_t HW, float eps, float* mean, float* inv_std);
+int iiseg_bn_relu_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
+                      int32_t HW, const float* beta, const float* gamma, const float* mean,
+                      const float* inv_std, float* out);
+int iiseg_bn_stats_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,
+                       int32_t HW, double eps, double* mean, double* inv_std);
+int iiseg_bn_relu_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,
+                      int32_t HW, const double* beta, const double* gamma, const double* mean,
+                      const double* inv_std, double* out);
 
 /* ---------------------------------------------------------------------------------------
  * float64 variants (strict-parity mode).  The reference's CPU path computes in float64 (Theano

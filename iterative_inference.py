@@ -102,8 +102,22 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
         padding = 100
         h_channels = {'input': nb_in_channels, 'pool1': 64, 'pool2': 128, 'pool3': 256,
                       'pool4': 512, 'pool5': 512}
-    elif segm_net == 'densenet':
-        raise NotImplementedError('FC-DenseNet103 host network is not built yet (SURVEY 8a A2)')
+    elif segm_net == 'densenet':                                 # :140-143
+        from iterative_inference_segm_amd.densenet import build_fcdensenet, layer_plan
+        dn_weights = os.path.join(weights_path, dataset, 'FC-DenseNet103_weights.npz')
+        dn_params = None
+        if not os.path.exists(dn_weights):
+            if not synthetic:
+                raise IOError('FC-DenseNet weights not found: %s (use --synthetic)' % dn_weights)
+            dn_params = S.make_densenet_params(layer_plan(nb_in_channels=nb_in_channels,
+                                                          n_classes=n_classes), seed=2024)
+        fcn = build_fcdensenet(layer=dae_dict['concat_h'], nb_in_channels=nb_in_channels,
+                               n_classes=n_classes, weight_path=dn_weights, params=dn_params,
+                               device=device)
+        padding = 0
+        # pool k stacks of DenseNet103: 48 + 16*(4,9,16,26,38) channels
+        h_channels = {'input': nb_in_channels, 'pool1': 112, 'pool2': 192, 'pool3': 304,
+                      'pool4': 464, 'pool5': 656}
     elif segm_net == 'fcn_fcresnet':
         raise NotImplementedError                                # :144-145
     else:

@@ -9,10 +9,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
+CONV_TRANSPOSED2 = 4
 
 
 class ConvDesc(C.Structure):
@@ -20,7 +21,8 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ('B', 'C1', 'C2', 'H', 'W', 'Cout', 'KH', 'KW', 'pad', 'dil',
                  'oy0', 'ox0', 'OH', 'OW', 'AH', 'AW', 'ay0', 'ax0')] + \
-               [('flags', C.c_uint32), ('Kpad', C.c_int32), ('Mpad', C.c_int32)]
+               [('flags', C.c_uint32), ('Kpad', C.c_int32), ('Mpad', C.c_int32),
+                ('out_ctot', C.c_int32), ('out_c0', C.c_int32)]
 
 
 class DeconvDesc(C.Structure):
@@ -49,6 +51,10 @@ SIGNATURES = {
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
     'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_bn_stats_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp]),
+    'iiseg_bn_relu_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
+    'iiseg_bn_stats_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _vp]),
+    'iiseg_bn_relu_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
     # float64 (strict-parity) variants
     'iiseg_conv_plan_f64': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pack_f64': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),

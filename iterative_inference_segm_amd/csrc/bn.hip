@@ -1,0 +1,103 @@
+// Batch-statistics BatchNorm + ReLU for the FC-DenseNet host network (float32 / float64).
+// Replaces lasagne BatchNormLayer with batch_norm_use_averages=False (reference
+// iterative_inference.py:187; SURVEY P10: batch mean, biased variance over (B,H,W), eps 1e-4) and
+// the rectify that follows it in BN_ReLU_Conv (FC_DenseNet.layers, models/FCDenseNet.py:12).
+// stats: one workgroup per channel, fp64 accumulation, fixed reduction order (deterministic);
+// apply: HBM-bound element-wise kernel.  A channel's statistics never change once the channel is
+// in the stack, so the host computes them once per produced tensor, not once per consumer.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t bstride,
+                                                       int B, int HW, double eps,
+                                                       T* __restrict__ mean, T* __restrict__ inv_std) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const T* xp = x + (size_t)b * bstride + (size_t)c * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const double v = (double)xp[i];
+            s += v;
+            ss += v * v;
+        }
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)B * HW;
+        const double m = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
+        double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (T)m;
+        inv_std[c] = (T)(1.0 / sqrt(var + eps));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_kernel(const T* __restrict__ x, int64_t bstride,
+                                                      int C, int HW, const T* __restrict__ beta,
+                                                      const T* __restrict__ gamma,
+                                                      const T* __restrict__ mean,
+                                                      const T* __restrict__ inv_std,
+                                                      T* __restrict__ out) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const T m = mean[c], g = gamma[c] * inv_std[c], be = beta[c];
+    const T* xp = x + (size_t)b * bstride + (size_t)c * HW;
+    T* op = out + ((size_t)b * C + c) * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const T v = (xp[i] - m) * g + be;   // (input - mean) * (gamma * inv_std) + beta
+        op[i] = v > (T)0 ? v : (T)0;
+    }
+}
+
+template <typename T>
+int bn_stats(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, int32_t HW, double eps,
+             T* mean, T* inv_std) {
+    if (!x || !mean || !inv_std) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0 || bstride < (int64_t)C * HW) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, bstride, B,
+                       HW, eps, mean, inv_std);
+    return iiseg_check_launch();
+}
+
+template <typename T>
+int bn_relu(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, int32_t HW,
+            const T* beta, const T* gamma, const T* mean, const T* inv_std, T* out) {
+    if (!x || !beta || !gamma || !mean || !inv_std || !out) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0 || bstride < (int64_t)C * HW) return IISEG_ERR_SHAPE;
+    if (C > 65535 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    int gx = (HW + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_relu_kernel<T>, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, x,
+                       bstride, C, HW, beta, gamma, mean, inv_std, out);
+    return iiseg_check_launch();
+}
+
+}  // namespace
+
+extern "C" int iiseg_bn_stats_f32(void* stream, const float* x, int64_t bstride, int32_t B,
+                                  int32_t C, int32_t HW, float eps, float* mean, float* inv_std) {
+    return bn_stats<float>(stream, x, bstride, B, C, HW, (double)eps, mean, inv_std);
+}
+extern "C" int iiseg_bn_stats_f64(void* stream, const double* x, int64_t bstride, int32_t B,
+                                  int32_t C, int32_t HW, double eps, double* mean, double* inv_std) {
+    return bn_stats<double>(stream, x, bstride, B, C, HW, eps, mean, inv_std);
+}
+extern "C" int iiseg_bn_relu_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
+                                 int32_t HW, const float* beta, const float* gamma,
+                                 const float* mean, const float* inv_std, float* out) {
+    return bn_relu<float>(stream, x, bstride, B, C, HW, beta, gamma, mean, inv_std, out);
+}
+extern "C" int iiseg_bn_relu_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,
+                                 int32_t HW, const double* beta, const double* gamma,
+                                 const double* mean, const double* inv_std, double* out) {
+    return bn_relu<double>(stream, x, bstride, B, C, HW, beta, gamma, mean, inv_std, out);
+}

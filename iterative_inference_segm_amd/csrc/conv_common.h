@@ -39,6 +39,8 @@ struct ConvParams {
     int n_ptiles, n_mtiles;
     int relu;
     int debug_nogather;
+    int out_ctot, out_c0;  // destination channel slice (out_ctot == Cout, out_c0 == 0: dense)
+    int transposed;        // 3x3 stride-2 transposed convolution (conv_taps only)
 };
 
 // Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give
@@ -72,7 +74,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p,
         if (pe >= p.P) continue;
         const int eb = pe / OHW;
         const int rem = pe - eb * OHW;
-        float* outp = p.out + (size_t)eb * p.Cout * OHW + rem;
+        float* outp = p.out + ((size_t)eb * p.out_ctot + p.out_c0) * OHW + rem;
         const float* addp = nullptr;
         size_t AHW = 0;
         if (p.add) {

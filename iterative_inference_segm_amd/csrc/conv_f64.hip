@@ -47,6 +47,8 @@ struct ConvParams64 {
     int P;
     int n_ptiles, n_mtiles;
     int relu;
+    int out_ctot, out_c0;
+    int transposed;
 };
 
 __device__ __forceinline__ double buf_ld64(const double* base, int bytes, unsigned voff, unsigned soff) {
@@ -112,9 +114,16 @@ __global__ __launch_bounds__(256) void conv_taps_f64_kernel(const ConvParams64 p
     unsigned voff[T], voff2[T];
     static_for<0, T>([&](auto TT) __attribute__((always_inline)) {
         constexpr int t = decltype(TT)::value;
-        const int iy = goy + (t / KW) * p.dil - p.pad;
-        const int ix = gox + (t % KW) * p.dil - p.pad;
-        bool ok = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        int iy = goy + (t / KW) * p.dil - p.pad;
+        int ix = gox + (t % KW) * p.dil - p.pad;
+        bool par = true;
+        if (p.transposed) {
+            const int ty = goy - t / KW, tx = gox - t % KW;
+            par = ty >= 0 && tx >= 0 && !((ty | tx) & 1);
+            iy = ty >> 1;
+            ix = tx >> 1;
+        }
+        bool ok = pvalid && par && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         voff[t] = ok ? 8u * (unsigned)(db * C1 * HW + iy * p.W + ix) : OOB;
         if constexpr (UNPOOL) {
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_taps_f64_kernel(const ConvParams64 p
         if (pe >= p.P) continue;
         const int eb = pe / OHW;
         const int rem = pe - eb * OHW;
-        double* outp = p.out + (size_t)eb * p.Cout * OHW + rem;
+        double* outp = p.out + ((size_t)eb * p.out_ctot + p.out_c0) * OHW + rem;
         const double* addp = nullptr;
         size_t AHW = 0;
         if (p.add) {
@@ -232,13 +241,14 @@ __global__ __launch_bounds__(256) void conv_taps_f64_kernel(const ConvParams64 p
 }
 
 __global__ void conv_pack_f64_kernel(const double* __restrict__ w, int64_t so, int64_t sc,
-                                     double* wp, int KK, int Cout, int K, int Kpad, int Mpad) {
+                                     double* wp, int KK, int Cout, int K, int Kpad, int Mpad,
+                                     int flip) {
     const int64_t n = (int64_t)Kpad * Mpad;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i / Mpad), m = (int)(i % Mpad);
         double v = 0.0;
-        if (k < K && m < Cout) v = w[m * so + (k / KK) * sc + (k % KK)];
+        if (k < K && m < Cout) v = w[m * so + (k / KK) * sc + (flip ? KK - 1 - k % KK : k % KK)];
         wp[i] = v;
     }
 }
@@ -285,9 +295,17 @@ int check64(const iiseg_conv_desc* d) {
         return IISEG_ERR_SHAPE;
     const int cpt = cpt64(d->KH, d->KW);
     if (cpt == 0) return IISEG_ERR_UNSUPPORTED;
-    const int fullH = d->H + 2 * d->pad - d->dil * (d->KH - 1);
-    const int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
+    int fullH = d->H + 2 * d->pad - d->dil * (d->KH - 1);
+    int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
+    if (d->flags & IISEG_CONV_TRANSPOSED2) {
+        if (d->KH != 3 || d->KW != 3 || (d->flags & IISEG_CONV_UNPOOL) || d->C2 != 0)
+            return IISEG_ERR_UNSUPPORTED;
+        fullH = 2 * d->H + 1;
+        fullW = 2 * d->W + 1;
+    }
     if (fullH <= 0 || fullW <= 0 || d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW)
+        return IISEG_ERR_SHAPE;
+    if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot))
         return IISEG_ERR_SHAPE;
     const int C = d->C1 + d->C2, T = d->KH * d->KW;
     if (d->Kpad != (C + cpt - 1) / cpt * cpt * T || d->Mpad != (d->Cout + BM - 1) / BM * BM)
@@ -321,7 +339,8 @@ extern "C" int iiseg_conv_pack_f64(void* stream, const iiseg_conv_desc* d, const
     const int64_t n = (int64_t)d->Kpad * d->Mpad;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv_pack_f64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
-                       stride_o, stride_c, wp, d->KH * d->KW, d->Cout, K, d->Kpad, d->Mpad);
+                       stride_o, stride_c, wp, d->KH * d->KW, d->Cout, K, d->Kpad, d->Mpad,
+                       (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0);
     return iiseg_check_launch();
 }
 
@@ -349,6 +368,9 @@ extern "C" int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const doub
     p.P = d->B * d->OH * d->OW;
     p.n_ptiles = p.n_mtiles = 0;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
+    p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (d->KH == 3) return launch64<3, 3, 4>(s, p, unpool);
     return launch64<1, 1, 16>(s, p, unpool);

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, int64_t so, int64_t sc, float* wp,
                                  int4* ktab, int C1, int C2, int KH, int KW, int pad, int dil,
-                                 int H, int W, int Cout, int K, int Kpad, int Mpad) {
+                                 int H, int W, int Cout, int K, int Kpad, int Mpad, int flip) {
     const int64_t n = (int64_t)Kpad * Mpad;
     const int KK = KH * KW;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -279,7 +279,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int64_t so, int64_
         float v = 0.f;
         if (k < K && m < Cout) {
             const int c = k / KK, r = k % KK;
-            v = w[m * so + c * sc + r];
+            v = w[m * so + c * sc + (flip ? KK - 1 - r : r)];
         }
         wp[i] = v;
         if (m == 0) {
@@ -335,9 +335,17 @@ static int check_desc(const iiseg_conv_desc* d) {
         d->KH <= 0 || d->KW <= 0 || d->pad < 0 || d->dil <= 0 || d->OH <= 0 || d->OW <= 0 ||
         d->oy0 < 0 || d->ox0 < 0)
         return IISEG_ERR_SHAPE;
-    const int fullH = d->H + 2 * d->pad - d->dil * (d->KH - 1);
-    const int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
+    int fullH = d->H + 2 * d->pad - d->dil * (d->KH - 1);
+    int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
+    if (d->flags & IISEG_CONV_TRANSPOSED2) {
+        if (d->KH != 3 || d->KW != 3 || (d->flags & IISEG_CONV_UNPOOL) || d->C2 != 0)
+            return IISEG_ERR_UNSUPPORTED;
+        fullH = 2 * d->H + 1;
+        fullW = 2 * d->W + 1;
+    }
     if (fullH <= 0 || fullW <= 0 || d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW)
+        return IISEG_ERR_SHAPE;
+    if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot))
         return IISEG_ERR_SHAPE;
     const int bm = pick_bm(d->Cout);
     if (d->Kpad != kpad_for(d) || d->Mpad != (d->Cout + bm - 1) / bm * bm) return IISEG_ERR_SHAPE;
@@ -362,7 +370,8 @@ extern "C" int iiseg_conv_pack_f32(void* stream, const iiseg_conv_desc* d, const
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
                        stride_c, wp, reinterpret_cast<int4*>(ktab), d->C1, d->C2, d->KH, d->KW,
-                       d->pad, d->dil, d->H, d->W, d->Cout, K, d->Kpad, d->Mpad);
+                       d->pad, d->dil, d->H, d->W, d->Cout, K, d->Kpad, d->Mpad,
+                       (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0);
     return iiseg_check_launch();
 }
 
@@ -408,6 +417,9 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     p.Kpad = d->Kpad; p.Mpad = d->Mpad;
     p.pad = d->pad; p.dil = d->dil;
     p.debug_nogather = 0;
+    p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
+    p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
     p.P = d->B * d->OH * d->OW;
     p.n_ptiles = p.n_mtiles = 0;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;

@@ -118,9 +118,18 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     unsigned voff[T], voff2[T];
     static_for<0, T>([&](auto TT) __attribute__((always_inline)) {
         constexpr int t = decltype(TT)::value;
-        const int iy = goy + (t / KW) * p.dil - p.pad;
-        const int ix = gox + (t % KW) * p.dil - p.pad;
-        bool ok = pvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        int iy = goy + (t / KW) * p.dil - p.pad;
+        int ix = gox + (t % KW) * p.dil - p.pad;
+        bool par = true;
+        if (p.transposed) {
+            // stride-2 transposed conv: out(Y,X) += x((Y-a)/2, (X-b)/2) * Wf[a][b] where the
+            // differences are even and inside the input -- just another validity pattern
+            const int ty = goy - t / KW, tx = gox - t % KW;
+            par = ty >= 0 && tx >= 0 && !((ty | tx) & 1);
+            iy = ty >> 1;
+            ix = tx >> 1;
+        }
+        bool ok = pvalid && par && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         voff[t] = ok ? 4u * (unsigned)(db * C1 * HW + iy * p.W + ix) : OOB;
         if constexpr (UNPOOL) {
             // DePool2D (layers/mylayers.py:95-114): only the 2h x 2w region has pooling windows

@@ -1,0 +1,190 @@
+"""FC-DenseNet103 host segmentation network on the HIP kernels (mirror of reference
+models/FCDenseNet.py:15-146,196-219; block internals restated from the un-vendored
+FC_DenseNet.layers, see oracle/densenet.py -- unverifiable here).
+
+MI355X mapping:
+  * a dense block's stack is ONE preallocated (B, C_final, H, W) buffer; every BN_ReLU_Conv
+    writes its `growth` new channels into the next channel slice (conv `out_c0`), so the
+    ConcatLayer([stack, l]) of models/FCDenseNet.py:92 costs no copy;
+  * BatchNorm uses batch statistics at inference (batch_norm_use_averages=False,
+    iterative_inference.py:187; P10).  A channel's statistics never change once it is in the
+    stack, so they are reduced once per produced slice (`bn_stats`), and each consumer applies its
+    own gamma/beta with `bn_relu` (HBM-bound) before its convolution;
+  * TransitionUp's 3x3 stride-2 Deconv2DLayer runs on the same static-tap conv kernel
+    (IISEG_CONV_TRANSPOSED2: the stride is just a different tap-validity pattern), written
+    center-cropped straight into the new stack; the skip stack is copied behind it.
+Because BN couples the images of a batch, a reference batch must stay on one GPU.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+GROWTH = 16
+N_POOL = 5
+LAYERS_PER_BLOCK = [4, 5, 7, 10, 12, 15, 12, 10, 7, 5, 4]      # FCDenseNet.py:208
+N_FILTERS_FIRST = 48
+BN_EPS = 1e-4
+
+
+def layer_plan(n_layers_per_block=LAYERS_PER_BLOCK, n_pool=N_POOL, growth=GROWTH,
+               n_first=N_FILTERS_FIRST, nb_in_channels=3, n_classes=11):
+    """Creation-order (kind, cin, cout) of every parametrised layer ('first', 'brc', 'td', 'tu',
+    'softmax'); 103 convolutions for the default configuration."""
+    plan = [('first', nb_in_channels, n_first)]
+    n = n_first
+    skips = []
+    for i in range(n_pool):
+        for _ in range(n_layers_per_block[i]):
+            plan.append(('brc', n, growth))
+            n += growth
+        skips.append(n)
+        plan.append(('td', n, n))
+    skips = skips[::-1]
+    nblock = 0
+    for _ in range(n_layers_per_block[n_pool]):
+        plan.append(('brc', n, growth))
+        n += growth
+        nblock += 1
+    for i in range(n_pool):
+        keep = growth * n_layers_per_block[n_pool + i]
+        plan.append(('tu', growth * nblock, keep))
+        n = keep + skips[i]
+        nblock = 0
+        for _ in range(n_layers_per_block[n_pool + i + 1]):
+            plan.append(('brc', n, growth))
+            n += growth
+            nblock += 1
+    plan.append(('softmax', n, n_classes))
+    return plan
+
+
+class _Stack:
+    """A growing (B, cap, H, W) feature stack with per-channel batch statistics."""
+
+    def __init__(self, B, cap, H, W, device, dtype):
+        self.buf = torch.empty((B, cap, H, W), dtype=dtype, device=device)
+        self.mean = torch.empty(cap, dtype=dtype, device=device)
+        self.inv_std = torch.empty(cap, dtype=dtype, device=device)
+        self.n = 0
+
+    def added(self, k):
+        ops.bn_stats(self.buf, self.n, k, self.mean, self.inv_std, BN_EPS)
+        self.n += k
+
+    def view(self):
+        return self.buf if self.n == self.buf.shape[1] else self.buf[:, :self.n].contiguous()
+
+
+class FCDenseNet:
+    def __init__(self, params, n_classes=11, layer=('pool4',), n_layers_per_block=LAYERS_PER_BLOCK,
+                 n_pool=N_POOL, growth=GROWTH, device='cuda', dtype=torch.float32):
+        self.layer = list(layer)
+        assert all(h in ['input', 'pool1', 'pool2', 'pool3', 'pool4', 'pool5'] for h in self.layer)
+        self.nlpb, self.n_pool, self.growth = list(n_layers_per_block), n_pool, growth
+        self.n_classes, self.device, self.dtype = n_classes, device, dtype
+        dev = lambda a: torch.as_tensor(a).to(dtype).contiguous().to(device)
+        self.layers = []
+        for p in params:
+            e = {'kind': p['kind']}
+            if p['kind'] in ('brc', 'td'):
+                e['beta'], e['gamma'] = dev(p['beta']), dev(p['gamma'])
+            if p['kind'] == 'tu':
+                e['conv'] = ops.Conv(p['W'], p['b'], pad=0, relu=False, layout='iohw',
+                                     transposed=True, device=device, dtype=dtype)
+            else:
+                k = p['W'].shape[2]
+                e['conv'] = ops.Conv(p['W'], p['b'], pad=k // 2, relu=False, device=device,
+                                     dtype=dtype)
+            self.layers.append(e)
+
+    def __call__(self, x):
+        return self.forward(x)
+
+    def _brc(self, it, stack, out=None, out_c0=None):
+        e = next(it)
+        t = ops.bn_relu(stack.buf, stack.n, e['beta'], e['gamma'], stack.mean, stack.inv_std)
+        return e['conv'](t, out=out, out_c0=out_c0)
+
+    def forward(self, x):
+        B, _, H, W = x.shape
+        g, dt, dev = self.growth, self.dtype, self.device
+        it = iter(self.layers)
+        hidden = [x] if 'input' in self.layer else []
+        ints = [int(h[-1]) for h in self.layer if h != 'input']
+        n = self.layers[0]['conv'].Cout
+        stack = _Stack(B, n + g * self.nlpb[0], H, W, dev, dt)
+        next(it)['conv'](x, out=stack.buf, out_c0=0)                  # first conv (linear)
+        stack.added(n)
+        skips = []
+        for i in range(self.n_pool):                                  # FCDenseNet.py:81-100
+            for _ in range(self.nlpb[i]):
+                self._brc(it, stack, out=stack.buf, out_c0=stack.n)
+                stack.added(g)
+            skips.append(stack)
+            t = ops.maxpool2x2(self._brc(it, stack))                  # TransitionDown
+            H, W = H // 2, W // 2
+            n = stack.n
+            stack = _Stack(B, n + g * self.nlpb[i + 1], H, W, dev, dt)
+            stack.buf[:, :n].copy_(t)                                 # plumbing: place the pool
+            stack.added(n)
+            if i + 1 in ints:
+                hidden.append(t)
+        skips = skips[::-1]
+        nblock = self.nlpb[self.n_pool]
+        block0 = stack.n
+        for _ in range(nblock):                                       # bottleneck, :107-111
+            self._brc(it, stack, out=stack.buf, out_c0=stack.n)
+            stack.added(g)
+        for i in range(self.n_pool):                                  # :116-127
+            e = next(it)                                              # TransitionUp
+            blk = stack.buf[:, block0:stack.n].contiguous()           # concat(block_to_upsample)
+            skip = skips[i]
+            uh, uw = e['conv'].out_hw(H, W)
+            H, W = min(uh, skip.buf.shape[2]), min(uw, skip.buf.shape[3])
+            if (H, W) != tuple(skip.buf.shape[2:]):
+                raise NotImplementedError('skip larger than the upsampled map')
+            keep = e['conv'].Cout
+            nlay = self.nlpb[self.n_pool + i + 1]
+            new = _Stack(B, keep + skip.n + g * nlay, H, W, dev, dt)
+            e['conv'](blk, window=((uh - H) // 2, (uw - W) // 2, H, W), out=new.buf, out_c0=0)
+            new.buf[:, keep:keep + skip.n].copy_(skip.buf[:, :skip.n])
+            new.added(keep + skip.n)
+            stack, block0 = new, new.n
+            for _ in range(nlay):
+                self._brc(it, stack, out=stack.buf, out_c0=stack.n)
+                stack.added(g)
+        score = next(it)['conv'](stack.view())                        # SoftmaxLayer's 1x1 conv
+        probs = ops.crop_softmax(score, H, W, off=(0, 0))
+        return hidden + [probs]
+
+
+def build_fcdensenet(input_var=None, layer=('pool4',), nb_in_channels=3, n_classes=11,
+                     output_d='4d', from_gt=False, weight_path=None, params=None, device='cuda',
+                     dtype=torch.float32):
+    """Mirror of models/FCDenseNet.py:196-219 (DenseNet103: 48 first filters, 5 pools, growth 16,
+    blocks [4,5,7,10,12,15,12,10,7,5,4]).  Weights: `params` (list in creation order) or an
+    `arr_%d` .npz (BN: beta, gamma, mean, inv_std; conv: W, b -- P10/P14)."""
+    if params is None:
+        if not weight_path:
+            raise ValueError('build_fcdensenet needs `params` or `weight_path`')
+        params = load_params(weight_path, layer_plan(nb_in_channels=nb_in_channels,
+                                                     n_classes=n_classes))
+    return FCDenseNet(params, n_classes, layer=layer, device=device, dtype=dtype)
+
+
+def load_params(path, plan):
+    with np.load(path) as f:
+        vals = [f['arr_%d' % i] for i in range(len(f.files))]
+    out, i = [], 0
+    for kind, _, _ in plan:
+        p = {'kind': kind}
+        if kind in ('brc', 'td'):
+            p['beta'], p['gamma'] = vals[i], vals[i + 1]      # mean, inv_std (i+2, i+3) unused:
+            i += 4                                            # batch statistics at inference
+        p['W'], p['b'] = vals[i], vals[i + 1]
+        i += 2
+        out.append(p)
+    if i != len(vals):
+        raise ValueError('%s holds %d arrays, the plan consumes %d' % (path, len(vals), i))
+    return out

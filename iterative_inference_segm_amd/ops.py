@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, check
+from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2, check
 
 # When set to a list, every conv launch appends (kernel, executed_flops, start_event, end_event):
 # HIP events recorded on the launch stream right around the kernel (bench.py's roofline leg).
@@ -50,8 +50,12 @@ class Conv:
     input geometry.  Weight layouts: 'oihw' (Lasagne Conv2DLayer W[out,in,kh,kw], P1) or
     'iohw' (DilatedConv2DLayer W[in,out,kh,kw], P11)."""
 
-    def __init__(self, W, b, pad, relu, dil=1, layout='oihw', device='cuda', dtype=torch.float32):
+    def __init__(self, W, b, pad, relu, dil=1, layout='oihw', device='cuda', dtype=torch.float32,
+                 transposed=False):
+        """transposed=True: 3x3 stride-2 transposed convolution, crop='valid' (Deconv2DLayer
+        W[in,out,3,3] -> layout 'iohw'); output (2H+1, 2W+1)."""
         self.lib = _lib.load()
+        self.transposed = bool(transposed)
         self.dtype = dtype
         self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
         self.b = None if b is None else torch.as_tensor(b).to(dtype).contiguous().to(device)
@@ -79,6 +83,8 @@ class Conv:
         self._plans = {}
 
     def out_hw(self, H, W):
+        if self.transposed:
+            return 2 * H + 1, 2 * W + 1
         return (H + 2 * self.pad - self.dil * (self.KH - 1),
                 W + 2 * self.pad - self.dil * (self.KW - 1))
 
@@ -86,8 +92,8 @@ class Conv:
         """Nominal 2*Cin*Cout*k*k*OH*OW*B (SURVEY 6.2 convention)."""
         return 2.0 * self.Cin * self.Cout * self.KH * self.KW * OH * OW * B
 
-    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool):
-        key = (B, C1, C2, H, W, window, add_geom, unpool)
+    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool, out_slice=None):
+        key = (B, C1, C2, H, W, window, add_geom, unpool, out_slice)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
@@ -101,7 +107,10 @@ class Conv:
         d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
         if add_geom is not None:
             d.AH, d.AW, d.ay0, d.ax0 = add_geom
-        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0)
+        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0) | \
+            (CONV_TRANSPOSED2 if self.transposed else 0)
+        if out_slice is not None:
+            d.out_ctot, d.out_c0 = out_slice
         so, sc = self.so, self.sc
         if self.via_im2col:
             # logical layer: 1x1 over C*KH*KW channels of the im2col'd tensor (OH x OW)
@@ -126,11 +135,12 @@ class Conv:
         return plan
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
-                 window=None, out=None):
+                 window=None, out=None, out_c0=None):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
-        `window` = (oy0, ox0, OH, OW) restricts the computed output region."""
+        `window` = (oy0, ox0, OH, OW) restricts the computed output region.  With `out_c0`
+        the result is written into channels [out_c0, out_c0+Cout) of the wider tensor `out`."""
         dt = self.dtype
         unpool = pre is not None
         B, C1 = x1.shape[0], x1.shape[1]
@@ -162,8 +172,13 @@ class Conv:
             d, wp, ktab = self._plan(B, C1, 0, H, W, None, add_geom, False)
             x1 = cols
         else:
-            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool)
-        if out is None:
+            out_slice = None if out_c0 is None else (out.shape[1], int(out_c0))
+            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool, out_slice)
+        if out_c0 is not None:
+            if self.via_im2col or tuple(out.shape[2:]) != (d.OH, d.OW) or out.shape[0] != B or \
+                    out.dtype != dt or out_c0 + self.Cout > out.shape[1]:
+                raise RuntimeError('bad output slice %s @%d' % (tuple(out.shape), out_c0))
+        elif out is None:
             out = torch.empty((B, self.Cout, d.OH, d.OW), dtype=dt, device=x1.device)
         elif tuple(out.shape) != (B, self.Cout, d.OH, d.OW) or out.dtype != dt:
             raise RuntimeError('out shape %s != %s' % (tuple(out.shape), (B, self.Cout, d.OH, d.OW)))
@@ -307,3 +322,29 @@ def confusion_accumulate(y, t, cm, sums):
     dt = y.dtype
     check(_fn('confusion', dt)(_stream(), _ptr(y, dt), _ptr(t, dt), _ptr(cm, torch.int64),
                                _ptr(sums, torch.float64), B, Cc, H * W), 'iiseg_confusion')
+
+
+def bn_stats(buf, c0, n, mean, inv_std, eps=1e-4):
+    """Batch statistics (P10) of channels [c0, c0+n) of `buf` (B, Ctot, H, W) into
+    mean[c0:c0+n], inv_std[c0:c0+n] (1-D tensors of length >= c0+n)."""
+    B, Ctot, H, W = buf.shape
+    dt = buf.dtype
+    item = buf.element_size()
+    _ptr(buf, dt), _ptr(mean, dt), _ptr(inv_std, dt)
+    xp = C.c_void_p(buf.data_ptr() + c0 * H * W * item)
+    check(_fn('bn_stats', dt)(_stream(), xp, Ctot * H * W, B, n, H * W, float(eps),
+                              C.c_void_p(mean.data_ptr() + c0 * item),
+                              C.c_void_p(inv_std.data_ptr() + c0 * item)), 'iiseg_bn_stats')
+
+
+def bn_relu(buf, n, beta, gamma, mean, inv_std, out=None):
+    """relu((x - mean) * (gamma * inv_std) + beta) of the first n channels of `buf`
+    (B, Ctot, H, W) -> dense (B, n, H, W)."""
+    B, Ctot, H, W = buf.shape
+    dt = buf.dtype
+    if out is None:
+        out = torch.empty((B, n, H, W), dtype=dt, device=buf.device)
+    check(_fn('bn_relu', dt)(_stream(), _ptr(buf, dt), Ctot * H * W, B, n, H * W, _ptr(beta, dt),
+                             _ptr(gamma, dt), _ptr(mean, dt), _ptr(inv_std, dt), _ptr(out, dt)),
+          'iiseg_bn_relu')
+    return out

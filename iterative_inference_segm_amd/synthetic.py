@@ -151,6 +151,27 @@ def make_fcn8_dae_params(n_classes=11, concat_h=('input',), h_channels=(3,), see
     return p
 
 
+def make_densenet_params(plan, seed=2024):
+    """FC-DenseNet parameters for a `layer_plan` (densenet.py): list of dicts in creation order.
+    Conv2DLayer W[out,in,k,k]; TransitionUp Deconv2DLayer W[in,out,3,3]; BN gamma/beta seeded
+    around (1, 0)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for kind, cin, cout in plan:
+        p = {'kind': kind}
+        if kind in ('brc', 'td'):
+            p['gamma'] = rng.uniform(0.5, 1.5, size=(cin,)).astype(np.float32)
+            p['beta'] = rng.uniform(-0.2, 0.2, size=(cin,)).astype(np.float32)
+        if kind == 'tu':
+            p['W'] = _he_uniform(rng, (cin, cout, 3, 3), cin * 9 / 4.0)
+        else:
+            k = 1 if kind in ('td', 'softmax') else 3
+            p['W'] = _he_uniform(rng, (cout, cin, k, k), cin * k * k)
+        p['b'] = _bias(rng, cout)
+        out.append(p)
+    return out
+
+
 def make_images(n, h=224, w=224, channels=3, seed=1234):
     """Uniform [0,1) float32 RGB batch (N,C,H,W)."""
     rng = np.random.default_rng(seed)

@@ -1,0 +1,36 @@
+"""Times the non-headline BASELINE configs on one MI355X (parity-test cases, not bench lines):
+  c3: FC-DenseNet103 + standard DAE (padding 0, h = pool4 464 ch @14^2), 224x224, batch 32, 10 steps
+  c2_f64: configs[1] network in the float64 strict-parity mode, batch 16
+Usage: python scripts/bench_configs.py [c3|c2_f64] [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from iterative_inference_segm_amd import synthetic as S
+from iterative_inference_segm_amd.api import IterativeInference
+from iterative_inference_segm_amd.dae import StandardDAE
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'c3'
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+if which == 'c3':
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    B, dt, gflop = 32, torch.float32, 254.6
+    net = FCDenseNet(S.make_densenet_params(layer_plan()), 11, layer=['pool4'])
+    dae = StandardDAE(S.make_dae_params(h_channels=(464,)), 11, padding=0)
+else:
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    B, dt, gflop = 16, torch.float64, 872.3
+    net = FCN8(S.make_fcn8_params(), 11, layer=['pool4', 'probs_dimshuffle'], dtype=dt)
+    dae = StandardDAE(S.make_dae_params(), 11, dtype=dt)
+ii = IterativeInference(net, dae, 11, [11], dtype=dt)
+X = torch.from_numpy(S.make_images(B, 224, 224)).to(dt).cuda()
+def step():
+    out = ii.pred_fcn_fn(X)
+    ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)
+step(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(reps):
+    step()
+torch.cuda.synchronize()
+dt_s = (time.perf_counter() - t0) / reps
+print('%s: batch %d, %.1f ms/batch, %.2f images/s, %.1f TFLOP/s nominal' %
+      (which, B, dt_s * 1e3, B / dt_s, B / dt_s * gflop / 1e3), flush=True)
