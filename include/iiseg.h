@@ -164,6 +164,15 @@ int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, 
 int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm, double* sums,
                         int32_t B, int32_t C, int32_t HW);
 
+/* Same accumulation restricted to images with active[b] != 0.  Used for the per-iteration Jaccard
+ * of the validation driver (iterative_inference_valid.py:231,280-288: `valid_mat[:, :, it] +=
+ * jacc_iter` only for images still iterating). */
+int iiseg_confusion_masked_f32(void* stream, const float* y, const float* t, const int32_t* active,
+                               int64_t* cm, double* sums, int32_t B, int32_t C, int32_t HW);
+int iiseg_confusion_masked_f64(void* stream, const double* y, const double* t,
+                               const int32_t* active, int64_t* cm, double* sums, int32_t B,
+                               int32_t C, int32_t HW);
+
 /* ---------------------------------------------------------------------------------------
  * Batch-statistics BatchNorm (+ReLU).  Replaces lasagne BatchNormLayer under
  * batch_norm_use_averages=False (iterative_inference.py:187) followed by the rectify

@@ -37,48 +37,13 @@ def _copy_tree(src, dst):
     shutil.copytree(src, dst, dirs_exist_ok=True)
 
 
-def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_updates={},
-              training_dict={}, data_augmentation=False, which_set='test', ae_h=False,
-              full_im_ft=False, savepath=None, loadpath=None, test_from_0_255=False,
-              weights_path=None, synthetic=False, n_images=20, image_size=(224, 224),
-              batch_size=10, early_stop=True, save_npz=True, verbose=True):
-    """Signature of reference iterative_inference.py:56-59 plus keyword-only extras.
-    Returns a dict of the three summary lines (the reference returns None and only prints)."""
-    # Update DAE parameters (:64-79)
-    dae_dict = {'kind': 'fcn8', 'dropout': 0.0, 'skip': True, 'unpool_type': 'standard',
-                'n_filters': 64, 'conv_before_pool': 1, 'additional_pool': 0,
-                'concat_h': ['input'], 'noise': 0.0, 'from_gt': True, 'temperature': 1.0,
-                'layer': 'probs_dimshuffle', 'exp_name': '', 'bn': 0}
-    dae_dict.update(dae_dict_updates)
-
-    # Prepare load/save directories (:84-104)
-    name_kw = dict(dae_dict)
-    name_kw.update(training_dict)
-    exp_name = build_experiment_name(segm_net, data_aug=data_augmentation, ae_h=ae_h, **name_kw)
-    if savepath is None:
-        raise ValueError('A saving directory must be specified')
-
-    rank, world, device = iidist.init_from_env()
-    say = print if (verbose and rank == 0) else (lambda *a, **k: None)
-    loadpath = loadpath if loadpath is not None else LOADPATH
-    weights_path = weights_path if weights_path is not None else WEIGHTS_PATH
-    savepath = os.path.join(savepath, dataset, exp_name, 'img_plots', which_set)
-    loadpath = os.path.join(loadpath, dataset, exp_name)
-    if rank == 0:
-        if not os.path.exists(savepath):
-            os.makedirs(savepath)
-        else:
-            say('\033[93m The following folder already exists {}. '
-                'It will be overwritten in a few seconds...\033[0m'.format(savepath))
-        say('Saving directory : ' + savepath)
-        with open(os.path.join(savepath, 'config.txt'), 'w') as f:
-            for key, value in sorted(locals().items()):
-                if key not in ('f', 'say'):
-                    f.write('{} = {}\n'.format(key, value))
-    iidist.barrier()
-
+def build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_set, device,
+                   synthetic=False, n_images=20, image_size=(224, 224), batch_size=10,
+                   val_batch_size=5, test_from_0_255=False, say=print):
+    """Data iterator + segmentation net + DAE as the reference builds them
+    (iterative_inference.py:114-179).  Returns (ii, data_iter)."""
     # Build dataset iterator (:117-125)
-    data_iter = load_data(dataset, {}, one_hot=True, batch_size=[batch_size, 5, batch_size],
+    data_iter = load_data(dataset, {}, one_hot=True, batch_size=[batch_size, val_batch_size, batch_size],
                           return_0_255=test_from_0_255, which_set=which_set, synthetic=synthetic,
                           n_images=n_images, image_size=image_size)
     n_batches_test = data_iter.nbatches
@@ -176,6 +141,57 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
         raise ValueError('Unknown dae kind')                     # :178-179
 
     ii = IterativeInference(fcn, dae, n_classes, void_labels, device=device)
+    return ii, data_iter
+
+
+def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_updates={},
+              training_dict={}, data_augmentation=False, which_set='test', ae_h=False,
+              full_im_ft=False, savepath=None, loadpath=None, test_from_0_255=False,
+              weights_path=None, synthetic=False, n_images=20, image_size=(224, 224),
+              batch_size=10, early_stop=True, save_npz=True, verbose=True):
+    """Signature of reference iterative_inference.py:56-59 plus keyword-only extras.
+    Returns a dict of the three summary lines (the reference returns None and only prints)."""
+    # Update DAE parameters (:64-79)
+    dae_dict = {'kind': 'fcn8', 'dropout': 0.0, 'skip': True, 'unpool_type': 'standard',
+                'n_filters': 64, 'conv_before_pool': 1, 'additional_pool': 0,
+                'concat_h': ['input'], 'noise': 0.0, 'from_gt': True, 'temperature': 1.0,
+                'layer': 'probs_dimshuffle', 'exp_name': '', 'bn': 0}
+    dae_dict.update(dae_dict_updates)
+
+    # Prepare load/save directories (:84-104)
+    name_kw = dict(dae_dict)
+    name_kw.update(training_dict)
+    exp_name = build_experiment_name(segm_net, data_aug=data_augmentation, ae_h=ae_h, **name_kw)
+    if savepath is None:
+        raise ValueError('A saving directory must be specified')
+
+    rank, world, device = iidist.init_from_env()
+    say = print if (verbose and rank == 0) else (lambda *a, **k: None)
+    loadpath = loadpath if loadpath is not None else LOADPATH
+    weights_path = weights_path if weights_path is not None else WEIGHTS_PATH
+    savepath = os.path.join(savepath, dataset, exp_name, 'img_plots', which_set)
+    loadpath = os.path.join(loadpath, dataset, exp_name)
+    if rank == 0:
+        if not os.path.exists(savepath):
+            os.makedirs(savepath)
+        else:
+            say('\033[93m The following folder already exists {}. '
+                'It will be overwritten in a few seconds...\033[0m'.format(savepath))
+        say('Saving directory : ' + savepath)
+        with open(os.path.join(savepath, 'config.txt'), 'w') as f:
+            for key, value in sorted(locals().items()):
+                if key not in ('f', 'say'):
+                    f.write('{} = {}\n'.format(key, value))
+    iidist.barrier()
+
+    ii, data_iter = build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_set,
+                                   device, synthetic=synthetic, n_images=n_images,
+                                   image_size=image_size, batch_size=batch_size,
+                                   test_from_0_255=test_from_0_255, say=say)
+    n_batches_test = data_iter.nbatches
+    n_classes = data_iter.non_void_nclasses
+    void_labels = data_iter.void_labels
+
 
     # Infer (:215-294); batches shard over ranks, every reference batch on exactly one rank
     say('Start infering')

@@ -51,6 +51,8 @@ SIGNATURES = {
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
     'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_confusion_masked_f32': (C.c_int, [_vp] * 6 + [_i32] * 3),
+    'iiseg_confusion_masked_f64': (C.c_int, [_vp] * 6 + [_i32] * 3),
     'iiseg_bn_stats_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp]),
     'iiseg_bn_relu_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
     'iiseg_bn_stats_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _vp]),

@@ -83,13 +83,19 @@ class IterativeInference:
         return m
 
     # ---- fused loop ---------------------------------------------------------------------
-    def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False):
+    def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
+               per_iter_target=None):
         """Batched replacement of iterative_inference.py:258-284.
 
         for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
                                     y = clip(y - step*(y - softmax(score)), 0, 1)  # :270-273
                                     per image: stop once mean_px ||de||_2 < eps     # :275-277
         Returns (Y_ii, iters_used[B] int32, last_norm[B] float64), all on the device.
+
+        `per_iter_target` (one-hot T): also returns a (num_iter, C*(C+1)) int64 tensor of
+        per-iteration confusion counts over the images still iterating after that iteration --
+        the `valid_mat[:, :, it] += jacc_iter` of iterative_inference_valid.py:231,280-288 (the
+        reference calls val_fn only when the loop did not break).
         """
         H = [self._dev(h) for h in (H if isinstance(H, (list, tuple)) else [H])]
         y = self._dev(Y)
@@ -98,10 +104,20 @@ class IterativeInference:
         B, _, Hh, Ww = y.shape
         st = ops.RefineState(B, Hh, Ww, y.device)
         eps_eff = eps if early_stop else -1.0
-        for _ in range(int(num_iter)):
+        per_iter = None
+        if per_iter_target is not None:
+            T = self._dev(per_iter_target)
+            nb = self.n_classes * (self.n_classes + 1)
+            per_iter = torch.zeros((int(num_iter), nb), dtype=torch.int64, device=y.device)
+            scratch = torch.zeros(2, dtype=torch.float64, device=y.device)
+        for it in range(int(num_iter)):
             score = self.dae.scores(H, y)
             ops.refine_update(score, y, st, step, off=(0, 0))
             ops.refine_finalize(st, eps_eff)
+            if per_iter is not None:
+                ops.confusion_accumulate(y, T, per_iter[it], scratch, active=st.active)
+        if per_iter is not None:
+            return y, st.iters, st.last_norm, per_iter
         return y, st.iters, st.last_norm
 
     def _dev(self, a):

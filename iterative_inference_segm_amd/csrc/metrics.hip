@@ -12,6 +12,7 @@ constexpr int MAXC = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
                                                         const T* __restrict__ t,
+                                                        const int* __restrict__ active,
                                                         unsigned long long* __restrict__ cm,
                                                         double* __restrict__ sums, int C, int HW) {
     __shared__ unsigned int bins[MAXC * (MAXC + 1)];
@@ -22,7 +23,10 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     double se = 0.0, mk = 0.0;
-    if (pix < HW) {
+    // images whose flag is 0 are skipped (per-iteration metrics of the validation driver only
+    // count images still being refined, iterative_inference_valid.py:280-288)
+    const bool on = !active || active[b] != 0;
+    if (pix < HW && on) {
         const T* yp = y + (size_t)b * C * HW + pix;
         const T* tp = t + (size_t)b * (C + 1) * HW + pix;
         // argmax returns the FIRST maximal index (T.argmax / np.argmax)
@@ -58,14 +62,14 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
 }
 
 template <typename T>
-int confusion(void* stream, const T* y, const T* t, int64_t* cm, double* sums, int32_t B, int32_t C,
-              int32_t HW) {
+int confusion(void* stream, const T* y, const T* t, const int32_t* active, int64_t* cm, double* sums,
+              int32_t B, int32_t C, int32_t HW) {
     if (!y || !t || !cm || !sums) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
     if (C >= MAXC || B > 65535) return IISEG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(confusion_kernel<T>, dim3((HW + 255) / 256, B), dim3(256), 0,
-                       (hipStream_t)stream, y, t, reinterpret_cast<unsigned long long*>(cm), sums,
-                       C, HW);
+                       (hipStream_t)stream, y, t, active,
+                       reinterpret_cast<unsigned long long*>(cm), sums, C, HW);
     return iiseg_check_launch();
 }
 
@@ -73,9 +77,22 @@ int confusion(void* stream, const T* y, const T* t, int64_t* cm, double* sums, i
 
 extern "C" int iiseg_confusion_f32(void* stream, const float* y, const float* t, int64_t* cm,
                                    double* sums, int32_t B, int32_t C, int32_t HW) {
-    return confusion<float>(stream, y, t, cm, sums, B, C, HW);
+    return confusion<float>(stream, y, t, nullptr, cm, sums, B, C, HW);
 }
 extern "C" int iiseg_confusion_f64(void* stream, const double* y, const double* t, int64_t* cm,
                                    double* sums, int32_t B, int32_t C, int32_t HW) {
-    return confusion<double>(stream, y, t, cm, sums, B, C, HW);
+    return confusion<double>(stream, y, t, nullptr, cm, sums, B, C, HW);
+}
+
+extern "C" int iiseg_confusion_masked_f32(void* stream, const float* y, const float* t,
+                                          const int32_t* active, int64_t* cm, double* sums,
+                                          int32_t B, int32_t C, int32_t HW) {
+    if (!active) return IISEG_ERR_NULL;
+    return confusion<float>(stream, y, t, active, cm, sums, B, C, HW);
+}
+extern "C" int iiseg_confusion_masked_f64(void* stream, const double* y, const double* t,
+                                          const int32_t* active, int64_t* cm, double* sums,
+                                          int32_t B, int32_t C, int32_t HW) {
+    if (!active) return IISEG_ERR_NULL;
+    return confusion<double>(stream, y, t, active, cm, sums, B, C, HW);
 }

@@ -313,13 +313,20 @@ def refine_finalize(state, eps):
                                     state.H * state.W, float(eps)), 'iiseg_refine_finalize')
 
 
-def confusion_accumulate(y, t, cm, sums):
-    """cm (C*(C+1)) int64 and sums (2) float64 are accumulated in place."""
+def confusion_accumulate(y, t, cm, sums, active=None):
+    """cm (C*(C+1)) int64 and sums (2) float64 are accumulated in place; with `active` (B int32)
+    only images whose flag is non-zero are counted."""
     B, Cc, H, W = y.shape
     if tuple(t.shape) != (B, Cc + 1, H, W):
         raise RuntimeError('target must be one-hot (B,C+1,H,W) with void last, got %s'
                            % (tuple(t.shape),))
     dt = y.dtype
+    if active is not None:
+        check(_fn('confusion_masked', dt)(_stream(), _ptr(y, dt), _ptr(t, dt),
+                                          _ptr(active, torch.int32), _ptr(cm, torch.int64),
+                                          _ptr(sums, torch.float64), B, Cc, H * W),
+              'iiseg_confusion_masked')
+        return
     check(_fn('confusion', dt)(_stream(), _ptr(y, dt), _ptr(t, dt), _ptr(cm, torch.int64),
                                _ptr(sums, torch.float64), B, Cc, H * W), 'iiseg_confusion')
 

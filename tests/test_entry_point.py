@@ -101,3 +101,46 @@ def test_synthetic_evaluation_end_to_end(built_lib, tmp_path):
     assert out['ii']['batches'] == 2
     assert abs(out['ii']['jaccard'] - miou_r) <= 0.05            # north_star: mIoU within +-0.05
     assert abs(out['ii']['acc'] - acc_r) <= 1e-3 and abs(out['ii']['loss'] - loss_r) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_valid_driver_per_iteration_jaccard(built_lib, tmp_path):
+    """iterative_inference_valid.inference: per-iteration mean Jaccard over images still
+    iterating == the oracle's restatement of valid_mat (reference :231,265-288,298), including an
+    image that stops early (big eps via a tiny step is not available, so we stop by eps below)."""
+    import torch
+    import iterative_inference_valid as iv
+    from oracle import dae as odae, fcn8 as ofcn8, metrics as ometrics
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.data_loader import load_data
+    dd = {'kind': 'standard', 'unpool_type': 'trackind', 'n_filters': 4, 'additional_pool': 2,
+          'concat_h': ['pool4'], 'skip': True, 'from_gt': False}
+    res = iv.inference('camvid', 'fcn8', 0.3, 3, dae_dict_updates=dd, which_set='val',
+                       savepath=str(tmp_path / 's'), loadpath=str(tmp_path / 'l'),
+                       weights_path=str(tmp_path / 'w'), synthetic=True, n_images=3,
+                       image_size=(32, 32), batch_size=2, verbose=False)
+    assert res.shape == (3,)
+    # oracle restatement with the same synthetic nets (full-width FCN-8 at 32x32 is cheap)
+    fp = S.make_fcn8_params(3, 11, seed=1234)
+    dp = S.make_dae_params(11, (512,), ['pool4'], 4, 1, 2, 'trackind', seed=4321)
+    to64 = lambda p: {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in p.items()}
+    fp64, dp64 = to64(fp), to64(dp)
+    it = load_data('camvid', {}, one_hot=True, batch_size=[2, 2, 2], which_set='val',
+                   synthetic=True, n_images=3, image_size=(32, 32))
+    valid_mat = np.zeros((2, 11, 3))
+    for i in range(it.nbatches):
+        X, L = it.batch(i)
+        h, y = ofcn8.fcn8_forward(fp64, X.astype(np.float64), layer=['pool4', 'probs_dimshuffle'])
+        for im in range(X.shape[0]):
+            y_im, h_im, t_im = y[im:im + 1], [h[im:im + 1]], L[im:im + 1].astype(np.float64)
+            for k in range(3):                                    # :265-288
+                grad = y_im - odae.dae_forward(dp64, h_im, y_im, n_filters=4)
+                y_im = np.clip(y_im - 0.3 * grad, 0, 1)
+                if np.linalg.norm(grad, axis=1).mean() < 1e-3:
+                    break
+                valid_mat[:, :, k] += ometrics.jaccard(y_im, t_im, 11)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ref = np.nanmean(valid_mat[0] / valid_mat[1], axis=0)
+    assert np.allclose(res, ref, atol=2e-3, equal_nan=True)
+    saved = tmp_path / 's' / 'camvid'
+    assert any(f.name.startswith('iterations0.3') for f in saved.rglob('*.npz'))
