@@ -33,7 +33,7 @@ GFLOP_PER_IMAGE = 872.3          # 119.24 (FCN-8) + 10 x 75.31 (DAE)
 PEAK_TFLOPS_F32_MFMA = 157.3     # MI355X_MICROARCH.md, fp32 matrix peak
 # HBM bytes per conv_taps launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
 # MI355X_MICROARCH.md HBM section); filled from profiles/, None until measured
-TRAFFIC_GB_PER_LAUNCH = None
+TRAFFIC_GB_PER_LAUNCH = 2.18   # profiles/r01_pmc_hbm_traffic.md: 1.349 (read, x2) + 0.831 (write)
 
 
 def build_model(device, concat_h):
@@ -88,6 +88,7 @@ def conv_roofline(ii, X, T, num_iter, step_size):
     return {'bound': 'mfma', 'kernel': 'conv_taps_f32_kernel', 'achieved': round(achieved, 2),
             'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_TFLOPS_F32_MFMA, 4), 'traffic': TRAFFIC_GB_PER_LAUNCH,
+            'traffic_unit': 'GB of HBM traffic per launch (rocprofv3 PMC, profiles/)',
             'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
             'gflop_per_launch': round(flops / n / 1e9, 3), 'kernel_ms_per_step': round(ms, 2),
             'all_conv_ms_per_step': round(all_ms, 2)}
