@@ -73,6 +73,11 @@ typedef struct iiseg_conv_desc {
      * out_c0 -- lets dense blocks grow a preallocated stack without concat copies
      * (ConcatLayer([stack, l]), models/FCDenseNet.py:92).  out_ctot == 0: dense (B, Cout, OH, OW). */
     int32_t out_ctot, out_c0;
+    /* destination as a spatial window of a larger plane: the (OH, OW) result is written at
+     * (out_y0, out_x0) of planes of size (out_H, out_W).  out_H == 0: dense (OH, OW) planes.
+     * Used to compute only the part of a decoder level that reaches the final center crop
+     * (models/fcn_up.py:104-113) while every tensor keeps its full-size addressing. */
+    int32_t out_H, out_W, out_y0, out_x0;
 } iiseg_conv_desc;
 
 /* Number of int32x4 entries of the gather table for `d` (== d->Kpad). */
@@ -107,6 +112,11 @@ int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC, i
  * out[y,x] = (y < 2h && x < 2w && pre[y,x] == pooled[y/2,x/2]) ? up[y/2,x/2] : 0 */
 int iiseg_unpool_eqmask_f32(void* stream, const float* up, const float* pre,
                             const float* pooled, float* out, int32_t BC, int32_t H, int32_t W);
+/* The same, restricted to the window [y0,y0+wh) x [x0,x0+ww) of the (H,W) planes (in place:
+ * elements outside the window are not written). */
+int iiseg_unpool_eqmask_window_f32(void* stream, const float* up, const float* pre,
+                                   const float* pooled, float* out, int32_t BC, int32_t H,
+                                   int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww);
 
 /* ---------------------------------------------------------------------------------------
  * Small-channel transposed convolution (gather form), crop='valid', linear.
@@ -214,6 +224,9 @@ int iiseg_maxpool2x2_f64(void* stream, const double* x, double* out, int32_t BC,
                          int32_t W);
 int iiseg_unpool_eqmask_f64(void* stream, const double* up, const double* pre,
                             const double* pooled, double* out, int32_t BC, int32_t H, int32_t W);
+int iiseg_unpool_eqmask_window_f64(void* stream, const double* up, const double* pre,
+                                   const double* pooled, double* out, int32_t BC, int32_t H,
+                                   int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww);
 int iiseg_deconv_f64(void* stream, const iiseg_deconv_desc* d, const double* x, const double* w,
                      const double* bias, const double* add, double* out);
 int iiseg_crop_softmax_f64(void* stream, const double* score, const double* minuend, double* out,

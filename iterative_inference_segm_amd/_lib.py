@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -22,7 +22,9 @@ class ConvDesc(C.Structure):
                 ('B', 'C1', 'C2', 'H', 'W', 'Cout', 'KH', 'KW', 'pad', 'dil',
                  'oy0', 'ox0', 'OH', 'OW', 'AH', 'AW', 'ay0', 'ax0')] + \
                [('flags', C.c_uint32), ('Kpad', C.c_int32), ('Mpad', C.c_int32),
-                ('out_ctot', C.c_int32), ('out_c0', C.c_int32)]
+                ('out_ctot', C.c_int32), ('out_c0', C.c_int32),
+                ('out_H', C.c_int32), ('out_W', C.c_int32), ('out_y0', C.c_int32),
+                ('out_x0', C.c_int32)]
 
 
 class DeconvDesc(C.Structure):
@@ -45,6 +47,8 @@ SIGNATURES = {
     'iiseg_conv_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_maxpool2x2_f32': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
     'iiseg_unpool_eqmask_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]),
+    'iiseg_unpool_eqmask_window_f32': (C.c_int, [_vp] * 5 + [_i32] * 7),
+    'iiseg_unpool_eqmask_window_f64': (C.c_int, [_vp] * 5 + [_i32] * 7),
     'iiseg_deconv_f32': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),
     'iiseg_crop_softmax_f32': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8),
     'iiseg_refine_partials': (C.c_int, [_i32, _i32]),

@@ -41,6 +41,7 @@ struct ConvParams {
     int debug_nogather;
     int out_ctot, out_c0;  // destination channel slice (out_ctot == Cout, out_c0 == 0: dense)
     int transposed;        // 3x3 stride-2 transposed convolution (conv_taps only)
+    int out_H, out_W, out_y0, out_x0;  // destination planes / placement (dense: OH, OW, 0, 0)
 };
 
 // Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give
@@ -74,11 +75,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p,
         if (pe >= p.P) continue;
         const int eb = pe / OHW;
         const int rem = pe - eb * OHW;
-        float* outp = p.out + ((size_t)eb * p.out_ctot + p.out_c0) * OHW + rem;
+        const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
+        const size_t OPL = (size_t)p.out_H * p.out_W;  // destination plane (dense: OH*OW)
+        float* outp = p.out + ((size_t)eb * p.out_ctot + p.out_c0) * OPL +
+                      (size_t)(p.out_y0 + eoy) * p.out_W + p.out_x0 + eox;
         const float* addp = nullptr;
         size_t AHW = 0;
         if (p.add) {
-            const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
             AHW = (size_t)p.AH * p.AW;
             addp = p.add + (size_t)eb * p.Cout * AHW + (size_t)(p.ay0 + eoy) * p.AW + p.ax0 + eox;
         }
@@ -92,7 +95,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p,
                     if (p.bias) v += p.bias[co];
                     if (addp) v += addp[(size_t)co * AHW];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    outp[(size_t)co * OHW] = v;
+                    outp[(size_t)co * OPL] = v;
                 }
             }
         }

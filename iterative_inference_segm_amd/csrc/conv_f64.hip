@@ -49,6 +49,7 @@ struct ConvParams64 {
     int relu;
     int out_ctot, out_c0;
     int transposed;
+    int out_H, out_W, out_y0, out_x0;
 };
 
 __device__ __forceinline__ double buf_ld64(const double* base, int bytes, unsigned voff, unsigned soff) {
@@ -216,11 +217,13 @@ __global__ __launch_bounds__(256) void conv_taps_f64_kernel(const ConvParams64 p
         if (pe >= p.P) continue;
         const int eb = pe / OHW;
         const int rem = pe - eb * OHW;
-        double* outp = p.out + ((size_t)eb * p.out_ctot + p.out_c0) * OHW + rem;
+        const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
+        const size_t OPL = (size_t)p.out_H * p.out_W;
+        double* outp = p.out + ((size_t)eb * p.out_ctot + p.out_c0) * OPL +
+                       (size_t)(p.out_y0 + eoy) * p.out_W + p.out_x0 + eox;
         const double* addp = nullptr;
         size_t AHW = 0;
         if (p.add) {
-            const int eoy = rem / p.OW, eox = rem - eoy * p.OW;
             AHW = (size_t)p.AH * p.AW;
             addp = p.add + (size_t)eb * p.Cout * AHW + (size_t)(p.ay0 + eoy) * p.AW + p.ax0 + eox;
         }
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_taps_f64_kernel(const ConvParams64 p
                     if (p.bias) v += p.bias[co];
                     if (addp) v += addp[(size_t)co * AHW];
                     if (p.relu) v = fmax(v, 0.0);
-                    outp[(size_t)co * OHW] = v;
+                    outp[(size_t)co * OPL] = v;
                 }
             }
     }
@@ -307,6 +310,9 @@ int check64(const iiseg_conv_desc* d) {
         return IISEG_ERR_SHAPE;
     if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot))
         return IISEG_ERR_SHAPE;
+    if (d->out_H != 0 && (d->out_y0 < 0 || d->out_x0 < 0 || d->out_y0 + d->OH > d->out_H ||
+                          d->out_x0 + d->OW > d->out_W))
+        return IISEG_ERR_SHAPE;
     const int C = d->C1 + d->C2, T = d->KH * d->KW;
     if (d->Kpad != (C + cpt - 1) / cpt * cpt * T || d->Mpad != (d->Cout + BM - 1) / BM * BM)
         return IISEG_ERR_SHAPE;
@@ -371,6 +377,10 @@ extern "C" int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const doub
     p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
     p.out_c0 = d->out_ctot ? d->out_c0 : 0;
     p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
+    p.out_H = d->out_H ? d->out_H : d->OH;
+    p.out_W = d->out_H ? d->out_W : d->OW;
+    p.out_y0 = d->out_H ? d->out_y0 : 0;
+    p.out_x0 = d->out_H ? d->out_x0 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (d->KH == 3) return launch64<3, 3, 4>(s, p, unpool);
     return launch64<1, 1, 16>(s, p, unpool);

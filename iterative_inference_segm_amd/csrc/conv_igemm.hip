@@ -347,6 +347,9 @@ static int check_desc(const iiseg_conv_desc* d) {
         return IISEG_ERR_SHAPE;
     if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot))
         return IISEG_ERR_SHAPE;
+    if (d->out_H != 0 && (d->out_y0 < 0 || d->out_x0 < 0 || d->out_y0 + d->OH > d->out_H ||
+                          d->out_x0 + d->OW > d->out_W))
+        return IISEG_ERR_SHAPE;
     const int bm = pick_bm(d->Cout);
     if (d->Kpad != kpad_for(d) || d->Mpad != (d->Cout + bm - 1) / bm * bm) return IISEG_ERR_SHAPE;
     // int32 index ranges used by the kernel: pixel index, and the per-tile relative BYTE offsets
@@ -420,6 +423,10 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
     p.out_c0 = d->out_ctot ? d->out_c0 : 0;
     p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
+    p.out_H = d->out_H ? d->out_H : d->OH;
+    p.out_W = d->out_H ? d->out_W : d->OW;
+    p.out_y0 = d->out_H ? d->out_y0 : 0;
+    p.out_x0 = d->out_H ? d->out_x0 : 0;
     p.P = d->B * d->OH * d->OW;
     p.n_ptiles = p.n_mtiles = 0;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;

@@ -47,6 +47,28 @@ __global__ __launch_bounds__(256) void unpool_eqmask_kernel(const T* __restrict_
     }
 }
 
+// window form: only [y0,y0+wh) x [x0,x0+ww) of every (H,W) plane is produced, in place
+template <typename T>
+__global__ __launch_bounds__(256) void unpool_eqmask_window_kernel(
+    const T* __restrict__ up, const T* __restrict__ pre, const T* __restrict__ pooled,
+    T* __restrict__ out, int BC, int H, int W, int h, int w, int y0, int x0, int wh, int ww) {
+    const size_t n = (size_t)BC * wh * ww;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = x0 + (int)(i % ww);
+        const size_t t = i / ww;
+        const int y = y0 + (int)(t % wh);
+        const size_t bc = t / wh;
+        const size_t o = (bc * H + y) * (size_t)W + x;
+        T v = 0;
+        if (y < 2 * h && x < 2 * w) {
+            const size_t j = (bc * h + (y >> 1)) * (size_t)w + (x >> 1);
+            v = (pre[o] == pooled[j]) ? up[j] : (T)0;
+        }
+        out[o] = v;
+    }
+}
+
 inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -72,7 +94,33 @@ int unpool(void* stream, const T* up, const T* pre, const T* pooled, T* out, int
     return iiseg_check_launch();
 }
 
+template <typename T>
+int unpool_window(void* stream, const T* up, const T* pre, const T* pooled, T* out, int32_t BC,
+                  int32_t H, int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww) {
+    if (!up || !pre || !pooled || !out) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2 || y0 < 0 || x0 < 0 || wh <= 0 || ww <= 0 || y0 + wh > H ||
+        x0 + ww > W)
+        return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(unpool_eqmask_window_kernel<T>, dim3(grid_for((size_t)BC * wh * ww)),
+                       dim3(256), 0, (hipStream_t)stream, up, pre, pooled, out, BC, H, W, H / 2,
+                       W / 2, y0, x0, wh, ww);
+    return iiseg_check_launch();
+}
+
 }  // namespace
+
+extern "C" int iiseg_unpool_eqmask_window_f32(void* stream, const float* up, const float* pre,
+                                              const float* pooled, float* out, int32_t BC,
+                                              int32_t H, int32_t W, int32_t y0, int32_t x0,
+                                              int32_t wh, int32_t ww) {
+    return unpool_window<float>(stream, up, pre, pooled, out, BC, H, W, y0, x0, wh, ww);
+}
+extern "C" int iiseg_unpool_eqmask_window_f64(void* stream, const double* up, const double* pre,
+                                              const double* pooled, double* out, int32_t BC,
+                                              int32_t H, int32_t W, int32_t y0, int32_t x0,
+                                              int32_t wh, int32_t ww) {
+    return unpool_window<double>(stream, up, pre, pooled, out, BC, H, W, y0, x0, wh, ww);
+}
 
 extern "C" int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC,
                                     int32_t H, int32_t W) {

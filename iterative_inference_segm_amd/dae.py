@@ -75,6 +75,8 @@ class StandardDAE:
         self.conv_log = None
         # DePool2D fused into the conv's gather (3 loads per element) or materialised first
         self.fuse_unpool = os.environ.get('IISEG_FUSE_UNPOOL', '0') != '0'
+        # compute each decoder level only on the window that reaches the final crop
+        self.dce = os.environ.get('IISEG_DECODER_DCE', '1') != '0'
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
 
     def conv_layers(self):
@@ -114,13 +116,34 @@ class StandardDAE:
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')
-        for p in range(self.total, 0, -1):               # fcn_up.py:143-151, UnpoolNet
-            name = 'up_conv%d' % p
-            conv = self.dec[name]
+        # ---- decoder, fcn_up.py:143-151 / UnpoolNet ------------------------------------------
+        # Only the final center crop (fused_up1) is an output, so each level is computed just on
+        # the window that reaches it (dead-code elimination, bit-identical results): level p
+        # needs fused_up_{p+1} on [floor((lo-1)/2), ceil((hi+1)/2)).  Tensors keep their full-size
+        # addressing; windows are written in place (`place`), the rest is never read.
+        geom = {}
+        for p in range(self.total, 0, -1):
             ph, pw = pre[p].shape[2], pre[p].shape[3]    # up_conv 'same' keeps the pre-pool size
             other = pool[p - 1]                          # pre-concat pool (or the input for p=1)
             oh, ow = min(ph, other.shape[2]), min(pw, other.shape[3])
-            window = (_center(ph, oh), _center(pw, ow), oh, ow)
+            geom[p] = (ph, pw, oh, ow, _center(ph, oh), _center(pw, ow))
+        need = {1: (0, 0, geom[1][2], geom[1][3])}       # (y0, x0, h, w) in fused_up_p coords
+        for p in range(1, self.total):
+            ph, pw, oh, ow, cy, cx = geom[p]
+            y0, x0, nh, nw = need[p] if self.dce else (0, 0, oh, ow)
+            uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)          # unpooled input rows/cols
+            uy1, ux1 = min(cy + y0 + nh + 1, ph), min(cx + x0 + nw + 1, pw)
+            qh, qw = geom[p + 1][2], geom[p + 1][3]                      # fused_up_{p+1} dims
+            ny0, nx0 = uy0 // 2, ux0 // 2
+            ny1, nx1 = min((uy1 + 1) // 2, qh), min((ux1 + 1) // 2, qw)
+            need[p + 1] = (ny0, nx0, ny1 - ny0, nx1 - nx0) if self.dce else (0, 0, qh, qw)
+        for p in range(self.total, 0, -1):
+            name = 'up_conv%d' % p
+            conv = self.dec[name]
+            ph, pw, oh, ow, cy, cx = geom[p]
+            other = pool[p - 1]
+            y0, x0, nh, nw = need[p]
+            window = (cy + y0, cx + x0, nh, nw)
             mpre, mpool = pre[p], pool[p]
             if mask_override and p in mask_override:
                 mpre, mpool = mask_override[p]
@@ -129,28 +152,36 @@ class StandardDAE:
                 # limited by its vector-memory instructions, so for wide layers it is faster to
                 # materialise DePool2D with the HBM-bound kernel and run the plain conv; the
                 # narrow last layer (Cout = 11, HBM-bound itself) keeps the fused form.
-                t = ops.unpool_eqmask(t, mpre, mpool)
+                uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)
+                uy1, ux1 = min(cy + y0 + nh + 1, ph), min(cx + x0 + nw + 1, pw)
+                u = torch.empty_like(mpre)
+                t = ops.unpool_eqmask(t, mpre, mpool, out=u, window=(uy0, ux0, uy1 - uy0, ux1 - ux0))
                 mpre = mpool = None
+            full = (nh, nw) == (oh, ow)
+            out = None if full else torch.empty((y.shape[0], conv.Cout, oh, ow), dtype=y.dtype,
+                                                device=y.device)
+            kw = dict(pre=mpre, pooled=mpool, window=window, out=out,
+                      place=None if full else (y0, x0))
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
-                t = conv(t, pre=mpre, pooled=mpool, add=other,
-                         add_off=(_center(other.shape[2], oh), _center(other.shape[3], ow)),
-                         window=window)
-            else:                                        # :104-113 CroppingLayer
-                t = conv(t, pre=mpre, pooled=mpool, window=window)
-            self._count(name, conv, t, full=(ph, pw))
+                kw.update(add=other, add_off=(_center(other.shape[2], oh) + y0,
+                                              _center(other.shape[3], ow) + x0))
+            t = conv(t, **kw)                            # else :104-113 CroppingLayer
+            self._count(name, conv, t, full=(ph, pw), computed=(nh, nw))
             if self.trace is not None:
                 self.trace['fused_up%d' % p] = t
+                self.trace['need%d' % p] = need[p]
         if self.trace is not None:
             self.trace.update({'pre%d' % k: v for k, v in pre.items()})
             self.trace.update({'pool%d' % k: v for k, v in pool.items() if k > 0})
         return t
 
-    def _count(self, name, conv, out, full=None):
+    def _count(self, name, conv, out, full=None, computed=None):
         # (name, nominal FLOPs of the FULL layer output, FLOPs of the computed window)
         if self.conv_log is not None:
             oh, ow = full if full is not None else (out.shape[2], out.shape[3])
+            ch, cw = computed if computed is not None else (out.shape[2], out.shape[3])
             self.conv_log.append((name, conv.flops(out.shape[0], oh, ow),
-                                  conv.flops(out.shape[0], out.shape[2], out.shape[3])))
+                                  conv.flops(out.shape[0], ch, cw)))
 
     def __call__(self, *args):
         """pred_dae_fn(h..., y) -> r  (softmax output, models/fcn_up.py:154-169)."""

@@ -92,8 +92,8 @@ class Conv:
         """Nominal 2*Cin*Cout*k*k*OH*OW*B (SURVEY 6.2 convention)."""
         return 2.0 * self.Cin * self.Cout * self.KH * self.KW * OH * OW * B
 
-    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool, out_slice=None):
-        key = (B, C1, C2, H, W, window, add_geom, unpool, out_slice)
+    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool, out_slice=None, place=None):
+        key = (B, C1, C2, H, W, window, add_geom, unpool, out_slice, place)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
@@ -111,6 +111,8 @@ class Conv:
             (CONV_TRANSPOSED2 if self.transposed else 0)
         if out_slice is not None:
             d.out_ctot, d.out_c0 = out_slice
+        if place is not None:
+            d.out_H, d.out_W, d.out_y0, d.out_x0 = place
         so, sc = self.so, self.sc
         if self.via_im2col:
             # logical layer: 1x1 over C*KH*KW channels of the im2col'd tensor (OH x OW)
@@ -135,12 +137,14 @@ class Conv:
         return plan
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
-                 window=None, out=None, out_c0=None):
+                 window=None, out=None, out_c0=None, place=None):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
         `window` = (oy0, ox0, OH, OW) restricts the computed output region.  With `out_c0`
-        the result is written into channels [out_c0, out_c0+Cout) of the wider tensor `out`."""
+        the result is written into channels [out_c0, out_c0+Cout) of the wider tensor `out`; with
+        `place` = (y0, x0) the (OH, OW) result is written at that offset of the larger planes of
+        `out` (everything else in `out` is left untouched)."""
         dt = self.dtype
         unpool = pre is not None
         B, C1 = x1.shape[0], x1.shape[1]
@@ -173,8 +177,13 @@ class Conv:
             x1 = cols
         else:
             out_slice = None if out_c0 is None else (out.shape[1], int(out_c0))
-            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool, out_slice)
-        if out_c0 is not None:
+            pl = None if place is None else (out.shape[2], out.shape[3], int(place[0]), int(place[1]))
+            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool, out_slice, pl)
+        if place is not None:
+            if self.via_im2col or out is None or out.shape[0] != B or out.dtype != dt or \
+                    (out_c0 is None and out.shape[1] != self.Cout):
+                raise RuntimeError('bad placement target %s' % (None if out is None else tuple(out.shape),))
+        elif out_c0 is not None:
             if self.via_im2col or tuple(out.shape[2:]) != (d.OH, d.OW) or out.shape[0] != B or \
                     out.dtype != dt or out_c0 + self.Cout > out.shape[1]:
                 raise RuntimeError('bad output slice %s @%d' % (tuple(out.shape), out_c0))
@@ -246,7 +255,9 @@ def maxpool2x2(x, out=None):
     return out
 
 
-def unpool_eqmask(up, pre, pooled, out=None):
+def unpool_eqmask(up, pre, pooled, out=None, window=None):
+    """DePool2D, materialised.  `window` = (y0, x0, h, w): only that region of the (H, W) planes
+    is produced (in place in `out`, the rest is left as it is)."""
     B, Cc, H, W = pre.shape
     if tuple(up.shape) != (B, Cc, H // 2, W // 2) or up.shape != pooled.shape:
         raise RuntimeError('unpool shapes: up %s pre %s pooled %s'
@@ -254,6 +265,12 @@ def unpool_eqmask(up, pre, pooled, out=None):
     if out is None:
         out = torch.empty_like(pre)
     dt = pre.dtype
+    if window is not None:
+        y0, x0, wh, ww = window
+        check(_fn('unpool_eqmask_window', dt)(_stream(), _ptr(up, dt), _ptr(pre, dt),
+                                              _ptr(pooled, dt), _ptr(out, dt), B * Cc, H, W, y0, x0,
+                                              wh, ww), 'iiseg_unpool_eqmask_window')
+        return out
     check(_fn('unpool_eqmask', dt)(_stream(), _ptr(up, dt), _ptr(pre, dt), _ptr(pooled, dt),
                                    _ptr(out, dt), B * Cc, H, W), 'iiseg_unpool_eqmask')
     return out

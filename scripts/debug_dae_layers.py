@@ -12,6 +12,7 @@ to64 = lambda p: {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in p.i
 X = S.make_images(1, 224, 224, seed=1234)
 fcn = FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'])
 dae = StandardDAE(dp, 11)
+dae.dce = False   # full maps, so every level can be compared
 h, y = fcn(torch.from_numpy(X).cuda())
 dae.trace = {}
 score = dae.scores([h], y)

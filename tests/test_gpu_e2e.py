@@ -123,7 +123,7 @@ def test_full_size_single_image(built_lib):
     r_ref, net = odae.dae_forward(dp64, [h64], y64, return_net=True)
     ii.dae.trace = {}
     ii.dae.scores(H, Y)
-    tr = {k: host(v) for k, v in ii.dae.trace.items()}
+    tr = {k: host(v) for k, v in ii.dae.trace.items() if isinstance(v, torch.Tensor)}
     ii.dae.trace = None
     total_bits, flips, override = 0, 0, {}
     for p in range(1, 7):
@@ -218,3 +218,30 @@ def test_fcn8_kind_dae(built_lib):
     Yii, iters, _ = ii.refine(H, Y, 0.2, 2)
     assert list(host(iters)) == list(it_ref)
     assert np.abs(host(Yii) - yii_ref).max() <= TOL
+
+
+@pytest.mark.parametrize('size,dtype', [((224, 224), torch.float32), ((48, 40), torch.float64),
+                                        ((37, 51), torch.float32)])
+def test_decoder_window_dce_is_bit_identical(built_lib, size, dtype):
+    """Computing every decoder level only on the window that reaches the final center crop must
+    give BIT-IDENTICAL scores to computing the full maps (each output pixel is the same fixed-order
+    sum either way).  Also with the fused-unpool gather."""
+    from iterative_inference_segm_amd.dae import StandardDAE
+    nf = 64 if size == (224, 224) else 4
+    rng = np.random.default_rng(3)
+    B = 1 if size == (224, 224) else 2
+    y = rng.random((B, 11) + size).astype(np.float32); y /= y.sum(1, keepdims=True)
+    hh, hw = (size[0] + 198) // 16, (size[1] + 198) // 16
+    hc = 512 if nf == 64 else 7
+    h = rng.random((B, hc, hh, hw)).astype(np.float32)
+    dp = S.make_dae_params(h_channels=(hc,), n_filters=nf, seed=5)
+    yt, ht = torch.from_numpy(y).to(dtype).cuda(), torch.from_numpy(h).to(dtype).cuda()
+    outs = {}
+    for dce in (False, True):
+        for fuse in (False, True):
+            dae = StandardDAE(dp, 11, n_filters=nf, dtype=dtype)
+            dae.dce, dae.fuse_unpool = dce, fuse
+            outs[(dce, fuse)] = host(dae.scores([ht], yt))
+    ref = outs[(False, False)]
+    for k, v in outs.items():
+        assert np.array_equal(v, ref), 'mode %s differs' % (k,)
