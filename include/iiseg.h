@@ -107,6 +107,13 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
 int iiseg_maxpool2x2_f32(void* stream, const float* x, float* out, int32_t BC, int32_t H,
                          int32_t W);
 
+/* The same for pooled outputs [y0,y0+wh) x [x0,x0+ww) only, written in place into the (H/2, W/2)
+ * planes of `out` (loop-invariant borders of the refinement loop are not recomputed). */
+int iiseg_maxpool2x2_window_f32(void* stream, const float* x, float* out, int32_t BC, int32_t H,
+                                int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww);
+int iiseg_maxpool2x2_window_f64(void* stream, const double* x, double* out, int32_t BC, int32_t H,
+                                int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww);
+
 /* Equality-mask unpool, materialised (the fused form is IISEG_CONV_UNPOOL).  Replaces
  * DePool2D.get_output_for, layers/mylayers.py:88-115:
  * out[y,x] = (y < 2h && x < 2w && pre[y,x] == pooled[y/2,x/2]) ? up[y/2,x/2] : 0 */

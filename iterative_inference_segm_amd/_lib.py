@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     'iiseg_conv_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_maxpool2x2_f32': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
     'iiseg_unpool_eqmask_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]),
+    'iiseg_maxpool2x2_window_f32': (C.c_int, [_vp] * 3 + [_i32] * 7),
+    'iiseg_maxpool2x2_window_f64': (C.c_int, [_vp] * 3 + [_i32] * 7),
     'iiseg_unpool_eqmask_window_f32': (C.c_int, [_vp] * 5 + [_i32] * 7),
     'iiseg_unpool_eqmask_window_f64': (C.c_int, [_vp] * 5 + [_i32] * 7),
     'iiseg_deconv_f32': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),

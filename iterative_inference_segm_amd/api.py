@@ -110,8 +110,11 @@ class IterativeInference:
             nb = self.n_classes * (self.n_classes + 1)
             per_iter = torch.zeros((int(num_iter), nb), dtype=torch.int64, device=y.device)
             scratch = torch.zeros(2, dtype=torch.float64, device=y.device)
+        # h is fixed and only y evolves: the DAE may keep loop-invariant parts of its maps
+        sess = self.dae.new_session() if hasattr(self.dae, 'new_session') else None
         for it in range(int(num_iter)):
-            score = self.dae.scores(H, y)
+            score = self.dae.scores(H, y, session=sess) if sess is not None \
+                else self.dae.scores(H, y)
             ops.refine_update(score, y, st, step, off=(0, 0))
             ops.refine_finalize(st, eps_eff)
             if per_iter is not None:

@@ -47,6 +47,27 @@ __global__ __launch_bounds__(256) void unpool_eqmask_kernel(const T* __restrict_
     }
 }
 
+// window form: only pooled outputs [y0,y0+wh) x [x0,x0+ww) of every (h,w) plane, in place
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2x2_window_kernel(const T* __restrict__ x,
+                                                                T* __restrict__ out, int BC, int H,
+                                                                int W, int h, int w, int y0, int x0,
+                                                                int wh, int ww) {
+    const size_t n = (size_t)BC * wh * ww;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = x0 + (int)(i % ww);
+        const size_t t = i / ww;
+        const int oy = y0 + (int)(t % wh);
+        const size_t bc = t / wh;
+        const T* r0 = x + (bc * H + 2 * oy) * (size_t)W + 2 * ox;
+        const T* r1 = r0 + W;
+        const T a = r0[0] > r0[1] ? r0[0] : r0[1];
+        const T b = r1[0] > r1[1] ? r1[0] : r1[1];
+        out[(bc * h + oy) * (size_t)w + ox] = a > b ? a : b;
+    }
+}
+
 // window form: only [y0,y0+wh) x [x0,x0+ww) of every (H,W) plane is produced, in place
 template <typename T>
 __global__ __launch_bounds__(256) void unpool_eqmask_window_kernel(
@@ -95,6 +116,18 @@ int unpool(void* stream, const T* up, const T* pre, const T* pooled, T* out, int
 }
 
 template <typename T>
+int maxpool_window(void* stream, const T* x, T* out, int32_t BC, int32_t H, int32_t W, int32_t y0,
+                   int32_t x0, int32_t wh, int32_t ww) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2 || y0 < 0 || x0 < 0 || wh <= 0 || ww <= 0 || y0 + wh > H / 2 ||
+        x0 + ww > W / 2)
+        return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(maxpool2x2_window_kernel<T>, dim3(grid_for((size_t)BC * wh * ww)), dim3(256),
+                       0, (hipStream_t)stream, x, out, BC, H, W, H / 2, W / 2, y0, x0, wh, ww);
+    return iiseg_check_launch();
+}
+
+template <typename T>
 int unpool_window(void* stream, const T* up, const T* pre, const T* pooled, T* out, int32_t BC,
                   int32_t H, int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww) {
     if (!up || !pre || !pooled || !out) return IISEG_ERR_NULL;
@@ -109,6 +142,16 @@ int unpool_window(void* stream, const T* up, const T* pre, const T* pooled, T* o
 
 }  // namespace
 
+extern "C" int iiseg_maxpool2x2_window_f32(void* stream, const float* x, float* out, int32_t BC,
+                                           int32_t H, int32_t W, int32_t y0, int32_t x0,
+                                           int32_t wh, int32_t ww) {
+    return maxpool_window<float>(stream, x, out, BC, H, W, y0, x0, wh, ww);
+}
+extern "C" int iiseg_maxpool2x2_window_f64(void* stream, const double* x, double* out, int32_t BC,
+                                           int32_t H, int32_t W, int32_t y0, int32_t x0,
+                                           int32_t wh, int32_t ww) {
+    return maxpool_window<double>(stream, x, out, BC, H, W, y0, x0, wh, ww);
+}
 extern "C" int iiseg_unpool_eqmask_window_f32(void* stream, const float* up, const float* pre,
                                               const float* pooled, float* out, int32_t BC,
                                               int32_t H, int32_t W, int32_t y0, int32_t x0,

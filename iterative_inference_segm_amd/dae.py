@@ -77,18 +77,26 @@ class StandardDAE:
         self.fuse_unpool = os.environ.get('IISEG_FUSE_UNPOOL', '0') != '0'
         # compute each decoder level only on the window that reaches the final crop
         self.dce = os.environ.get('IISEG_DECODER_DCE', '1') != '0'
+        # inside a refinement loop recompute only the y-dependent part of the encoder maps
+        self.licm = os.environ.get('IISEG_ENCODER_LICM', '1') != '0'
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
+
+    def new_session(self):
+        """State of one refinement loop (h fixed, y evolving): see `scores`."""
+        return {'primed': False}
 
     def conv_layers(self):
         d = dict(self.enc)
         d.update(self.dec)
         return d
 
-    def scores(self, h_list, y, mask_override=None):
+    def scores(self, h_list, y, mask_override=None, session=None):
         """Runs the DAE up to the pre-softmax score map already cropped to y's size
         (fused_up1 of fcn_up.py:104-113).  Returns score (B, n_classes, H, W).
         `mask_override` {level: (pre, pooled)} substitutes the tensors whose equality defines
-        the DePool2D mask of that level (parity tests use it to inject reference masks)."""
+        the DePool2D mask of that level (parity tests use it to inject reference masks).
+        `session` (a dict from `new_session()`) makes consecutive calls with the SAME h recompute
+        only what depends on y (used by the refinement loop)."""
         h_list = list(h_list)
         if len(h_list) != len(self.concat_h):
             raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
@@ -98,21 +106,54 @@ class StandardDAE:
             pending_h, pos = h_list[pos], pos + 1
         t = y
         pre, pool = {}, {0: y}
+        # Loop-invariant code motion for the refinement loop: between two steps only y changes, so
+        # only the part of every encoder map that y can reach has to be recomputed (the pad-100
+        # border and everything fed by h alone keep the values of the first step).  `session`
+        # carries the full-size buffers; `dep` is the y-dependent region (y0, x0, h, w) of `t`.
+        primed = session is not None and session.get('primed', False) and self.licm
+        dep = (0, 0, y.shape[2], y.shape[3])
+
+        def clip(lo, hi, size):
+            lo, hi = max(lo, 0), min(hi, size)
+            return lo, max(hi - lo, 0)
+
         for p in range(self.total):                      # fcn_down.py:77-136
             for i in range(1, self.conv_before_pool + 1):
                 name = 'conv%d_%d' % (p + 1, i)
                 conv = self.enc[name]
+                kw = {}
+                if primed:
+                    buf = session[name]
+                    fh, fw = buf.shape[2], buf.shape[3]
+                    wy0, wh = clip(dep[0] + conv.pad - (conv.KH - 1), dep[0] + dep[2] + conv.pad, fh)
+                    wx0, ww = clip(dep[1] + conv.pad - (conv.KW - 1), dep[1] + dep[3] + conv.pad, fw)
+                    dep = (wy0, wx0, wh, ww)
+                    kw = dict(window=dep, out=buf, place=(wy0, wx0))
                 if pending_h is not None:                # h first, then features (P13)
-                    t = conv(pending_h, x2=t)
+                    t = conv(pending_h, x2=t, **kw)
                     pending_h = None
                 else:
-                    t = conv(t)
-                self._count(name, conv, t)
+                    t = conv(t, **kw)
+                if session is not None and not primed:
+                    session[name] = t
+                self._count(name, conv, t, computed=(dep[2], dep[3]) if primed else None)
             pre[p + 1] = t
-            pool[p + 1] = t = ops.maxpool2x2(t)          # :122
+            if primed:
+                buf = session['pool%d' % (p + 1)]
+                qy0, qh = clip(dep[0] // 2, (dep[0] + dep[2] + 1) // 2, buf.shape[2])
+                qx0, qw = clip(dep[1] // 2, (dep[1] + dep[3] + 1) // 2, buf.shape[3])
+                dep = (qy0, qx0, qh, qw)
+                t = ops.maxpool2x2(t, out=buf, window=dep)
+            else:
+                t = ops.maxpool2x2(t)                    # :122
+                if session is not None:
+                    session['pool%d' % (p + 1)] = t
+            pool[p + 1] = t
             if p < self.n_pool and pos < len(self.concat_h) and \
                     self.concat_h[pos] == 'pool%d' % (p + 1):   # :131-134
                 pending_h, pos = h_list[pos], pos + 1
+        if session is not None:
+            session['primed'] = True
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')

@@ -246,10 +246,17 @@ class Deconv:
         return out
 
 
-def maxpool2x2(x, out=None):
+def maxpool2x2(x, out=None, window=None):
+    """`window` = (y0, x0, h, w) in pooled coordinates: only that region of `out` is written."""
     B, Cc, H, W = x.shape
     if out is None:
         out = torch.empty((B, Cc, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    if window is not None:
+        y0, x0, wh, ww = window
+        check(_fn('maxpool2x2_window', x.dtype)(_stream(), _ptr(x, x.dtype), _ptr(out, x.dtype),
+                                                B * Cc, H, W, y0, x0, wh, ww),
+              'iiseg_maxpool2x2_window')
+        return out
     check(_fn('maxpool2x2', x.dtype)(_stream(), _ptr(x, x.dtype), _ptr(out, x.dtype), B * Cc, H, W),
           'iiseg_maxpool2x2')
     return out

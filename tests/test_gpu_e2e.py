@@ -245,3 +245,27 @@ def test_decoder_window_dce_is_bit_identical(built_lib, size, dtype):
     ref = outs[(False, False)]
     for k, v in outs.items():
         assert np.array_equal(v, ref), 'mode %s differs' % (k,)
+
+
+@pytest.mark.parametrize('size,nf,dtype', [((224, 224), 64, torch.float32), ((40, 56), 4, torch.float64)])
+def test_refine_loop_invariant_encoder_is_bit_identical(built_lib, size, nf, dtype):
+    """Inside refine() only the y-dependent part of the encoder maps is recomputed after the first
+    step (loop-invariant code motion: the pad-100 border and h-only contributions keep their
+    values).  The refined map must be BIT-IDENTICAL to recomputing everything every step."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    rng = np.random.default_rng(4)
+    B = 1 if nf == 64 else 3
+    y = rng.random((B, 11) + size).astype(np.float32); y /= y.sum(1, keepdims=True)
+    hc = 512 if nf == 64 else 6
+    h = rng.random((B, hc, (size[0] + 198) // 16, (size[1] + 198) // 16)).astype(np.float32)
+    dp = S.make_dae_params(h_channels=(hc,), n_filters=nf, seed=6)
+    res = {}
+    for licm in (False, True):
+        dae = StandardDAE(dp, 11, n_filters=nf, dtype=dtype)
+        dae.licm = licm
+        ii = IterativeInference(None, dae, 11, [11], dtype=dtype)
+        out, iters, norms = ii.refine([h], y, 0.25, 4)
+        res[licm] = (host(out), host(norms))
+    assert np.array_equal(res[True][0], res[False][0])
+    assert np.array_equal(res[True][1], res[False][1])
