@@ -50,10 +50,12 @@ const char* iiseg_target_arch(void);
 
 #define IISEG_CONV_RELU 1u   /* out = max(out, 0)                                   */
 #define IISEG_CONV_UNPOOL 2u /* logical input = eq-mask unpool(up=x1, pre, pooled)  */
-/* 3x3 stride-2 TRANSPOSED convolution, crop='valid' (Deconv2DLayer of FC-DenseNet's TransitionUp,
- * models/FCDenseNet.py:119 via FC_DenseNet.layers): logical output (2H+1, 2W+1); w is the
- * reference layout W[in][out][3][3] (pass stride_o = 9, stride_c = Cout*9), the spatial flip of
- * Lasagne's gradient form is applied while packing; pad/dil are ignored. */
+/* KxK (K = 3 or 4) stride-2 TRANSPOSED convolution, crop='valid': Deconv2DLayer of FC-DenseNet's
+ * TransitionUp (K=3, models/FCDenseNet.py:119 via FC_DenseNet.layers) and of the DAE's
+ * unpool_type='standard' (K=4, models/fcn_up.py:41-45; float32 only).  Logical output
+ * ((H-1)*2+K, (W-1)*2+K); w is the reference layout W[in][out][K][K] (pass stride_o = K*K,
+ * stride_c = Cout*K*K), the spatial flip of Lasagne's gradient form is applied
+ * while packing; pad/dil are ignored. */
 #define IISEG_CONV_TRANSPOSED2 4u
 
 typedef struct iiseg_conv_desc {

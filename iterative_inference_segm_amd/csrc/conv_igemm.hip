@@ -338,10 +338,11 @@ static int check_desc(const iiseg_conv_desc* d) {
     int fullH = d->H + 2 * d->pad - d->dil * (d->KH - 1);
     int fullW = d->W + 2 * d->pad - d->dil * (d->KW - 1);
     if (d->flags & IISEG_CONV_TRANSPOSED2) {
-        if (d->KH != 3 || d->KW != 3 || (d->flags & IISEG_CONV_UNPOOL) || d->C2 != 0)
+        if (!((d->KH == 3 && d->KW == 3) || (d->KH == 4 && d->KW == 4)) ||
+            (d->flags & IISEG_CONV_UNPOOL) || d->C2 != 0)
             return IISEG_ERR_UNSUPPORTED;
-        fullH = 2 * d->H + 1;
-        fullW = 2 * d->W + 1;
+        fullH = (d->H - 1) * 2 + d->KH;
+        fullW = (d->W - 1) * 2 + d->KW;
     }
     if (fullH <= 0 || fullW <= 0 || d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW)
         return IISEG_ERR_SHAPE;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     constexpr int WVEC = BK * BM / 4;            // float4 per weight tile
     constexpr int WPT = (WVEC + 255) / 256;
     static_assert(WM * WN == 4 && BK % 2 == 0 && CPT % RG == 0, "tile config");
-    static_assert(WPT <= 3, "weight staging registers");
+    static_assert(WPT <= 4, "weight staging registers");
     static_assert(!(DMA && UNPOOL), "LDS-DMA staging is for the plain gather");
 
     __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     float xv[XE];
     float xq[UNPOOL ? XE : 1];
     float xu[UNPOOL ? XE : 1];
-    float4 wv0 = make_float4(0.f, 0.f, 0.f, 0.f), wv1 = wv0, wv2 = wv0;
+    float4 wv0 = make_float4(0.f, 0.f, 0.f, 0.f), wv1 = wv0, wv2 = wv0, wv3 = wv0;
     const int wrow0 = tid / (BM / 4);  // row of this thread's j-th weight vector = wrow0 + j*RPJ
     constexpr int RPJ = 256 / (BM / 4);
     const int wc4 = tid % (BM / 4);    // (256 % (BM/4) == 0: same column group for every j)
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
         if (IISEG_W_ON(0)) wv0 = IISEG_W_SRC(KT, 0);                                            \
         if (IISEG_W_ON(1)) wv1 = IISEG_W_SRC(KT, 1);                                            \
         if (IISEG_W_ON(2)) wv2 = IISEG_W_SRC(KT, 2);                                            \
+        if (IISEG_W_ON(3)) wv3 = IISEG_W_SRC(KT, 3);                                            \
     }
 #define IISEG_STORE_TILE(BUF)                                                                   \
     {                                                                                           \
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
         if (IISEG_W_ON(0)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0][wc4 * 4]) = wv0;          \
         if (IISEG_W_ON(1)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + RPJ][wc4 * 4]) = wv1;    \
         if (IISEG_W_ON(2)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 2 * RPJ][wc4 * 4]) = wv2; \
+        if (IISEG_W_ON(3)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 3 * RPJ][wc4 * 4]) = wv3; \
     }
 
     const int nkt = p.Kpad / BK;
@@ -303,6 +305,7 @@ int launch_taps(hipStream_t s, const ConvParams& cp, bool unpool) {
 int iiseg_taps_cpt(int KH, int KW) {
     if (KH == 3 && KW == 3) return 2;    // BK = 18
     if (KH == 1 && KW == 1) return 16;   // BK = 16
+    if (KH == 4 && KW == 4) return 2;    // BK = 32 (the 4x4/2 transposed conv of unpool 'standard')
     return 0;
 }
 
@@ -319,6 +322,13 @@ int iiseg_launch_conv_taps(hipStream_t s, const ConvParams& p, int KH, int KW, i
             case 128: return launch_taps<128, 128, 2, 2, 1, 1, 16>(s, p, unpool);
             case 64: return launch_taps<64, 256, 1, 4, 1, 1, 16>(s, p, unpool);
             default: return launch_taps<32, 256, 1, 4, 1, 1, 16>(s, p, unpool);
+        }
+    }
+    if (KH == 4 && KW == 4) {
+        switch (bm) {
+            case 128: return launch_taps<128, 128, 2, 2, 4, 4, 2>(s, p, unpool);
+            case 64: return launch_taps<64, 128, 2, 2, 4, 4, 2>(s, p, unpool);
+            default: return launch_taps<32, 128, 1, 4, 4, 4, 2>(s, p, unpool);
         }
     }
     return IISEG_ERR_UNSUPPORTED;

@@ -48,11 +48,12 @@ class StandardDAE:
             raise ValueError('It seems your DAE will have no conv/pooling layers!')  # :71-72
         if unpool_type not in ('standard', 'trackind', 'inverse'):
             raise ValueError('Unkown unpool type')                       # fcn_up.py:114-115
-        if unpool_type == 'standard':
-            raise NotImplementedError("unpool_type='standard' (many-channel 4x4/2 transposed "
-                                      "conv) has no HIP kernel yet")
+        if unpool_type == 'standard' and dtype != torch.float32:
+            raise NotImplementedError("unpool_type='standard' (4x4/2 transposed conv) is float32 "
+                                      "only")
         if bn:
             raise NotImplementedError('bn=1 DAE has no HIP kernel yet')
+        self.unpool_type = unpool_type
         self.concat_h, self.padding, self.skip = concat_h, padding, skip
         self.conv_before_pool = conv_before_pool
         self.n_classes = n_classes
@@ -69,6 +70,12 @@ class StandardDAE:
                                           pad=padding if first_pad else 1, relu=True,
                                           device=device, dtype=dtype)                 # :102-104
         for p in range(self.total, 0, -1):
+            if unpool_type == 'standard':                                # fcn_up.py:41-45
+                name = 'up%d' % p
+                self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=0, relu=False,
+                                          layout='iohw', transposed=True, device=device,
+                                          dtype=dtype)
+                continue
             name = 'up_conv%d' % p
             self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
                                       device=device, dtype=dtype)                     # fcn_up.py:83-86
@@ -157,6 +164,23 @@ class StandardDAE:
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')
+        if self.unpool_type == 'standard':
+            # fcn_up.py:37-63: up_p = Deconv2DLayer(prev, n_cl, 4, stride=2, crop='valid', linear),
+            # then ElemwiseSumLayer with pool_{p-1} (center crop) or CroppingLayer.  The 4x4/2
+            # transposed conv runs on the static-tap conv kernel; crop + sum are its window + add.
+            for p in range(self.total, 0, -1):
+                name = 'up%d' % p
+                conv = self.dec[name]
+                other = pool[p - 1]
+                uh, uw = conv.out_hw(t.shape[2], t.shape[3])
+                oh, ow = min(uh, other.shape[2]), min(uw, other.shape[3])
+                kw = dict(window=(_center(uh, oh), _center(uw, ow), oh, ow))
+                if self.skip and p > 1:
+                    kw.update(add=other, add_off=(_center(other.shape[2], oh),
+                                                  _center(other.shape[3], ow)))
+                t = conv(t, **kw)
+                self._count(name, conv, t, full=(uh, uw))
+            return t
         # ---- decoder, fcn_up.py:143-151 / UnpoolNet ------------------------------------------
         # Only the final center crop (fused_up1) is an output, so each level is computed just on
         # the window that reaches it (dead-code elimination, bit-identical results): level p

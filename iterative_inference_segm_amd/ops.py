@@ -68,7 +68,8 @@ class Conv:
         else:
             raise ValueError(layout)
         self.pad, self.dil, self.relu = int(pad), int(dil), bool(relu)
-        taps = (self.KH, self.KW) in ((1, 1), (3, 3))
+        taps = (self.KH, self.KW) in ((1, 1), (3, 3)) or \
+            ((self.KH, self.KW) == (4, 4) and dtype == torch.float32)
         # which kernel family the C ABI dispatches this filter shape to
         if dtype == torch.float64:
             self.kernel = 'conv_taps_f64_kernel'
@@ -84,7 +85,7 @@ class Conv:
 
     def out_hw(self, H, W):
         if self.transposed:
-            return 2 * H + 1, 2 * W + 1
+            return (H - 1) * 2 + self.KH, (W - 1) * 2 + self.KW
         return (H + 2 * self.pad - self.dil * (self.KH - 1),
                 W + 2 * self.pad - self.dil * (self.KW - 1))
 

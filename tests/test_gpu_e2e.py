@@ -269,3 +269,30 @@ def test_refine_loop_invariant_encoder_is_bit_identical(built_lib, size, nf, dty
         res[licm] = (host(out), host(norms))
     assert np.array_equal(res[True][0], res[False][0])
     assert np.array_equal(res[True][1], res[False][1])
+
+
+def test_unpool_type_standard_and_inverse(built_lib):
+    """dae_dict['unpool_type'] knobs: 'standard' = 4x4 stride-2 Deconv2DLayer + crop-sum
+    (fcn_up.py:37-63) on the static-tap conv kernel; 'inverse' = InverseLayer of the pool
+    (fcn_up.py:76-79), the same equality-mask arithmetic as 'trackind'."""
+    from iterative_inference_segm_amd.dae import StandardDAE
+    rng = np.random.default_rng(8)
+    y = rng.random((2, 11, 40, 48)).astype(np.float32); y /= y.sum(1, keepdims=True)
+    h = rng.random((2, 9, (40 + 198) // 16, (48 + 198) // 16)).astype(np.float32)
+    yt, ht = torch.from_numpy(y).cuda(), torch.from_numpy(h).cuda()
+    for ut in ('standard', 'inverse'):
+        dp = S.make_dae_params(h_channels=(9,), n_filters=4, unpool_type=ut, seed=9)
+        r_ref = odae.dae_forward(to64(dp), [h.astype(np.float64)], y.astype(np.float64), n_filters=4,
+                                 unpool_type=ut)
+        got = host(StandardDAE(dp, 11, n_filters=4, unpool_type=ut)(ht, yt))
+        assert np.abs(got - r_ref).max() <= TOL, ut
+    # transposed 4x4/2 conv alone, asymmetric weights, wide channels (BM = 128 variant)
+    from iterative_inference_segm_amd import ops
+    from oracle import nn as onn
+    x, Wt, b = rng.standard_normal((2, 70, 9, 7)), rng.standard_normal((70, 130, 4, 4)) / 30, \
+        rng.standard_normal(130)
+    ref = onn.deconv2d(x, Wt, b, stride=2)
+    got = host(ops.Conv(Wt, b, pad=0, relu=False, layout='iohw', transposed=True)(
+        torch.from_numpy(x.astype(np.float32)).cuda()))
+    assert got.shape == ref.shape == (2, 130, 20, 16)
+    assert np.abs(got - ref).max() <= 1e-4 * (1 + np.abs(ref).max())
