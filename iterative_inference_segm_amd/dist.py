@@ -25,6 +25,9 @@ def init_from_env(device_type=None):
     if device_type is None:
         device_type = 'cuda' if torch.cuda.is_available() else 'cpu'
     if device_type == 'cuda':
+        # IISEG_FORCE_DEVICE: rehearse N ranks on one GPU (with IISEG_DIST_BACKEND=gloo; RCCL
+        # itself needs one device per rank)
+        local = int(os.environ.get('IISEG_FORCE_DEVICE', local))
         torch.cuda.set_device(local)
         device = torch.device('cuda', local)
     else:
@@ -32,7 +35,8 @@ def init_from_env(device_type=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        backend = 'nccl' if device_type == 'cuda' else 'gloo'   # 'nccl' is RCCL on ROCm
+        backend = os.environ.get('IISEG_DIST_BACKEND',
+                                 'nccl' if device_type == 'cuda' else 'gloo')  # 'nccl' = RCCL on ROCm
         if backend == 'nccl':
             dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=device)
         else:
