@@ -119,3 +119,24 @@ def test_full_size_end_to_end_strict(built_lib):
     print('float64 end-to-end max-abs err after 3 steps: %.3e' % err)
     assert list(host(iters)) == list(it_ref)
     assert err <= 1e-4
+
+
+def test_config4_geometry_360x480_strict(built_lib):
+    """BASELINE configs[3] geometry: a full 360x480 CamVid frame (pool4 34x42, fc 11x15, upsample
+    408x536 with crop offsets 24/28) through FCN-8 + one DAE reconstruction, float64 on
+    the GPU vs the oracle; and the fp32 path on the same frame for the FCN output."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, dp = S.make_fcn8_params(), S.make_dae_params()
+    X = S.make_images(1, 360, 480, seed=77)
+    h_ref, y_ref = ofcn8.fcn8_forward(to64(fp), X.astype(np.float64), layer=['pool4', 'probs_dimshuffle'])
+    assert h_ref.shape == (1, 512, 34, 42) and y_ref.shape == (1, 11, 360, 480)
+    r_ref = odae.dae_forward(to64(dp), [h_ref], y_ref)
+    ii = IterativeInference(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=F64),
+                            StandardDAE(dp, 11, dtype=F64), 11, [11], dtype=F64)
+    out = ii.pred_fcn_fn(X)
+    assert np.abs(host(out[1]) - y_ref).max() <= 1e-10
+    assert np.abs(host(ii.pred_dae_fn(out[0], out[1])) - r_ref).max() <= 1e-9
+    y32 = FCN8(fp, 11, layer=['probs_dimshuffle'])(torch.from_numpy(X).cuda())[0]
+    assert np.abs(host(y32) - y_ref).max() <= 1e-4
