@@ -228,8 +228,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     constexpr int GPC = (XE + GCH - 1) / GCH;            // gathers per such chunk
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        const bool more = (kt + 1 < nkt) && !(p.debug_nogather & 1);
-        const bool dbg_ld = !(p.debug_nogather & 2), dbg_st = !(p.debug_nogather & 4);
+        const bool more = kt + 1 < nkt;
         const int DMABUF = buf ^ 1;
         float a[2][TM], b[2][TN];
 #pragma unroll
@@ -254,18 +253,16 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch & 1][i], b[ch & 1][j],
                                                                      acc[i][j], 0, 0, 0);
             // staging loads of the next tile go right BEHIND this chunk's MFMAs
-            if (more && dbg_ld) {
-                if constexpr (ch == 0)
-                    if (!(p.debug_nogather & 16)) IISEG_LOAD_W(kt + 1)
-                if (!(p.debug_nogather & 8))
-                    static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
-                        constexpr int ge = ch * GPC + decltype(G)::value;
-                        if constexpr (ch < GCH && ge < XE) IISEG_GATHER(kt + 1, ge)
-                    });
+            if (more) {
+                if constexpr (ch == 0) IISEG_LOAD_W(kt + 1)
+                static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
+                    constexpr int ge = ch * GPC + decltype(G)::value;
+                    if constexpr (ch < GCH && ge < XE) IISEG_GATHER(kt + 1, ge)
+                });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (more && dbg_st) IISEG_STORE_TILE(buf ^ 1)
+        if (more) IISEG_STORE_TILE(buf ^ 1)
         if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -281,8 +278,6 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
 template <int BM, int BN, int WM, int WN, int KH, int KW, int CPT>
 int launch_taps(hipStream_t s, const ConvParams& cp, bool unpool) {
     ConvParams p = cp;
-    static const int nog = getenv("IISEG_DEBUG_NOGATHER") ? atoi(getenv("IISEG_DEBUG_NOGATHER")) : 0;
-    p.debug_nogather = nog;
     p.n_ptiles = (p.P + BN - 1) / BN;
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
