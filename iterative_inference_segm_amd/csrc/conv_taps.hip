@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     const int wrow0 = tid / (BM / 4);  // row of this thread's j-th weight vector = wrow0 + j*RPJ
     constexpr int RPJ = 256 / (BM / 4);
     const int wc4 = tid % (BM / 4);    // (256 % (BM/4) == 0: same column group for every j)
+    const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, p.Kpad * p.Mpad * 4);
 
     // stage element j = (channel cc of this thread's group, tap t): one buffer_load, no VALU.
     // Channel -> (descriptor, scalar byte offset) is wave-uniform scalar work.
@@ -186,8 +187,18 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
 #define IISEG_W_ON(j) ((j) < WPT && (((j) + 1) * 256 <= WVEC || tid + 256 * (j) < WVEC))
 #define IISEG_W_SRC(KT, j) \
     (*reinterpret_cast<const float4*>(p.wp + (size_t)((KT) * BK + wrow0 + (j) * RPJ) * p.Mpad + m0 + wc4 * 4))
+#define IISEG_W_DMA(KT, j)                                                                      \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                   \
+        wrsrc, (__attribute__((address_space(3))) void*)(&Ws[DMABUF][0][0] + (wave * 64 + 256 * (j)) * 4), \
+        16, (int)(4u * (unsigned)(((KT) * BK + wrow0 + (j) * RPJ) * p.Mpad + m0 + wc4 * 4)), 0, 0, 0)
 #define IISEG_LOAD_W(KT)                                                                        \
-    {                                                                                           \
+    if constexpr (DMA) {                                                                        \
+        /* weight tile global -> LDS directly: thread-linear == LDS-linear, 1 KiB per wave op */ \
+        if (IISEG_W_ON(0)) IISEG_W_DMA(KT, 0);                                                  \
+        if (IISEG_W_ON(1)) IISEG_W_DMA(KT, 1);                                                  \
+        if (IISEG_W_ON(2)) IISEG_W_DMA(KT, 2);                                                  \
+        if (IISEG_W_ON(3)) IISEG_W_DMA(KT, 3);                                                  \
+    } else {                                                                                    \
         if (IISEG_W_ON(0)) wv0 = IISEG_W_SRC(KT, 0);                                            \
         if (IISEG_W_ON(1)) wv1 = IISEG_W_SRC(KT, 1);                                            \
         if (IISEG_W_ON(2)) wv2 = IISEG_W_SRC(KT, 2);                                            \
@@ -203,10 +214,12 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
                 if constexpr (UNPOOL) v = (xv[j] == xq[j]) ? xu[j] : 0.f;                       \
                 Xs[BUF][rg * XE + j][lp] = v;                                                   \
             });                                                                                 \
+        if constexpr (!DMA) {                                                                   \
         if (IISEG_W_ON(0)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0][wc4 * 4]) = wv0;          \
         if (IISEG_W_ON(1)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + RPJ][wc4 * 4]) = wv1;    \
         if (IISEG_W_ON(2)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 2 * RPJ][wc4 * 4]) = wv2; \
         if (IISEG_W_ON(3)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 3 * RPJ][wc4 * 4]) = wv3; \
+        }                                                                                       \
     }
 
     const int nkt = p.Kpad / BK;
@@ -215,8 +228,8 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     {
         constexpr int DMABUF = 0;
         static_for<0, XE>([&](auto J) __attribute__((always_inline)) { IISEG_GATHER(0, decltype(J)::value) });
+        IISEG_LOAD_W(0)
     }
-    IISEG_LOAD_W(0)
     IISEG_STORE_TILE(0)
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -268,6 +281,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     }
 #undef IISEG_GATHER
 #undef IISEG_LOAD_W
+#undef IISEG_W_DMA
 #undef IISEG_W_ON
 #undef IISEG_W_SRC
 #undef IISEG_STORE_TILE
