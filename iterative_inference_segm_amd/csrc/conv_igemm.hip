@@ -307,6 +307,13 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int64_t so, int64_
 
 int pick_bm(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 
+// channel padding of the packed weights: wide 3x3 layers are padded to 256 so that the
+// 256-channel tile of conv_taps applies (128-channel kernels read the same layout)
+int mpad_for(const iiseg_conv_desc* d) {
+    const int bm = (d->KH == 3 && d->KW == 3 && d->Cout >= 256) ? 256 : pick_bm(d->Cout);
+    return (d->Cout + bm - 1) / bm * bm;
+}
+
 // k extent of the packed weights: whole channel groups for the static-tap kernel (1x1, 3x3),
 // multiples of BK for the table-driven one.
 int kpad_for(const iiseg_conv_desc* d) {
@@ -323,7 +330,7 @@ extern "C" int iiseg_conv_plan(iiseg_conv_desc* d) {
     if (d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->C1 <= 0 || d->C2 < 0) return IISEG_ERR_SHAPE;
     const int bm = pick_bm(d->Cout);
     d->Kpad = kpad_for(d);
-    d->Mpad = (d->Cout + bm - 1) / bm * bm;
+    d->Mpad = mpad_for(d);
     return IISEG_OK;
 }
 
@@ -352,7 +359,7 @@ static int check_desc(const iiseg_conv_desc* d) {
                           d->out_x0 + d->OW > d->out_W))
         return IISEG_ERR_SHAPE;
     const int bm = pick_bm(d->Cout);
-    if (d->Kpad != kpad_for(d) || d->Mpad != (d->Cout + bm - 1) / bm * bm) return IISEG_ERR_SHAPE;
+    if (d->Kpad != kpad_for(d) || d->Mpad != mpad_for(d)) return IISEG_ERR_SHAPE;
     // int32 index ranges used by the kernel: pixel index, and the per-tile relative BYTE offsets
     // (a 256-pixel tile touches at most 256/(OH*OW) + 2 images)
     if ((int64_t)d->B * d->OH * d->OW >= (1ll << 31) - 512) return IISEG_ERR_SHAPE;

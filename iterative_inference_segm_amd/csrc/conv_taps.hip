@@ -42,19 +42,21 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff,
 }
 
 template <int BM, int BN, int WM, int WN, int KH, int KW, int CPT, bool UNPOOL, bool DMA>
-__global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f32_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f32_kernel(const ConvParams p) {
     constexpr int T = KH * KW;                   // taps
     constexpr int BK = CPT * T;                  // k-tile depth (whole channels)
     constexpr int NCH = BK / 2;                  // MFMA k-steps per tile
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile (channels x pixels)
     constexpr int TM = WTM / 32, TN = WTN / 32;  // 32x32 MFMA tiles per wave
+    constexpr int NW = WM * WN;                  // waves: 4, or 8 (256-channel tiles: waves 0-3
+    constexpr int NT = NW * 64;                  // stage X, waves 4-7 stage W, all 8 compute)
     constexpr int RG = 256 / BN;                 // staging row groups
     constexpr int CPG = CPT / RG;                // channels staged per thread per tile
     constexpr int XE = CPG * T;                  // staged elements per thread per tile
     constexpr int WVEC = BK * BM / 4;            // float4 per weight tile
     constexpr int WPT = (WVEC + 255) / 256;
-    static_assert(WM * WN == 4 && BK % 2 == 0 && CPT % RG == 0, "tile config");
-    static_assert(WPT <= 4, "weight staging registers");
+    static_assert((NW == 4 || NW == 8) && BK % 2 == 0 && CPT % RG == 0, "tile config");
+    static_assert(WPT <= 5, "weight staging registers");
     static_assert(!(DMA && UNPOOL), "LDS-DMA staging is for the plain gather");
 
     __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
@@ -70,8 +72,11 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     const int hw2 = p.h2 * p.w2;
 
     // ---- staging setup: this thread's pixel, its T tap offsets --------------------------
+    const bool xstager = NW == 4 || wave < 4;           // wave-uniform staging roles
+    const bool wstager = NW == 4 || wave >= NW - 4;
+    const int wtid = tid - (NT - 256);                  // 0..255 on the W-staging waves
     const int lp = tid % BN;
-    const int rg = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int rg = __builtin_amdgcn_readfirstlane((tid & 255) / BN);
     const int lp0 = __builtin_amdgcn_readfirstlane(lp & ~63);  // first pixel column of this wave
     const int pg = p0 + lp;
     const bool pvalid = pg < p.P;
@@ -151,10 +156,10 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
     float xv[XE];
     float xq[UNPOOL ? XE : 1];
     float xu[UNPOOL ? XE : 1];
-    float4 wv0 = make_float4(0.f, 0.f, 0.f, 0.f), wv1 = wv0, wv2 = wv0, wv3 = wv0;
-    const int wrow0 = tid / (BM / 4);  // row of this thread's j-th weight vector = wrow0 + j*RPJ
+    float4 wv0 = make_float4(0.f, 0.f, 0.f, 0.f), wv1 = wv0, wv2 = wv0, wv3 = wv0, wv4 = wv0;
+    const int wrow0 = wtid / (BM / 4);  // row of this thread's j-th weight vector = wrow0 + j*RPJ
     constexpr int RPJ = 256 / (BM / 4);
-    const int wc4 = tid % (BM / 4);    // (256 % (BM/4) == 0: same column group for every j)
+    const int wc4 = wtid % (BM / 4);    // (256 % (BM/4) == 0: same column group for every j)
     const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, p.Kpad * p.Mpad * 4);
 
     // stage element j = (channel cc of this thread's group, tap t): one buffer_load, no VALU.
@@ -184,12 +189,13 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
             }                                                                                   \
         }                                                                                       \
     }
-#define IISEG_W_ON(j) ((j) < WPT && (((j) + 1) * 256 <= WVEC || tid + 256 * (j) < WVEC))
+#define IISEG_W_ON(j) \
+    ((j) < WPT && wstager && (((j) + 1) * 256 <= WVEC || wtid + 256 * (j) < WVEC))
 #define IISEG_W_SRC(KT, j) \
     (*reinterpret_cast<const float4*>(p.wp + (size_t)((KT) * BK + wrow0 + (j) * RPJ) * p.Mpad + m0 + wc4 * 4))
 #define IISEG_W_DMA(KT, j)                                                                      \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                   \
-        wrsrc, (__attribute__((address_space(3))) void*)(&Ws[DMABUF][0][0] + (wave * 64 + 256 * (j)) * 4), \
+        wrsrc, (__attribute__((address_space(3))) void*)(&Ws[DMABUF][0][0] + ((wave - (NW - 4)) * 64 + 256 * (j)) * 4), \
         16, (int)(4u * (unsigned)(((KT) * BK + wrow0 + (j) * RPJ) * p.Mpad + m0 + wc4 * 4)), 0, 0, 0)
 #define IISEG_LOAD_W(KT)                                                                        \
     if constexpr (DMA) {                                                                        \
@@ -198,15 +204,17 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
         if (IISEG_W_ON(1)) IISEG_W_DMA(KT, 1);                                                  \
         if (IISEG_W_ON(2)) IISEG_W_DMA(KT, 2);                                                  \
         if (IISEG_W_ON(3)) IISEG_W_DMA(KT, 3);                                                  \
+        if (IISEG_W_ON(4)) IISEG_W_DMA(KT, 4);                                                  \
     } else {                                                                                    \
         if (IISEG_W_ON(0)) wv0 = IISEG_W_SRC(KT, 0);                                            \
         if (IISEG_W_ON(1)) wv1 = IISEG_W_SRC(KT, 1);                                            \
         if (IISEG_W_ON(2)) wv2 = IISEG_W_SRC(KT, 2);                                            \
         if (IISEG_W_ON(3)) wv3 = IISEG_W_SRC(KT, 3);                                            \
+        if (IISEG_W_ON(4)) wv4 = IISEG_W_SRC(KT, 4);                                            \
     }
 #define IISEG_STORE_TILE(BUF)                                                                   \
     {                                                                                           \
-        if constexpr (!DMA)                                                                     \
+        if constexpr (!DMA) if (xstager)                                                        \
             static_for<0, XE>([&](auto JJ) __attribute__((always_inline)) {                     \
                 constexpr int j = decltype(JJ)::value;                                          \
                 float v = xv[j];                                                                \
@@ -219,6 +227,7 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
         if (IISEG_W_ON(1)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + RPJ][wc4 * 4]) = wv1;    \
         if (IISEG_W_ON(2)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 2 * RPJ][wc4 * 4]) = wv2; \
         if (IISEG_W_ON(3)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 3 * RPJ][wc4 * 4]) = wv3; \
+        if (IISEG_W_ON(4)) *reinterpret_cast<float4*>(&Ws[BUF][wrow0 + 4 * RPJ][wc4 * 4]) = wv4; \
         }                                                                                       \
     }
 
@@ -227,7 +236,8 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
 
     {
         constexpr int DMABUF = 0;
-        static_for<0, XE>([&](auto J) __attribute__((always_inline)) { IISEG_GATHER(0, decltype(J)::value) });
+        if (xstager)
+            static_for<0, XE>([&](auto J) __attribute__((always_inline)) { IISEG_GATHER(0, decltype(J)::value) });
         IISEG_LOAD_W(0)
     }
     IISEG_STORE_TILE(0)
@@ -268,10 +278,11 @@ __global__ __launch_bounds__(256, (UNPOOL || BN > 128) ? 2 : 4) void conv_taps_f
             // staging loads of the next tile go right BEHIND this chunk's MFMAs
             if (more) {
                 if constexpr (ch == 0) IISEG_LOAD_W(kt + 1)
-                static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
-                    constexpr int ge = ch * GPC + decltype(G)::value;
-                    if constexpr (ch < GCH && ge < XE) IISEG_GATHER(kt + 1, ge)
-                });
+                if (xstager)
+                    static_for<0, GPC>([&](auto G) __attribute__((always_inline)) {
+                        constexpr int ge = ch * GPC + decltype(G)::value;
+                        if constexpr (ch < GCH && ge < XE) IISEG_GATHER(kt + 1, ge)
+                    });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -298,13 +309,13 @@ int launch_taps(hipStream_t s, const ConvParams& cp, bool unpool) {
     static const int dma = getenv("IISEG_CONV_DMA") ? atoi(getenv("IISEG_CONV_DMA")) : 1;
     if (unpool)
         hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, true, false>),
-                           dim3(grid), dim3(256), 0, s, p);
+                           dim3(grid), dim3(WM * WN * 64), 0, s, p);
     else if (dma)
         hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, true>),
-                           dim3(grid), dim3(256), 0, s, p);
+                           dim3(grid), dim3(WM * WN * 64), 0, s, p);
     else
         hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, false>),
-                           dim3(grid), dim3(256), 0, s, p);
+                           dim3(grid), dim3(WM * WN * 64), 0, s, p);
     return iiseg_check_launch();
 }
 
@@ -320,6 +331,8 @@ int iiseg_taps_cpt(int KH, int KW) {
 
 int iiseg_launch_conv_taps(hipStream_t s, const ConvParams& p, int KH, int KW, int bm, bool unpool) {
     if (KH == 3 && KW == 3) {
+        if (!unpool && p.Mpad % 256 == 0 && p.Cout >= 256)
+            return launch_taps<256, 128, 4, 2, 3, 3, 2>(s, p, unpool);
         switch (bm) {
             case 128: return launch_taps<128, 128, 2, 2, 3, 3, 2>(s, p, unpool);
             case 64: return launch_taps<64, 256, 1, 4, 3, 3, 2>(s, p, unpool);
