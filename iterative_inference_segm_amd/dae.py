@@ -69,6 +69,27 @@ class StandardDAE:
                 self.enc[name] = ops.Conv(params[name][0], params[name][1],
                                           pad=padding if first_pad else 1, relu=True,
                                           device=device, dtype=dtype)                 # :102-104
+        # The conv that follows a concat point computes W_h*h + W_y*features.  h does not change
+        # during a refinement loop, so the h half (a per-pixel bias map) is loop-invariant
+        # (SURVEY section 7): it is kept as its own linear conv whose output the y half adds in its
+        # epilogue.  Same association with or without a session, float32 only (float64 keeps the
+        # single-sum form of the oracle).
+        self.hsplit = {}
+        if dtype == torch.float32 and os.environ.get('IISEG_H_SPLIT', '1') != '0':
+            prev = n_classes
+            for p in range(self.total):
+                name = 'conv%d_1' % (p + 1)
+                W, b = params[name]
+                ch = W.shape[1] - prev
+                at = 'input' if p == 0 else 'pool%d' % p
+                if ch > 0 and at in concat_h:
+                    Wt = torch.as_tensor(W)
+                    conv_h = ops.Conv(Wt[:, :ch].contiguous(), b, pad=self.enc[name].pad,
+                                      relu=False, device=device, dtype=dtype)
+                    conv_y = ops.Conv(Wt[:, ch:].contiguous(), None, pad=self.enc[name].pad,
+                                      relu=True, device=device, dtype=dtype)
+                    self.hsplit[name] = (conv_h, conv_y)
+                prev = params['conv%d_%d' % (p + 1, conv_before_pool)][0].shape[0]
         for p in range(self.total, 0, -1):
             if unpool_type == 'standard':                                # fcn_up.py:41-45
                 name = 'up%d' % p
@@ -82,6 +103,7 @@ class StandardDAE:
         self.conv_log = None
         # DePool2D fused into the conv's gather (3 loads per element) or materialised first
         self.fuse_unpool = os.environ.get('IISEG_FUSE_UNPOOL', '0') != '0'
+        self.fuse_max_cout = int(os.environ.get('IISEG_FUSE_MAX_COUT', '0'))
         # compute each decoder level only on the window that reaches the final crop
         self.dce = os.environ.get('IISEG_DECODER_DCE', '1') != '0'
         # inside a refinement loop recompute only the y-dependent part of the encoder maps
@@ -136,7 +158,18 @@ class StandardDAE:
                     wx0, ww = clip(dep[1] + conv.pad - (conv.KW - 1), dep[1] + dep[3] + conv.pad, fw)
                     dep = (wy0, wx0, wh, ww)
                     kw = dict(window=dep, out=buf, place=(wy0, wx0))
-                if pending_h is not None:                # h first, then features (P13)
+                if pending_h is not None and name in self.hsplit:
+                    conv_h, conv_y = self.hsplit[name]
+                    keep = session is not None and self.licm
+                    hb = session.get('hb_' + name) if keep else None
+                    if hb is None:                       # loop-invariant: once per refine()
+                        hb = conv_h(pending_h)
+                        if keep:
+                            session['hb_' + name] = hb
+                    off = kw['place'] if 'place' in kw else (0, 0)
+                    t = conv_y(t, add=hb, add_off=off, **kw)
+                    pending_h = None
+                elif pending_h is not None:              # h first, then features (P13)
                     t = conv(pending_h, x2=t, **kw)
                     pending_h = None
                 else:
@@ -212,7 +245,7 @@ class StandardDAE:
             mpre, mpool = pre[p], pool[p]
             if mask_override and p in mask_override:
                 mpre, mpool = mask_override[p]
-            if not (self.fuse_unpool or conv.Cout <= 32):
+            if not (self.fuse_unpool or conv.Cout <= self.fuse_max_cout):
                 # Measured on MI355X: the fused gather needs 3 loads per element and the conv is
                 # limited by its vector-memory instructions, so for wide layers it is faster to
                 # materialise DePool2D with the HBM-bound kernel and run the plain conv; the
