@@ -5,6 +5,8 @@ sense without Theano: there is no symbolic `input_var`; the returned object is c
 the image batch and returns `[net[el] for el in layer]` (models/fcn8.py:200), i.e. it plays
 the role of the compiled `pred_fcn_fn` (iterative_inference.py:187-188).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -22,6 +24,25 @@ _BLOCKS = [('conv1_1', 'conv1_2'), ('conv2_1', 'conv2_2'), ('conv3_1', 'conv3_2'
 
 def _center(big, small):
     return (big - small) // 2  # lasagne autocrop 'center' (P6)
+
+
+def _clip(lo, hi, size):
+    lo, hi = max(lo, 0), min(hi, size)
+    return lo, max(hi - lo, 0)
+
+
+def _conv_region(dep, conv, fh, fw):
+    """Outputs (y0, x0, h, w) of a stride-1 conv whose receptive field meets input region dep."""
+    ey, ex = conv.dil * (conv.KH - 1), conv.dil * (conv.KW - 1)
+    y0, h = _clip(dep[0] + conv.pad - ey, dep[0] + dep[2] + conv.pad, fh)
+    x0, w = _clip(dep[1] + conv.pad - ex, dep[1] + dep[3] + conv.pad, fw)
+    return (y0, x0, h, w)
+
+
+def _pool_region(dep, ph, pw):
+    y0, h = _clip(dep[0] // 2, (dep[0] + dep[2] + 1) // 2, ph)
+    x0, w = _clip(dep[1] // 2, (dep[1] + dep[3] + 1) // 2, pw)
+    return (y0, x0, h, w)
 
 
 class FCN8:
@@ -52,6 +73,9 @@ class FCN8:
         self.upsample = ops.Deconv(np.asarray(Wu) / temperature, np.asarray(bu) / temperature, 8,
                                    device=device, dtype=dtype)                                      # :109-110
         self.conv_log = None  # optional list collecting (name, flops) per conv launch
+        # fold the weights-only pad-100 border of the encoder maps once per input geometry
+        self.fold_border = os.environ.get('IISEG_FCN_BORDER_FOLD', '1') != '0'
+        self._border = {}
 
     def conv_layers(self):
         return self.convs
@@ -59,23 +83,57 @@ class FCN8:
     def __call__(self, x):
         return self.forward(x)
 
-    def forward(self, x, hs=None):
+    def forward(self, x, hs=None, session=None):
         """hs: optional {concat point: h tensor} -- the buildFCN8_DAE wiring
         (models/fcn8_dae.py:52-54,63-65,...): h is concatenated FIRST in front of the conv that
-        follows the concat point; fused as a two-source gather, never materialised."""
+        follows the concat point; fused as a two-source gather, never materialised.
+
+        `session` (a dict, see `new_session`) keeps the full-size encoder maps between calls whose
+        only difference is `x` (same hs, same weights): a primed call recomputes just the region
+        of every map that x can reach; the pad-100 border, a function of the weights (and hs)
+        alone, keeps its values.  Bit-identical to the full computation."""
         hs = hs or {}
+        own = False
+        if session is None and self.fold_border and not hs:
+            # plain FCN-8: the border depends on the weights only, so it is folded once per
+            # input geometry (like weight packing) and reused for every later batch
+            key = (tuple(x.shape), x.dtype)
+            if self._border.get('key') != key:
+                self._border = {'key': key, 'primed': False}
+            session, own = self._border, True
+        primed = session is not None and session.get('primed', False)
         net = {'input': x}
         t = x
+        dep = (0, 0, x.shape[2], x.shape[3])       # region of `t` that depends on x
         pending = hs.get('input')
         for bi, names in enumerate(_BLOCKS):
             for name in names:
+                conv = self.convs[name]
+                kw = {}
+                if primed:
+                    buf = session[name]
+                    dep = _conv_region(dep, conv, buf.shape[2], buf.shape[3])
+                    kw = dict(window=dep, out=buf, place=(dep[0], dep[1]))
                 if pending is not None:
-                    t = self._conv(name, pending, x2=t)
+                    t = self._conv(name, pending, x2=t, **kw)
                     pending = None
                 else:
-                    t = self._conv(name, t)
-            net['pool%d' % (bi + 1)] = t = ops.maxpool2x2(t)     # :38,45,54,63,72
-            pending = hs.get('pool%d' % (bi + 1))
+                    t = self._conv(name, t, **kw)
+                if session is not None and not primed:
+                    session[name] = t
+            pname = 'pool%d' % (bi + 1)
+            if primed:
+                buf = session[pname]
+                dep = _pool_region(dep, buf.shape[2], buf.shape[3])
+                t = ops.maxpool2x2(t, out=buf, window=dep)             # :38,45,54,63,72
+            else:
+                t = ops.maxpool2x2(t)
+                if session is not None:
+                    session[pname] = t
+            net[pname] = t
+            pending = hs.get(pname)
+        if session is not None:
+            session['primed'] = True
         if pending is not None:          # concat after pool5 feeds fc6 (7x7: table kernel)
             t = self._conv('fc6', pending, x2=t)
         else:
@@ -93,7 +151,13 @@ class FCN8:
         score = self.upsample(t, window=(_center(uh, oh), _center(uw, ow), oh, ow))
         net['score'] = score
         net['probs_dimshuffle'] = ops.crop_softmax(score, oh, ow, off=(0, 0))  # :122-130,187-191
-        return [net[el] for el in self.layer]
+        # maps owned by the internal border store are overwritten by the next call: hand out copies
+        return [net[el].clone() if own and el.startswith('pool') else net[el]
+                for el in self.layer]
+
+    def new_session(self):
+        """State for consecutive forwards that differ only in x (see `forward`)."""
+        return {'primed': False}
 
     def _conv(self, name, t, **kw):
         conv = self.convs[name]
@@ -101,8 +165,10 @@ class FCN8:
         if self.conv_log is not None:
             # (name, nominal FLOPs of the full layer, FLOPs of the computed window)
             fh, fw = conv.out_hw(t.shape[2], t.shape[3])
+            ch, cw = (kw['window'][2], kw['window'][3]) if 'window' in kw else \
+                (out.shape[2], out.shape[3])
             self.conv_log.append((name, conv.flops(out.shape[0], fh, fw),
-                                  conv.flops(out.shape[0], out.shape[2], out.shape[3])))
+                                  conv.flops(out.shape[0], ch, cw)))
         return out
 
     def _deconv_sum(self, deconv, t, score_name, pool):
@@ -122,14 +188,20 @@ class FCN8DAE:
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input'] for el in concat_h)  # :33-34
         self.concat_h = list(concat_h)
         self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype)
+        self.net.fold_border = False       # the border depends on h here: sessions only
+        self.licm = os.environ.get('IISEG_ENCODER_LICM', '1') != '0'
 
     def conv_layers(self):
         return self.net.convs
 
-    def scores(self, h_list, y, mask_override=None):
+    def new_session(self):
+        """State of one refinement loop (h fixed, y evolving)."""
+        return self.net.new_session() if self.licm else None
+
+    def scores(self, h_list, y, mask_override=None, session=None):
         if len(h_list) != len(self.concat_h):
             raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
-        return self.net.forward(y, hs=dict(zip(self.concat_h, h_list)))[0]
+        return self.net.forward(y, hs=dict(zip(self.concat_h, h_list)), session=session)[0]
 
     def __call__(self, *args):
         score = self.scores(args[:-1], args[-1])

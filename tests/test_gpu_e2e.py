@@ -271,6 +271,62 @@ def test_refine_loop_invariant_encoder_is_bit_identical(built_lib, size, nf, dty
     assert np.array_equal(res[True][1], res[False][1])
 
 
+@pytest.mark.parametrize('size,div,dtype', [((224, 224), 1, torch.float32),
+                                            ((36, 52), 16, torch.float64),
+                                            ((41, 33), 16, torch.float32)])
+def test_fcn8_border_fold_is_bit_identical(built_lib, size, div, dtype):
+    """The pad-100 border of the FCN-8 encoder maps depends on the weights only: after the first
+    batch of a geometry only the image-dependent region is recomputed.  Outputs for a DIFFERENT
+    second (and third) batch must be BIT-IDENTICAL to a from-scratch forward, and the handed-out h
+    must not alias the internal store."""
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp = S.make_fcn8_params(width_div=div, fc_channels=4096 // div, seed=51)
+    layer = ['pool3', 'pool4', 'probs_dimshuffle']
+    B = 1 if div == 1 else 2
+    folded = FCN8(fp, 11, layer=layer, dtype=dtype)
+    plain = FCN8(fp, 11, layer=layer, dtype=dtype)
+    folded.fold_border, plain.fold_border = True, False
+    kept = None
+    for i in range(3):
+        X = torch.from_numpy(S.make_images(B, size[0], size[1], seed=60 + i)).to(dtype).cuda()
+        got, ref = folded(X), plain(X)
+        for g, r in zip(got, ref):
+            assert np.array_equal(host(g), host(r)), 'batch %d differs' % i
+        if i == 0:
+            kept = (got[1], host(got[1]).copy())
+    assert folded._border.get('primed')
+    assert np.array_equal(host(kept[0]), kept[1])       # batch 0's h survived batches 1, 2
+    # a new geometry re-folds
+    X = torch.from_numpy(S.make_images(B, size[0] + 16, size[1], seed=70)).to(dtype).cuda()
+    for g, r in zip(folded(X), plain(X)):
+        assert np.array_equal(host(g), host(r))
+
+
+def test_fcn8_kind_dae_session_is_bit_identical(built_lib):
+    """dae kind 'fcn8' inside refine(): only the y-dependent region of the encoder maps is
+    recomputed after the first step; refined maps identical to full recomputation."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.fcn8 import FCN8DAE
+    concat_h = ['input', 'pool2']
+    rng = np.random.default_rng(8)
+    size = (40, 36)
+    y = rng.random((2, 11) + size).astype(np.float32); y /= y.sum(1, keepdims=True)
+    c2 = 128 // 16
+    h = [rng.random((2, 3) + size).astype(np.float32),
+         rng.random((2, c2, (size[0] + 198) // 4, (size[1] + 198) // 4)).astype(np.float32)]
+    dp = S.make_fcn8_dae_params(concat_h=concat_h, h_channels=(3, c2), seed=9, width_div=16,
+                                fc_channels=32)
+    res = {}
+    for licm in (False, True):
+        dae = FCN8DAE(dp, 11, concat_h=concat_h)
+        dae.licm = licm
+        ii = IterativeInference(None, dae, 11, [11])
+        out, iters, norms = ii.refine(h, y, 0.25, 3)
+        res[licm] = (host(out), host(norms))
+    assert np.array_equal(res[True][0], res[False][0])
+    assert np.array_equal(res[True][1], res[False][1])
+
+
 def test_unpool_type_standard_and_inverse(built_lib):
     """dae_dict['unpool_type'] knobs: 'standard' = 4x4 stride-2 Deconv2DLayer + crop-sum
     (fcn_up.py:37-63) on the static-tap conv kernel; 'inverse' = InverseLayer of the pool
