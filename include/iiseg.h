@@ -102,6 +102,34 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
                    const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
                    const float* bias, const float* add, float* out);
 
+/* Winograd F(2x2,3x3) form of the same convolution (same call sites as iiseg_conv_f32 for
+ * 3x3, dil 1, stride 1 layers with (C1+C2) % 16 == 0, no IISEG_CONV_UNPOOL / TRANSPOSED2):
+ * 2.25x fewer fp32 multiplies on the matrix pipe.  Same descriptor (window, placement, channel
+ * slice, add, ReLU; Kpad/Mpad are ignored), results equal to iiseg_conv_f32 up to fp32 rounding,
+ * and bit-identical between any two windows of one layer (tiles are anchored at even absolute
+ * output coordinates).
+ *   iiseg_conv_wino_supported      1 if `d` can run on this path, else 0
+ *   iiseg_conv_wino_weight_elems   floats of the transformed weights U = G g G^T
+ *   iiseg_conv_wino_workspace_elems floats of the caller-owned workspace one call needs
+ *                                  (transformed input V + products M), for the window in `d`
+ *   iiseg_conv_wino_pack_f32       w (layout as in iiseg_conv_pack_f32) -> U, once per layer
+ *   iiseg_conv_wino_f32            input transform -> 16 GEMMs -> output transform + epilogue;
+ *                                  `stages` selects which of the three kernels are enqueued
+ *                                  (IISEG_WINO_ALL normally; single stages let a caller time
+ *                                  the MFMA kernel on its own) */
+#define IISEG_WINO_INPUT 1u
+#define IISEG_WINO_GEMM 2u
+#define IISEG_WINO_OUTPUT 4u
+#define IISEG_WINO_ALL 7u
+int iiseg_conv_wino_supported(const iiseg_conv_desc* d);
+int64_t iiseg_conv_wino_weight_elems(const iiseg_conv_desc* d);
+int64_t iiseg_conv_wino_workspace_elems(const iiseg_conv_desc* d);
+int iiseg_conv_wino_pack_f32(void* stream, const iiseg_conv_desc* d, const float* w,
+                             int64_t stride_o, int64_t stride_c, float* U);
+int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                        const float* U, const float* bias, const float* add, float* workspace,
+                        float* out, uint32_t stages);
+
 /* ---------------------------------------------------------------------------------------
  * 2x2/2 max-pool, ignore_border (floor).  Replaces Pool2DLayer(x, 2): models/fcn8.py:38-72,
  * models/fcn_down.py:122.   x (B,C,H,W) -> out (B,C,H/2,W/2)

@@ -1,0 +1,444 @@
+// Winograd F(2x2, 3x3) convolution for gfx950 (CDNA4), fp32.
+//
+// The fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) is what bounds the wide 3x3 layers of
+// the hot path, so the way to go faster at full fp32 precision is to issue fewer multiplies:
+// Y = A^T [ (G g G^T) . (B^T d B) ] A computes a 2x2 output tile from a 4x4 input tile with 16
+// instead of 36 multiplies per (cin, cout) pair (2.25x fewer MFMAs).  Three kernels:
+//   1. wino_input_kernel   V[xi][c][t]  = (B^T d B)[xi]          HBM-bound, lanes along tiles
+//   2. wino_gemm_kernel    M[xi][co][t] = sum_c U[xi][c][co] * V[xi][c][t]
+//                          16 independent GEMMs, MFMA-bound, both operands stream global -> LDS
+//                          with 16-byte LDS-DMA (no gather, no VALU address work)
+//   3. wino_output_kernel  out = relu(A^T M A + bias + add), cropped to the window
+// U = G g G^T is packed once per layer (wino_weight_kernel, computed in double).
+//
+// Tiles are anchored at EVEN ABSOLUTE output coordinates, so a pixel is produced by the same
+// tile, the same 4x4 patch and the same fixed-order sums whatever window of the layer is being
+// computed: windowed / placed launches stay bit-identical to full-map launches (the property the
+// decoder dead-code elimination and the loop-invariant encoder borders rely on).
+//
+// Replaces the same Lasagne Conv2DLayer(3x3, stride 1) call sites as conv_taps.hip for layers
+// with Cin % 16 == 0 (models/fcn8.py:41-71, models/fcn_down.py:102-104, models/fcn_up.py:83-86);
+// fusions kept: two-source channel concat (h first), bias / skip-add / ReLU / window / placement.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+struct WinoParams {
+    const float* x1;
+    const float* x2;
+    const float* U;
+    const float* bias;
+    const float* add;
+    float* V;
+    float* M;
+    float* out;
+    int B, C1, C2, H, W;
+    int Cout, pad;
+    int oy0, ox0, OH, OW;    // output window in conv-output coordinates
+    int ty0, tx0, nty, ntx;  // tile grid (absolute tile coordinates = output coordinate / 2)
+    int T, Tpad;             // B*nty*ntx, padded to the GEMM pixel tile
+    int Kc, Mpad;            // channels (multiple of 16), output channels padded to the GEMM tile
+    int AH, AW, ay0, ax0;
+    int relu;
+    int out_ctot, out_c0, out_H, out_W, out_y0, out_x0;
+    int n_ttiles, n_mtiles;
+};
+
+constexpr int RSRC_W3 = 0x00027000;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const float* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
+}
+
+// ---- 0. weights: U[xi][c][co] = (G g G^T)[xi], g = w[co][c] (cross-correlation, P1) -----------
+__global__ void wino_weight_kernel(const float* __restrict__ w, int64_t so, int64_t sc,
+                                   float* __restrict__ U, int Cin, int Cout, int Kc, int Mpad) {
+    const int64_t n = (int64_t)Kc * Mpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / Mpad), co = (int)(i % Mpad);
+        double g[3][3], t[4][3];
+        const bool real = c < Cin && co < Cout;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = real ? (double)w[co * so + c * sc + a * 3 + b] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {  // G g
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {  // (G g) G^T
+            const double u0 = t[a][0], u1 = 0.5 * (t[a][0] + t[a][1] + t[a][2]),
+                         u2 = 0.5 * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+            U[(int64_t)(a * 4 + 0) * n + i] = (float)u0;
+            U[(int64_t)(a * 4 + 1) * n + i] = (float)u1;
+            U[(int64_t)(a * 4 + 2) * n + i] = (float)u2;
+            U[(int64_t)(a * 4 + 3) * n + i] = (float)u3;
+        }
+    }
+}
+
+// ---- 1. input transform ------------------------------------------------------------------------
+// One thread = one tile x ICH channels; lanes run along tiles (coalesced V stores).
+constexpr int ICH = 4;
+__global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.T) return;
+    const int ntt = p.nty * p.ntx;
+    const int b = t / ntt;
+    const int r = t - b * ntt;
+    const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
+    const int iy0 = 2 * (p.ty0 + tyl) - p.pad, ix0 = 2 * (p.tx0 + txl) - p.pad;
+    int rowoff[4];
+    bool rok[4], cok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rok[i] = (unsigned)(iy0 + i) < (unsigned)p.H;
+        cok[i] = (unsigned)(ix0 + i) < (unsigned)p.W;
+        rowoff[i] = (iy0 + i) * p.W + ix0;
+    }
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t xis = (size_t)p.Kc * p.Tpad;
+    const int c0 = blockIdx.y * ICH;
+#pragma unroll
+    for (int cc = 0; cc < ICH; ++cc) {
+        const int c = c0 + cc;
+        if (c >= p.Kc) break;
+        const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
+                                    : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[i][j] = (rok[i] && cok[j]) ? src[rowoff[i] + j] : 0.f;
+        float e[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // B^T d
+            e[0][j] = d[0][j] - d[2][j];
+            e[1][j] = d[1][j] + d[2][j];
+            e[2][j] = d[2][j] - d[1][j];
+            e[3][j] = d[1][j] - d[3][j];
+        }
+        float* v = p.V + (size_t)c * p.Tpad + t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // (B^T d) B
+            v[(size_t)(i * 4 + 0) * xis] = e[i][0] - e[i][2];
+            v[(size_t)(i * 4 + 1) * xis] = e[i][1] + e[i][2];
+            v[(size_t)(i * 4 + 2) * xis] = e[i][2] - e[i][1];
+            v[(size_t)(i * 4 + 3) * xis] = e[i][1] - e[i][3];
+        }
+    }
+}
+
+// ---- 2. the 16 GEMMs ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoParams p) {
+    constexpr int BK = 16, NCH = BK / 2;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int AV = BK * BM / 4, BV = BK * BN / 4;  // float4 per operand tile
+    constexpr int NA = NW == 8 ? 256 : NT;             // threads staging A / B
+    constexpr int APT = AV / NA, BPT = BV / 256;
+    static_assert((NW == 4 || NW == 8) && AV % NA == 0 && BV % 256 == 0, "tile config");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    // XCD-aware order: each XCD (bid % 8) walks a contiguous run of (xi, tile) work, inside a
+    // run groups of 8 pixel-tiles x all channel-tiles share U and V rows in that XCD's L2
+    const int per_xi = p.n_ttiles * p.n_mtiles;
+    int xi, tt, mt;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb / 8, r = nb % 8, xcd = bid % 8, l = bid / 8;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + l;
+        xi = v / per_xi;
+        const int w = v - xi * per_xi;
+        constexpr int GP = 8;
+        const int gsize = GP * p.n_mtiles;
+        const int g = w / gsize, rr = w % gsize;
+        const int gp = min(GP, p.n_ttiles - g * GP);
+        tt = g * GP + rr % gp;
+        mt = rr / gp;
+    }
+    const int m0 = mt * BM, t0 = tt * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t arsrc = mk_rsrc(p.U + (size_t)xi * p.Kc * p.Mpad, p.Kc * p.Mpad * 4);
+    const __amdgpu_buffer_rsrc_t brsrc = mk_rsrc(p.V + (size_t)xi * p.Kc * p.Tpad, p.Kc * p.Tpad * 4);
+    const bool bstager = NW == 4 || wave < 4;   // wave-uniform roles
+    const bool astager = NW == 4 || wave >= 4;
+    const int atid = NW == 8 ? tid - 256 : tid;
+    const int awave = NW == 8 ? wave - 4 : wave;
+
+    // global -> LDS directly, 16 bytes per lane: thread-linear == LDS-linear
+#define WINO_STAGE(KT, BUF)                                                                        \
+    {                                                                                              \
+        if (astager)                                                                               \
+            static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                        \
+                constexpr int j = decltype(J)::value;                                              \
+                const int f = j * NA + atid;                                                       \
+                const int row = f / (BM / 4), c4 = f % (BM / 4);                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                          \
+                    arsrc,                                                                         \
+                    (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + (j * NA + awave * 64) * 4), \
+                    16, (int)(4u * (unsigned)(((KT) * BK + row) * p.Mpad + m0 + c4 * 4)), 0, 0, 0); \
+            });                                                                                    \
+        if (bstager)                                                                               \
+            static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                        \
+                constexpr int j = decltype(J)::value;                                              \
+                const int f = j * 256 + (tid & 255);                                               \
+                const int row = f / (BN / 4), c4 = f % (BN / 4);                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                          \
+                    brsrc,                                                                         \
+                    (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + (j * 256 + (wave & 3) * 64) * 4), \
+                    16, (int)(4u * (unsigned)(((KT) * BK + row) * p.Tpad + t0 + c4 * 4)), 0, 0, 0); \
+            });                                                                                    \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = p.Kc / BK;
+    WINO_STAGE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lh][wm * WTM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][lh][wn * WTN + j * 32 + l31];
+        static_for<0, NCH>([&](auto CH) __attribute__((always_inline)) {
+            constexpr int ch = decltype(CH)::value;
+            if constexpr (ch + 1 < NCH) {
+                const int kk = (ch + 1) * 2 + lh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(ch + 1) & 1][i] = As[buf][kk][wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(ch + 1) & 1][j] = Bs[buf][kk][wn * WTN + j * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch & 1][i], b[ch & 1][j],
+                                                                     acc[i][j], 0, 0, 0);
+            if constexpr (ch == 0) {
+                if (more) WINO_STAGE(kt + 1, buf ^ 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef WINO_STAGE
+
+    // M[xi][co][t]: rows of the C/D layout are channels, columns (lane & 31) are tiles
+    float* Mx = p.M + (size_t)xi * p.Mpad * p.Tpad;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int t = t0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Mx[(size_t)co * p.Tpad + t] = acc[i][j][r];
+            }
+    }
+}
+
+// ---- 3. output transform + epilogue ------------------------------------------------------------
+constexpr int OCH = 4;
+__global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.T) return;
+    const int ntt = p.nty * p.ntx;
+    const int b = t / ntt;
+    const int r = t - b * ntt;
+    const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
+    const int wy = 2 * (p.ty0 + tyl) - p.oy0, wx = 2 * (p.tx0 + txl) - p.ox0;  // window coords
+    const bool okr[2] = {(unsigned)wy < (unsigned)p.OH, (unsigned)(wy + 1) < (unsigned)p.OH};
+    const bool okc[2] = {(unsigned)wx < (unsigned)p.OW, (unsigned)(wx + 1) < (unsigned)p.OW};
+    const size_t xis = (size_t)p.Mpad * p.Tpad;
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    const int co0 = blockIdx.y * OCH;
+#pragma unroll
+    for (int cc = 0; cc < OCH; ++cc) {
+        const int co = co0 + cc;
+        if (co >= p.Cout) break;
+        const float* m = p.M + (size_t)co * p.Tpad + t;
+        float s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // A^T m
+            const float m0 = m[(size_t)j * xis], m1 = m[(size_t)(4 + j) * xis],
+                        m2 = m[(size_t)(8 + j) * xis], m3 = m[(size_t)(12 + j) * xis];
+            s[0][j] = m0 + m1 + m2;
+            s[1][j] = m1 - m2 - m3;
+        }
+        const float bias = p.bias ? p.bias[co] : 0.f;
+        float* o = p.out + ((size_t)b * p.out_ctot + p.out_c0 + co) * OPL +
+                   (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        const float* ad = p.add ? p.add + ((size_t)b * p.Cout + co) * APL +
+                                      (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
+                                : nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // (A^T m) A
+            float y[2] = {s[i][0] + s[i][1] + s[i][2], s[i][1] - s[i][2] - s[i][3]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (okr[i] && okc[j]) {
+                    float v = y[j] + bias;
+                    if (ad) v += ad[(size_t)i * p.AW + j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    o[(size_t)i * p.out_W + j] = v;
+                }
+            }
+        }
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// geometry shared by the sizing queries and the launcher
+struct WinoGeom {
+    int Kc, Mpad, bm, ty0, tx0, nty, ntx, T, Tpad;
+};
+
+int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 ||
+        (d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2)))
+        return IISEG_ERR_UNSUPPORTED;
+    if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
+        d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
+        return IISEG_ERR_SHAPE;
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
+    if ((d->C1 + d->C2) % 16) return IISEG_ERR_UNSUPPORTED;
+    g.Kc = d->C1 + d->C2;
+    g.bm = d->Cout > 128 ? 256 : 128;
+    g.Mpad = round_up(d->Cout, g.bm);
+    g.ty0 = d->oy0 >> 1;
+    g.tx0 = d->ox0 >> 1;
+    g.nty = ((d->oy0 + d->OH - 1) >> 1) - g.ty0 + 1;
+    g.ntx = ((d->ox0 + d->OW - 1) >> 1) - g.tx0 + 1;
+    const int64_t T = (int64_t)d->B * g.nty * g.ntx;
+    const int64_t Tpad = (T + 127) / 128 * 128;
+    // buffer descriptors address one xi-slice of U / V with 32-bit byte offsets
+    if (Tpad * g.Kc * 4 >= (int64_t)1 << 31 || (int64_t)g.Kc * g.Mpad * 4 >= (int64_t)1 << 31)
+        return IISEG_ERR_UNSUPPORTED;
+    g.T = (int)T;
+    g.Tpad = (int)Tpad;
+    return IISEG_OK;
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_wino_supported(const iiseg_conv_desc* d) {
+    WinoGeom g;
+    return wino_geom(d, g) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int64_t iiseg_conv_wino_weight_elems(const iiseg_conv_desc* d) {
+    WinoGeom g;
+    if (wino_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)16 * g.Kc * g.Mpad;
+}
+
+extern "C" int64_t iiseg_conv_wino_workspace_elems(const iiseg_conv_desc* d) {
+    WinoGeom g;
+    if (wino_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)16 * g.Tpad * ((int64_t)g.Kc + g.Mpad);
+}
+
+extern "C" int iiseg_conv_wino_pack_f32(void* stream, const iiseg_conv_desc* d, const float* w,
+                                        int64_t stride_o, int64_t stride_c, float* U) {
+    WinoGeom g;
+    const int st = wino_geom(d, g);
+    if (st) return st;
+    if (!w || !U) return IISEG_ERR_NULL;
+    const int64_t n = (int64_t)g.Kc * g.Mpad;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                       stride_o, stride_c, U, d->C1 + d->C2, d->Cout, g.Kc, g.Mpad);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
+                                   const float* x2, const float* U, const float* bias,
+                                   const float* add, float* workspace, float* out,
+                                   uint32_t stages) {
+    WinoGeom g;
+    const int st = wino_geom(d, g);
+    if (st) return st;
+    if (!x1 || !U || !workspace || !out) return IISEG_ERR_NULL;
+    if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    if (((uintptr_t)U & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
+    WinoParams p;
+    p.x1 = x1;
+    p.x2 = x2;
+    p.U = U;
+    p.bias = bias;
+    p.add = add;
+    p.V = workspace;
+    p.M = workspace + (size_t)16 * g.Kc * g.Tpad;
+    p.out = out;
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.Cout = d->Cout; p.pad = d->pad;
+    p.oy0 = d->oy0; p.ox0 = d->ox0; p.OH = d->OH; p.OW = d->OW;
+    p.ty0 = g.ty0; p.tx0 = g.tx0; p.nty = g.nty; p.ntx = g.ntx;
+    p.T = g.T; p.Tpad = g.Tpad; p.Kc = g.Kc; p.Mpad = g.Mpad;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    if (add && (d->ay0 < 0 || d->ax0 < 0 || d->ay0 + d->OH > d->AH || d->ax0 + d->OW > d->AW))
+        return IISEG_ERR_SHAPE;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot > 0 ? d->out_c0 : 0;
+    if (p.out_c0 < 0 || p.out_c0 + d->Cout > p.out_ctot) return IISEG_ERR_SHAPE;
+    p.out_H = d->out_H > 0 ? d->out_H : d->OH;
+    p.out_W = d->out_H > 0 ? d->out_W : d->OW;
+    p.out_y0 = d->out_H > 0 ? d->out_y0 : 0;
+    p.out_x0 = d->out_H > 0 ? d->out_x0 : 0;
+    if (p.out_y0 < 0 || p.out_x0 < 0 || p.out_y0 + d->OH > p.out_H || p.out_x0 + d->OW > p.out_W)
+        return IISEG_ERR_SHAPE;
+    p.n_ttiles = g.Tpad / 128;
+    p.n_mtiles = g.Mpad / g.bm;
+    hipStream_t s = (hipStream_t)stream;
+    const int tb = (g.T + 255) / 256;
+    if (stages & IISEG_WINO_INPUT)
+        hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
+    const int grid = 16 * p.n_ttiles * p.n_mtiles;
+    if (stages & IISEG_WINO_GEMM) {
+        if (g.bm == 256)
+            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2>), dim3(grid), dim3(512), 0, s, p);
+        else
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+    }
+    if (stages & IISEG_WINO_OUTPUT)
+        hipLaunchKernelGGL(wino_output_kernel, dim3(tb, (d->Cout + OCH - 1) / OCH), dim3(256), 0, s,
+                           p);
+    return iiseg_check_launch();
+}

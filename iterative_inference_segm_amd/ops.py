@@ -6,6 +6,7 @@ never synchronise.  Two arithmetic modes: float32 (throughput path) and float64 
 path: the reference's CPU numerics), selected by the tensors' dtype.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -17,6 +18,21 @@ from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2
 CONV_PROFILE = None
 
 _SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
+
+# float32 3x3 layers with at least this many input / output channels (and Cin % 16 == 0) run in
+# Winograd F(2x2,3x3) form (conv_wino.hip); IISEG_WINO_MIN_CIN=0 switches the path off.  Below
+# these widths the HBM-bound transforms cost more than the saved MFMAs (scripts/bench_wino.py).
+WINO_MIN_CIN = int(os.environ.get('IISEG_WINO_MIN_CIN', '128'))
+WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
+_wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
+
+
+def _wino_workspace(n, device):
+    ws = _wino_ws.get(device)
+    if ws is None or ws.numel() < n:
+        _wino_ws[device] = None
+        ws = _wino_ws[device] = torch.empty(int(n), dtype=torch.float32, device=device)
+    return ws
 
 
 def _stream():
@@ -81,6 +97,10 @@ class Conv:
         else:
             self.kernel = 'conv_taps_f32_kernel' if taps else 'conv_igemm_f32_kernel'
             self.via_im2col = False
+        self.wino = (dtype == torch.float32 and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
+                     not self.transposed and self.Cin % 16 == 0 and
+                     0 < WINO_MIN_CIN <= self.Cin and self.Cout >= WINO_MIN_COUT)
+        self._U = None
         self._plans = {}
 
     def out_hw(self, H, W):
@@ -196,6 +216,8 @@ class Conv:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        if self.wino and not unpool and self.lib.iiseg_conv_wino_supported(C.byref(d)):
+            return self._call_wino(d, x1, x2, add, out, prof, ev0 if prof is not None else None)
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
                                           _ptr(pre, dt), _ptr(pooled, dt), _ptr(wp, dt),
@@ -208,6 +230,33 @@ class Conv:
         if prof is not None:
             ev1.record()
             prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
+        return out
+
+
+    def _call_wino(self, d, x1, x2, add, out, prof, ev0):
+        """Winograd F(2x2,3x3) form of the layer (include/iiseg.h, iiseg_conv_wino_f32)."""
+        lib = self.lib
+        if self._U is None:
+            self._U = torch.empty(lib.iiseg_conv_wino_weight_elems(C.byref(d)), dtype=torch.float32,
+                                  device=self.W.device)
+            check(lib.iiseg_conv_wino_pack_f32(_stream(), C.byref(d), _ptr(self.W), self.so, self.sc,
+                                               _ptr(self._U)), 'iiseg_conv_wino_pack_f32')
+        ws = _wino_workspace(lib.iiseg_conv_wino_workspace_elems(C.byref(d)), x1.device)
+        args = (C.byref(d), _ptr(x1), _ptr(x2), _ptr(self._U), _ptr(self.b), _ptr(add), _ptr(ws),
+                _ptr(out))
+        if prof is None:
+            check(lib.iiseg_conv_wino_f32(_stream(), *args, 7), 'iiseg_conv_wino_f32')
+            return out
+        # profiling: the three kernels separately, events around each
+        evs = [ev0] + [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for i, stage in enumerate((1, 2, 4)):
+            check(lib.iiseg_conv_wino_f32(_stream(), *args, stage), 'iiseg_conv_wino_f32')
+            evs[i + 1].record()
+        T = d.B * ((d.oy0 + d.OH + 1) // 2 - d.oy0 // 2) * ((d.ox0 + d.OW + 1) // 2 - d.ox0 // 2)
+        gemm_flops = 16 * 2.0 * self.Cin * self.Cout * T      # multiplies actually issued
+        prof.append(('wino_input_kernel', 0.0, evs[0], evs[1]))
+        prof.append(('wino_gemm_kernel', gemm_flops, evs[1], evs[2]))
+        prof.append(('wino_output_kernel', 0.0, evs[2], evs[3]))
         return out
 
 

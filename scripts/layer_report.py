@@ -20,7 +20,9 @@ log = []
 def wrapped(self, *a, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); out = orig(self, *a, **kw); e1.record()
-    log.append((names.get(id(self), '?'), self.flops(out.shape[0], out.shape[2], out.shape[3]), e0, e1))
+    w = kw.get('window')
+    oh, ow = (w[2], w[3]) if w is not None else (out.shape[2], out.shape[3])
+    log.append((names.get(id(self), '?') + ('' if w is None else ' [%dx%d]' % (oh, ow)), self.flops(out.shape[0], oh, ow), e0, e1))
     return out
 ops.Conv.__call__ = wrapped
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,5 +31,5 @@ torch.cuda.synchronize()
 tot = 0
 for n, f, a, b in log:
     ms = a.elapsed_time(b); tot += ms
-    print('%-18s %8.3f ms %7.1f TF/s' % (n, ms, f / ms / 1e9))
+    print('%-28s %8.3f ms %7.1f TF/s' % (n, ms, f / ms / 1e9))
 print('conv total %.1f ms; step (FCN + 1 DAE iter + metrics) %.1f ms' % (tot, t0.elapsed_time(t1)))

@@ -225,7 +225,7 @@ def test_fcn8_kind_dae(built_lib):
 def test_decoder_window_dce_is_bit_identical(built_lib, size, dtype):
     """Computing every decoder level only on the window that reaches the final center crop must
     give BIT-IDENTICAL scores to computing the full maps (each output pixel is the same fixed-order
-    sum either way).  Also with the fused-unpool gather."""
+    sum either way).  Also with the fused-unpool gather (IISEG_FUSE_UNPOOL=1)."""
     from iterative_inference_segm_amd.dae import StandardDAE
     nf = 64 if size == (224, 224) else 4
     rng = np.random.default_rng(3)
@@ -242,9 +242,15 @@ def test_decoder_window_dce_is_bit_identical(built_lib, size, dtype):
             dae = StandardDAE(dp, 11, n_filters=nf, dtype=dtype)
             dae.dce, dae.fuse_unpool = dce, fuse
             outs[(dce, fuse)] = host(dae.scores([ht], yt))
+    for fuse in (False, True):
+        assert np.array_equal(outs[(True, fuse)], outs[(False, fuse)]), 'fuse=%s differs' % fuse
+    # the fused-unpool gather runs on the direct kernel, the materialised path may run the wide
+    # layers in Winograd form: same values up to fp32 rounding (bit-identical in float64)
     ref = outs[(False, False)]
-    for k, v in outs.items():
-        assert np.array_equal(v, ref), 'mode %s differs' % (k,)
+    if dtype == torch.float64:
+        assert np.array_equal(outs[(False, True)], ref)
+    else:
+        assert np.abs(outs[(False, True)] - ref).max() <= 1e-4 * (1 + np.abs(ref).max())
 
 
 @pytest.mark.parametrize('size,nf,dtype', [((224, 224), 64, torch.float32), ((40, 56), 4, torch.float64)])

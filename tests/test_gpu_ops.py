@@ -98,6 +98,64 @@ def test_conv_window_and_add(ops):
     assert np.abs(got - ref).max() <= conv_tol(ref, 81)
 
 
+WINO_CASES = [
+    # B, Cin, H, W, Cout, pad, relu   (Cin % 16 == 0; Cout <= 128 -> 128-tile, > 128 -> 256-tile)
+    (2, 16, 9, 11, 8, 1, True),
+    (1, 32, 14, 6, 40, 0, False),
+    (3, 48, 7, 7, 130, 5, True),
+    (2, 64, 12, 13, 260, 1, True),
+    (1, 16, 40, 33, 24, 100, True),     # the pad-100 geometry
+    (70, 32, 5, 4, 16, 1, False),       # many images, few tiles each
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv_winograd_matches_oracle(ops, case):
+    """Winograd F(2x2,3x3) path (iiseg_conv_wino_f32) against the float64 oracle conv."""
+    B, Cin, H, W, Cout, pad, relu = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x, w, b = rnd(rng, B, Cin, H, W), rnd(rng, Cout, Cin, 3, 3) * 0.2, rnd(rng, Cout)
+    conv = ops.Conv(w, b, pad=pad, relu=relu)
+    conv.wino = True
+    got = host(conv(dev(x)))
+    assert conv._U is not None, 'Winograd path did not run'
+    ref = onn.conv2d(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), pad=pad)
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 4 * conv_tol(ref, Cin * 9)
+
+
+def test_conv_winograd_windows_are_bit_identical(ops):
+    """Any window of a layer (odd/even origins, placement into a larger plane, channel slice,
+    two-source concat, skip add) gives exactly the values of the full-map launch."""
+    rng = np.random.default_rng(77)
+    B, C1, C2, H, W, Cout, pad = 2, 16, 32, 15, 18, 36, 3
+    x1, x2 = rnd(rng, B, C1, H, W), rnd(rng, B, C2, H, W)
+    w, b = rnd(rng, Cout, C1 + C2, 3, 3) * 0.2, rnd(rng, Cout)
+    OH, OW = H + 2 * pad - 2, W + 2 * pad - 2
+    add = rnd(rng, B, Cout, OH + 3, OW + 2)
+    conv = ops.Conv(w, b, pad=pad, relu=True)
+    conv.wino = True
+    full = host(conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2, 1)))
+    direct = ops.Conv(w, b, pad=pad, relu=True)
+    direct.wino = False
+    ref = host(direct(dev(x1), x2=dev(x2), add=dev(add), add_off=(2, 1)))
+    assert np.abs(full - ref).max() <= 4 * conv_tol(ref, (C1 + C2) * 9)
+    for (y0, x0, h, ww) in [(0, 0, OH, OW), (1, 1, 5, 7), (2, 3, 4, 4), (3, 0, OH - 3, 1),
+                            (OH - 1, OW - 1, 1, 1), (0, 5, 2, OW - 5)]:
+        win = host(conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2 + y0, 1 + x0),
+                        window=(y0, x0, h, ww)))
+        assert np.array_equal(win, full[:, :, y0:y0 + h, x0:x0 + ww]), (y0, x0, h, ww)
+        big = torch.full((B, Cout + 3, OH + 4, OW + 5), -7.0, device='cuda')
+        conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2 + y0, 1 + x0), window=(y0, x0, h, ww),
+             out=big, out_c0=2, place=(y0 + 1, x0 + 2))
+        bigh = host(big)
+        assert np.array_equal(bigh[:, 2:2 + Cout, y0 + 1:y0 + 1 + h, x0 + 2:x0 + 2 + ww], win)
+        bigh[:, 2:2 + Cout, y0 + 1:y0 + 1 + h, x0 + 2:x0 + 2 + ww] = -7.0
+        assert (bigh == -7.0).all(), 'wrote outside the placement window'
+
+
 @pytest.mark.parametrize('shape', [(2, 5, 8, 8), (1, 3, 9, 7), (2, 70, 13, 13), (1, 1, 211, 5)])
 def test_conv_fused_unpool(ops, shape):
     """DePool2D as the conv's input gather == oracle depool + conv; includes tie masks
