@@ -121,6 +121,9 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
 #define IISEG_WINO_GEMM 2u
 #define IISEG_WINO_OUTPUT 4u
 #define IISEG_WINO_ALL 7u
+/* with IISEG_WINO_FUSED the GEMM stage also applies the output transform + epilogue (the
+ * products stay in registers; IISEG_WINO_OUTPUT is ignored): INPUT | GEMM | FUSED is a full call */
+#define IISEG_WINO_FUSED 8u
 int iiseg_conv_wino_supported(const iiseg_conv_desc* d);
 int64_t iiseg_conv_wino_weight_elems(const iiseg_conv_desc* d);
 int64_t iiseg_conv_wino_workspace_elems(const iiseg_conv_desc* d);

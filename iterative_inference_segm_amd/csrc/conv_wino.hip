@@ -270,6 +270,169 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoPa
     }
 }
 
+// ---- 2+3 fused: one workgroup walks all 16 xi of its (channel, tile) block ------------------------
+// M_xi lives in registers only: after the K loop of each xi it is folded into the four output
+// accumulators Y_ab += AT[a][i] * AT[b][j] * M_xi (coefficients 0 / +-1, xi = 4i + j), so the
+// products never travel to HBM and the output transform costs 4 FMAs per element per xi.
+template <int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(WM * WN * 64, 2) void wino_fused_kernel(const WinoParams p) {
+    constexpr int NCH = BK / 2;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int AV = BK * BM / 4, BV = BK * BN / 4;
+    constexpr int APT = AV / NT, BPT = BV / NT;
+    static_assert(AV % NT == 0 && BV % NT == 0, "tile config");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    int tt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ttiles, p.n_mtiles, tt, mt);
+    const int m0 = mt * BM, t0 = tt * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nkt = p.Kc / BK;
+    const size_t ustride = (size_t)p.Kc * p.Mpad, vstride = (size_t)p.Kc * p.Tpad;
+    const int ubytes = p.Kc * p.Mpad * 4, vbytes = p.Kc * p.Tpad * 4;
+
+    // stage k-tile KT of transform point XI into LDS buffer BUF (global -> LDS, 16 B per lane)
+#define WINO_STAGE(XI, KT, BUF)                                                                    \
+    {                                                                                              \
+        const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)(XI) * ustride, ubytes);           \
+        const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)(XI) * vstride, vbytes);           \
+        static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            const int f = j * NT + tid;                                                            \
+            const int row = f / (BM / 4), c4 = f % (BM / 4);                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                ar, (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + (j * NT + wave * 64) * 4), \
+                16, (int)(4u * (unsigned)(((KT) * BK + row) * p.Mpad + m0 + c4 * 4)), 0, 0, 0);    \
+        });                                                                                        \
+        static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            const int f = j * NT + tid;                                                            \
+            const int row = f / (BN / 4), c4 = f % (BN / 4);                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                br, (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + (j * NT + wave * 64) * 4), \
+                16, (int)(4u * (unsigned)(((KT) * BK + row) * p.Tpad + t0 + c4 * 4)), 0, 0, 0);    \
+        });                                                                                        \
+    }
+
+    f32x16 acc[TM][TN], Y[4][TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                Y[0][i][j][r] = Y[1][i][j][r] = Y[2][i][j][r] = Y[3][i][j][r] = 0.f;
+            }
+
+    WINO_STAGE(0, 0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int xi = 0, kt = 0;              // the k-tile being multiplied
+    const int total = 16 * nkt;
+    for (int s = 0; s < total; ++s) {
+        const int buf = s & 1;
+        int nxi = xi, nkt1 = kt + 1;  // the k-tile being staged
+        if (nkt1 == nkt) { nkt1 = 0; ++nxi; }
+        const bool more = s + 1 < total;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lh][wm * WTM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][lh][wn * WTN + j * 32 + l31];
+        static_for<0, NCH>([&](auto CH) __attribute__((always_inline)) {
+            constexpr int ch = decltype(CH)::value;
+            if constexpr (ch + 1 < NCH) {
+                const int kk = (ch + 1) * 2 + lh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(ch + 1) & 1][i] = As[buf][kk][wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(ch + 1) & 1][j] = Bs[buf][kk][wn * WTN + j * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch & 1][i], b[ch & 1][j],
+                                                                     acc[i][j], 0, 0, 0);
+            if constexpr (ch == 0) {
+                if (more) WINO_STAGE(nxi, nkt1, buf ^ 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (nkt1 == 0) {
+            // M_xi complete: Y_ab += AT[a][xi/4] * AT[b][xi%4] * M_xi,  AT = [1 1 1 0; 0 1 -1 -1]
+            const int wi = xi >> 2, wj = xi & 3;
+            const float r0 = wi < 3 ? 1.f : 0.f, r1 = wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f);
+            const float c0 = wj < 3 ? 1.f : 0.f, c1 = wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f);
+            const float k00 = r0 * c0, k01 = r0 * c1, k10 = r1 * c0, k11 = r1 * c1;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float m = acc[i][j][r];
+                        Y[0][i][j][r] = fmaf(k00, m, Y[0][i][j][r]);
+                        Y[1][i][j][r] = fmaf(k01, m, Y[1][i][j][r]);
+                        Y[2][i][j][r] = fmaf(k10, m, Y[2][i][j][r]);
+                        Y[3][i][j][r] = fmaf(k11, m, Y[3][i][j][r]);
+                        acc[i][j][r] = 0.f;
+                    }
+        }
+        xi = nxi;
+        kt = nkt1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef WINO_STAGE
+
+    // epilogue: rows of the C/D layout are channels, columns (lane & 31) are tiles
+    const int ntt = p.nty * p.ntx;
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int t = t0 + wn * WTN + j * 32 + l31;
+        if (t >= p.T) continue;
+        const int b = t / ntt;
+        const int rr = t - b * ntt;
+        const int tyl = rr / p.ntx, txl = rr - tyl * p.ntx;
+        const int wy = 2 * (p.ty0 + tyl) - p.oy0, wx = 2 * (p.tx0 + txl) - p.ox0;
+        const bool ok[4] = {(unsigned)wy < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
+                            (unsigned)wy < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW,
+                            (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
+                            (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW};
+        float* ob = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                    (ptrdiff_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        const float* ab = p.add ? p.add + (size_t)b * p.Cout * APL +
+                                      (ptrdiff_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
+                                : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!ok[q]) continue;
+                    float v = Y[q][i][j][r] + bias;
+                    if (ab) v += ab[(size_t)co * APL + (q >> 1) * p.AW + (q & 1)];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    ob[(size_t)co * OPL + (size_t)(q >> 1) * p.out_W + (q & 1)] = v;
+                }
+            }
+    }
+}
+
 // ---- 3. output transform + epilogue ------------------------------------------------------------
 constexpr int OCH = 4;
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
@@ -428,6 +591,18 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
     p.n_mtiles = g.Mpad / g.bm;
     hipStream_t s = (hipStream_t)stream;
     const int tb = (g.T + 255) / 256;
+    if (stages & IISEG_WINO_FUSED) {
+        if (g.Kc % 32) return IISEG_ERR_UNSUPPORTED;  // the fused kernel's k-tile is 32 channels
+        // input transform, then GEMMs + output transform in one kernel (M stays in registers)
+        if (stages & IISEG_WINO_INPUT)
+            hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
+        if (stages & IISEG_WINO_GEMM) {
+            p.n_mtiles = g.Mpad / 128;
+            hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 32>),
+                               dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
+        }
+        return iiseg_check_launch();
+    }
     if (stages & IISEG_WINO_INPUT)
         hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
     const int grid = 16 * p.n_ttiles * p.n_mtiles;

@@ -24,6 +24,10 @@ _SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
 # these widths the HBM-bound transforms cost more than the saved MFMAs (scripts/bench_wino.py).
 WINO_MIN_CIN = int(os.environ.get('IISEG_WINO_MIN_CIN', '128'))
 WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
+# Layers with at most this many input channels use the kernel that also applies the output
+# transform (products stay in registers, no M round trip through HBM); deeper layers are
+# MFMA-bound and run faster on the plain 256x128 GEMM + separate output transform.  0: never.
+WINO_FUSED_MAX_CIN = int(os.environ.get('IISEG_WINO_FUSED_MAX_CIN', '256'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
 
 
@@ -244,19 +248,22 @@ class Conv:
         ws = _wino_workspace(lib.iiseg_conv_wino_workspace_elems(C.byref(d)), x1.device)
         args = (C.byref(d), _ptr(x1), _ptr(x2), _ptr(self._U), _ptr(self.b), _ptr(add), _ptr(ws),
                 _ptr(out))
+        fused = 8 if (self.Cin <= WINO_FUSED_MAX_CIN and self.Cin % 32 == 0) else 0
         if prof is None:
-            check(lib.iiseg_conv_wino_f32(_stream(), *args, 7), 'iiseg_conv_wino_f32')
+            check(lib.iiseg_conv_wino_f32(_stream(), *args, 7 | fused), 'iiseg_conv_wino_f32')
             return out
-        # profiling: the three kernels separately, events around each
-        evs = [ev0] + [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        for i, stage in enumerate((1, 2, 4)):
-            check(lib.iiseg_conv_wino_f32(_stream(), *args, stage), 'iiseg_conv_wino_f32')
-            evs[i + 1].record()
+        # profiling: the kernels separately, events around each
+        stages = (1 | fused, 2 | fused) if fused else (1, 2, 4)
+        names = ('wino_input_kernel', 'wino_fused_kernel' if fused else 'wino_gemm_kernel',
+                 'wino_output_kernel')
         T = d.B * ((d.oy0 + d.OH + 1) // 2 - d.oy0 // 2) * ((d.ox0 + d.OW + 1) // 2 - d.ox0 // 2)
         gemm_flops = 16 * 2.0 * self.Cin * self.Cout * T      # multiplies actually issued
-        prof.append(('wino_input_kernel', 0.0, evs[0], evs[1]))
-        prof.append(('wino_gemm_kernel', gemm_flops, evs[1], evs[2]))
-        prof.append(('wino_output_kernel', 0.0, evs[2], evs[3]))
+        for i, stage in enumerate(stages):
+            check(lib.iiseg_conv_wino_f32(_stream(), *args, stage), 'iiseg_conv_wino_f32')
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            prof.append((names[i], gemm_flops if i == 1 else 0.0, ev0, ev1))
+            ev0 = ev1
         return out
 
 

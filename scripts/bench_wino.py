@@ -56,7 +56,7 @@ for name, cin, cout, H, pad, win in LAYERS:
     wino(x, out=ow, **kw)
     torch.cuda.synchronize()
     ops.CONV_PROFILE = None
-    st = [s.elapsed_time(e) for _, _, s, e in prof]
+    st = [s.elapsed_time(e) for _, _, s, e in prof] + [0.0]
     gf = prof[1][1]
     fl = direct.flops(B, od.shape[2], od.shape[3])
     print('%-28s direct %7.3f ms %6.1f TF/s | wino %7.3f ms (in %.3f gemm %.3f [%5.1f TF/s] out %.3f) '

@@ -109,9 +109,12 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize('fused_max', [0, 4096])
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_conv_winograd_matches_oracle(ops, case):
-    """Winograd F(2x2,3x3) path (iiseg_conv_wino_f32) against the float64 oracle conv."""
+def test_conv_winograd_matches_oracle(ops, case, fused_max, monkeypatch):
+    """Winograd F(2x2,3x3) path (iiseg_conv_wino_f32) against the float64 oracle conv; both the
+    GEMM + output-transform pair and the fused kernel (Cin % 32 == 0 cases)."""
+    monkeypatch.setattr(ops, 'WINO_FUSED_MAX_CIN', fused_max)
     B, Cin, H, W, Cout, pad, relu = case
     rng = np.random.default_rng(hash(case) % 2**32)
     x, w, b = rnd(rng, B, Cin, H, W), rnd(rng, Cout, Cin, 3, 3) * 0.2, rnd(rng, Cout)
@@ -126,11 +129,17 @@ def test_conv_winograd_matches_oracle(ops, case):
     assert np.abs(got - ref).max() <= 4 * conv_tol(ref, Cin * 9)
 
 
-def test_conv_winograd_windows_are_bit_identical(ops):
+@pytest.mark.parametrize('fused_max', [0, 4096])
+def test_conv_winograd_windows_are_bit_identical(ops, fused_max, monkeypatch):
+    monkeypatch.setattr(ops, 'WINO_FUSED_MAX_CIN', fused_max)
+    _winograd_windows(ops)
+
+
+def _winograd_windows(ops):
     """Any window of a layer (odd/even origins, placement into a larger plane, channel slice,
     two-source concat, skip add) gives exactly the values of the full-map launch."""
     rng = np.random.default_rng(77)
-    B, C1, C2, H, W, Cout, pad = 2, 16, 32, 15, 18, 36, 3
+    B, C1, C2, H, W, Cout, pad = 2, 16, 48, 15, 18, 36, 3
     x1, x2 = rnd(rng, B, C1, H, W), rnd(rng, B, C2, H, W)
     w, b = rnd(rng, Cout, C1 + C2, 3, 3) * 0.2, rnd(rng, Cout)
     OH, OW = H + 2 * pad - 2, W + 2 * pad - 2
