@@ -1,0 +1,282 @@
+// Halo-tile direct 3x3 convolution for gfx950 (CDNA4), fp32 MFMA: the kernel for the SHALLOW 3x3
+// layers of the hot path (few channels, 113^2..422^2 maps), where conv_taps.hip is bound by its
+// gather (one buffer_load per (channel, tap, pixel)) and Winograd by its transforms' HBM traffic.
+//
+// A workgroup owns a TH x 32 pixel tile of one image and BM output channels.  Per k-tile (4 input
+// channels = 36 k) it stages the (TH+2) x 34 input PATCH of those channels into LDS once --
+// 9x fewer global loads and LDS writes than materialising the im2col tile -- and the MFMA B
+// operand is read straight out of the patch: element (k = (c, ky, kx), pixel (y, x)) lives at
+// patch[c][y + ky][x + kx], i.e. lane address = lane base + a compile-time constant per k.
+// The accumulation order over k is the same (channel-major, tap-minor, sequential 32x32x2 steps)
+// as conv_taps.hip / conv_igemm.hip, so results are bit-identical to those kernels.
+//
+// Fusions: two-source channel concat (h first; needs C1 % 4 == 0), DePool2D equality-mask unpool
+// as the patch load (3 loads + compare per patch element instead of per im2col element:
+// layers/mylayers.py:88-115), bias / skip-add with crop / ReLU / window / placement epilogue.
+// Same Lasagne Conv2DLayer call sites as conv_taps.hip (models/fcn8.py:34-45,
+// models/fcn_down.py:102-104, models/fcn_up.py:83-86).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+constexpr int RSRC_W3 = 0x00027000;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const float* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+template <int BM, int TH, int WM, int WN, bool UNPOOL>
+__global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams p, const int tiles_y,
+                                                               const int tiles_x) {
+    constexpr int CPT = 4, BK = 9 * CPT, NCH = BK / 2;
+    constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int PE = CPT * PP;              // patch elements per k-tile
+    constexpr int NE = (PE + 255) / 256;      // ... per thread
+    constexpr int WTM = BM / WM, TM = WTM / 32;
+    constexpr int RW = TH / WN, TN = RW;      // output rows per wave = 32-pixel MFMA column tiles
+    constexpr int WVEC = BK * BM / 4, WPT = (WVEC + 255) / 256;
+    static_assert(WM * WN == 4 && TH % WN == 0 && BM % (WM * 32) == 0 && WPT <= 5, "tile config");
+
+    __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Ps[2][NE * 256];
+
+    int pt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
+    const int m0 = mt * BM;
+    const int tpi = tiles_y * tiles_x;
+    const int b = pt / tpi;
+    const int tr = pt - b * tpi;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int wy0 = ty * TH, wx0 = tx * TW;                        // tile origin, window coords
+    const int iy0 = p.oy0 + wy0 - p.pad, ix0 = p.ox0 + wx0 - p.pad;  // patch origin, input coords
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW = p.H * p.W, hw2 = p.h2 * p.w2;
+    const int C1 = p.C1, Ctot = p.C1 + p.C2;
+
+    // ---- patch staging: element e = i*256 + tid  ->  (channel of the k-tile, patch y, patch x) ----
+    unsigned voff[NE], voff2[UNPOOL ? NE : 1];
+    int cl[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = i * 256 + tid;
+        const int c = e / PP, rr = e - c * PP;
+        const int py = rr / PW, px = rr - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        bool ok = e < PE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        cl[i] = c;
+        voff[i] = ok ? 4u * (unsigned)(c * HW + iy * p.W + ix) : OOB;
+        if constexpr (UNPOOL) {
+            // DePool2D (layers/mylayers.py:95-114): only the 2h x 2w region has pooling windows
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+            voff2[i] = ok ? 4u * (unsigned)(c * hw2 + (iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+        }
+    }
+    // one image per tile: descriptors start at image b of each source
+    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
+    const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
+    const float* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
+    const float* baseu = UNPOOL ? p.x1 + (size_t)b * C1 * hw2 : nullptr;
+    const int nq = C1 * hw2 * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float xv[UNPOOL ? NE : 1], xq[UNPOOL ? NE : 1], xu[UNPOOL ? NE : 1];
+    const int wrow0 = tid / (BM / 4);
+    constexpr int RPJ = 256 / (BM / 4);
+    const int wc4 = tid % (BM / 4);
+    const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, p.Kpad * p.Mpad * 4);
+
+    // channels [c0, c0+4) of the logical (concatenated) input; the source is tile-uniform
+#define HALO_LOAD_X(KT, BUF)                                                                       \
+    {                                                                                              \
+        const int c0 = (KT) * CPT;                                                                 \
+        if constexpr (UNPOOL) {                                                                    \
+            const int crem = C1 - c0;                                                              \
+            static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const bool cok = cl[i] < crem;                                                     \
+                const unsigned vo = cok ? voff[i] : OOB, vo2 = cok ? voff2[i] : OOB;               \
+                xv[i] = buf_ld(mk_rsrc(base1, n1), vo, (unsigned)(c0 * HW) * 4u);                  \
+                xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+                xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+            });                                                                                    \
+        } else {                                                                                   \
+            const bool s1 = c0 < C1;                                                               \
+            const int crem = (s1 ? C1 : Ctot) - c0;                                                \
+            const unsigned so = (unsigned)((s1 ? c0 : c0 - C1) * HW) * 4u;                         \
+            static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const unsigned vo = cl[i] < crem ? voff[i] : OOB;                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                          \
+                    mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2),                                     \
+                    (__attribute__((address_space(3))) void*)(&Ps[BUF][i * 256 + wave * 64]), 4,   \
+                    (int)vo, (int)so, 0, 0);                                                       \
+            });                                                                                    \
+        }                                                                                          \
+    }
+#define HALO_STORE_X(BUF)                                                                          \
+    if constexpr (UNPOOL) {                                                                        \
+        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */          \
+            Ps[BUF][i * 256 + tid] = (xv[i] == xq[i]) ? xu[i] : 0.f;                               \
+        });                                                                                        \
+    }
+#define HALO_W_ON(j) ((j) < WPT && (((j) + 1) * 256 <= WVEC || tid + 256 * (j) < WVEC))
+#define HALO_W_DMA(KT, BUF, j)                                                                     \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                      \
+        wrsrc, (__attribute__((address_space(3))) void*)(&Ws[BUF][0][0] + (wave * 64 + 256 * (j)) * 4), \
+        16, (int)(4u * (unsigned)(((KT) * BK + wrow0 + (j) * RPJ) * p.Mpad + m0 + wc4 * 4)), 0, 0, 0)
+#define HALO_LOAD_W(KT, BUF)                                                                       \
+    {                                                                                              \
+        if (HALO_W_ON(0)) HALO_W_DMA(KT, BUF, 0);                                                  \
+        if (HALO_W_ON(1)) HALO_W_DMA(KT, BUF, 1);                                                  \
+        if (HALO_W_ON(2)) HALO_W_DMA(KT, BUF, 2);                                                  \
+        if (HALO_W_ON(3)) HALO_W_DMA(KT, BUF, 3);                                                  \
+        if (HALO_W_ON(4)) HALO_W_DMA(KT, BUF, 4);                                                  \
+    }
+
+    const int nkt = p.Kpad / BK;
+    HALO_LOAD_X(0, 0)
+    HALO_LOAD_W(0, 0)
+    HALO_STORE_X(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lbase = wn * RW * PW + l31;   // this lane's pixel inside the patch (tap 0,0)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        float a[2][TM], bq[2][TN];
+        // k = 2*ch + lh  ->  patch offset of (channel, ky, kx) = compile-time constant per ch
+#define HALO_KOFF(K) (((K) / 9) * PP + (((K) % 9) / 3) * PW + ((K) % 9) % 3)
+        {
+            const int kb = lh ? HALO_KOFF(1) : HALO_KOFF(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = Ws[buf][lh][wm * WTM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[0][j] = Ps[buf][lbase + kb + j * PW];
+        }
+        static_for<0, NCH>([&](auto CH) __attribute__((always_inline)) {
+            constexpr int ch = decltype(CH)::value;
+            if constexpr (ch + 1 < NCH) {
+                constexpr int k0 = 2 * (ch + 1);
+                const int kb = lh ? HALO_KOFF(k0 + 1) : HALO_KOFF(k0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[(ch + 1) & 1][i] = Ws[buf][k0 + lh][wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bq[(ch + 1) & 1][j] = Ps[buf][lbase + kb + j * PW];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch & 1][i], bq[ch & 1][j],
+                                                                     acc[i][j], 0, 0, 0);
+            if constexpr (ch == 0) {
+                if (more) {
+                    HALO_LOAD_W(kt + 1, buf ^ 1)
+                    HALO_LOAD_X(kt + 1, buf ^ 1)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more) HALO_STORE_X(buf ^ 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef HALO_KOFF
+#undef HALO_LOAD_X
+#undef HALO_STORE_X
+#undef HALO_LOAD_W
+#undef HALO_W_DMA
+#undef HALO_W_ON
+
+    // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store ---------------------------
+    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh
+    const int wx = wx0 + l31;
+    if (wx >= p.OW) return;
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int wy = wy0 + wn * RW + j;
+        if (wy >= p.OH) continue;
+        float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                      (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        const float* addp = p.add ? p.add + (size_t)b * p.Cout * APL +
+                                        (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
+                                  : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) {
+                    float v = acc[i][j][r];
+                    if (p.bias) v += p.bias[co];
+                    if (addp) v += addp[(size_t)co * APL];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    outp[(size_t)co * OPL] = v;
+                }
+            }
+    }
+}
+
+template <int BM, int TH, int WM, int WN>
+int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
+    ConvParams p = cp;
+    const int tiles_y = (p.OH + TH - 1) / TH, tiles_x = (p.OW + 31) / 32;
+    p.n_ptiles = p.B * tiles_y * tiles_x;
+    p.n_mtiles = p.Mpad / BM;
+    const int grid = p.n_ptiles * p.n_mtiles;
+    if (unpool)
+        hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
+                           p, tiles_y, tiles_x);
+    else
+        hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, false>), dim3(grid), dim3(256), 0, s,
+                           p, tiles_y, tiles_x);
+    return iiseg_check_launch();
+}
+
+}  // namespace
+
+// 1 if the halo kernel can run this (already validated) 3x3 request
+bool iiseg_conv_halo_ok(const ConvParams& p, int KH, int KW) {
+    if (KH != 3 || KW != 3 || p.dil != 1 || p.transposed) return false;
+    if (p.Kpad % 36) return false;
+    if (p.C2 > 0 && p.C1 % 4) return false;  // a k-tile (4 channels) must not straddle the sources
+    const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;
+    if (cmax * p.H * p.W * 4 >= (1ll << 31)) return false;  // per-image 32-bit byte offsets
+    if ((int64_t)p.B * ((p.OH + 3) / 4) * ((p.OW + 31) / 32) * (p.Mpad / 32) >= (1ll << 31)) return false;
+    return true;
+}
+
+int iiseg_launch_conv_halo(hipStream_t s, const ConvParams& p, int bm, bool unpool) {
+    switch (bm) {
+        case 128: return launch_halo<128, 4, 2, 2>(s, p, unpool);
+        case 64: return launch_halo<64, 8, 1, 4>(s, p, unpool);
+        default: return launch_halo<32, 8, 1, 4>(s, p, unpool);
+    }
+}

@@ -24,6 +24,9 @@ using namespace iiseg;
 // conv_taps.hip
 int iiseg_taps_cpt(int KH, int KW);
 int iiseg_launch_conv_taps(hipStream_t s, const ConvParams& p, int KH, int KW, int bm, bool unpool);
+// conv_halo.hip: halo-tile direct 3x3 kernel
+bool iiseg_conv_halo_ok(const ConvParams& p, int KH, int KW);
+int iiseg_launch_conv_halo(hipStream_t s, const ConvParams& p, int bm, bool unpool);
 
 namespace {
 
@@ -318,7 +321,8 @@ int mpad_for(const iiseg_conv_desc* d) {
 // multiples of BK for the table-driven one.
 int kpad_for(const iiseg_conv_desc* d) {
     const int C = d->C1 + d->C2, T = d->KH * d->KW;
-    const int cpt = iiseg_taps_cpt(d->KH, d->KW);
+    int cpt = iiseg_taps_cpt(d->KH, d->KW);
+    if (d->KH == 3 && d->KW == 3) cpt = 4;  // conv_halo's k-tile (conv_taps' 2 divides it)
     if (cpt > 0) return (C + cpt - 1) / cpt * cpt * T;
     return (C * T + BK - 1) / BK * BK;
 }
@@ -440,6 +444,10 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
 
     hipStream_t s = (hipStream_t)stream;
+    // IISEG_CONV_HALO: 0 = never, 1 = 3x3 layers with Cout < 256 (default), 2 = every 3x3 layer
+    static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
+    if (halo && (halo > 1 || d->Cout < 256) && iiseg_conv_halo_ok(p, d->KH, d->KW))
+        return iiseg_launch_conv_halo(s, p, pick_bm(d->Cout), unpool);
     if (iiseg_taps_cpt(d->KH, d->KW) > 0)
         return iiseg_launch_conv_taps(s, p, d->KH, d->KW, pick_bm(d->Cout), unpool);
     switch (pick_bm(d->Cout)) {

@@ -101,9 +101,11 @@ class StandardDAE:
             self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
                                       device=device, dtype=dtype)                     # fcn_up.py:83-86
         self.conv_log = None
-        # DePool2D fused into the conv's gather (3 loads per element) or materialised first
-        self.fuse_unpool = os.environ.get('IISEG_FUSE_UNPOOL', '0') != '0'
-        self.fuse_max_cout = int(os.environ.get('IISEG_FUSE_MAX_COUT', '0'))
+        # DePool2D fused into the conv's input load or materialised first.  None (auto): fused for
+        # the layers that run on the direct halo-tile kernel (the mask costs 3 loads per PATCH
+        # element there), materialised for the Winograd layers; True / False force either form.
+        env = os.environ.get('IISEG_FUSE_UNPOOL', 'auto')
+        self.fuse_unpool = None if env == 'auto' else env != '0'
         # compute each decoder level only on the window that reaches the final crop
         self.dce = os.environ.get('IISEG_DECODER_DCE', '1') != '0'
         # inside a refinement loop recompute only the y-dependent part of the encoder maps
@@ -245,11 +247,12 @@ class StandardDAE:
             mpre, mpool = pre[p], pool[p]
             if mask_override and p in mask_override:
                 mpre, mpool = mask_override[p]
-            if not (self.fuse_unpool or conv.Cout <= self.fuse_max_cout):
-                # Measured on MI355X: the fused gather needs 3 loads per element and the conv is
-                # limited by its vector-memory instructions, so for wide layers it is faster to
-                # materialise DePool2D with the HBM-bound kernel and run the plain conv; the
-                # narrow last layer (Cout = 11, HBM-bound itself) keeps the fused form.
+            fuse = self.fuse_unpool
+            if fuse is None:
+                fuse = conv.dtype == torch.float32 and not conv.wino
+            if not fuse:
+                # materialise DePool2D with the HBM-bound kernel and run the plain conv (Winograd
+                # form for the wide layers)
                 uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)
                 uy1, ux1 = min(cy + y0 + nh + 1, ph), min(cx + x0 + nw + 1, pw)
                 u = torch.empty_like(mpre)

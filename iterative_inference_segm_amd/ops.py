@@ -100,6 +100,11 @@ class Conv:
                                           'go through im2col')
         else:
             self.kernel = 'conv_taps_f32_kernel' if taps else 'conv_igemm_f32_kernel'
+            # direct 3x3 layers below 256 output channels run on the halo-tile kernel (the C side
+            # dispatches: conv_igemm.hip, IISEG_CONV_HALO)
+            if (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed and \
+                    self.Cout < 256 and os.environ.get('IISEG_CONV_HALO', '1') != '0':
+                self.kernel = 'conv_halo_f32_kernel'
             self.via_im2col = False
         self.wino = (dtype == torch.float32 and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
                      not self.transposed and self.Cin % 16 == 0 and
@@ -233,7 +238,10 @@ class Conv:
                                           _ptr(self.b), _ptr(add), _ptr(out)), 'iiseg_conv_f32')
         if prof is not None:
             ev1.record()
-            prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
+            kern = self.kernel
+            if kern == 'conv_halo_f32_kernel' and C2 > 0 and C1 % 4:
+                kern = 'conv_taps_f32_kernel'      # a k-tile would straddle the two sources
+            prof.append((kern, self.flops(B, d.OH, d.OW), ev0, ev1))
         return out
 
 
