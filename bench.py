@@ -40,9 +40,11 @@ from iterative_inference_segm_amd import synthetic as S  # noqa: E402
 N_CLASSES = 11
 GFLOP_PER_IMAGE = 872.3          # 119.24 (FCN-8) + 10 x 75.31 (DAE), nominal
 PEAK_TFLOPS_F32_MFMA = 157.3     # MI355X_MICROARCH.md, fp32 matrix peak
-# HBM bytes per conv_taps launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
-# MI355X_MICROARCH.md HBM section); filled from profiles/, None until measured
-TRAFFIC_GB_PER_LAUNCH = 2.18   # profiles/r01_pmc_hbm_traffic.md: 1.349 (read, x2) + 0.831 (write)
+# HBM GB per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
+# MI355X_MICROARCH.md HBM section), profiles/r01_pmc_hbm_traffic.md; None = not measured
+TRAFFIC_GB_PER_LAUNCH = {'wino_gemm_kernel': 0.997, 'wino_fused_kernel': 1.404,
+                         'conv_halo_f32_kernel': 1.455, 'conv_taps_f32_kernel': 0.293,
+                         'conv_igemm_f32_kernel': 2.201}
 
 
 def build_model(device, concat_h):
@@ -101,7 +103,8 @@ def conv_roofline(ii, X, T, num_iter, step_size):
     achieved = flops / (ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'kernel': kern, 'achieved': round(achieved, 2),
             'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_TFLOPS_F32_MFMA, 4), 'traffic': TRAFFIC_GB_PER_LAUNCH,
+            'frac': round(achieved / PEAK_TFLOPS_F32_MFMA, 4),
+            'traffic': TRAFFIC_GB_PER_LAUNCH.get(kern),
             'traffic_unit': 'GB of HBM traffic per launch (rocprofv3 PMC, profiles/)',
             'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
             'gflop_per_launch': round(flops / n / 1e9, 3), 'kernel_ms_per_step': round(ms, 2),

@@ -21,6 +21,7 @@
 // fusions kept: two-source channel concat (h first), bias / skip-add / ReLU / window / placement.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoPa
 // M_xi lives in registers only: after the K loop of each xi it is folded into the four output
 // accumulators Y_ab += AT[a][i] * AT[b][j] * M_xi (coefficients 0 / +-1, xi = 4i + j), so the
 // products never travel to HBM and the output transform costs 4 FMAs per element per xi.
-template <int BM, int BN, int WM, int WN, int BK>
-__global__ __launch_bounds__(WM * WN * 64, 2) void wino_fused_kernel(const WinoParams p) {
+template <int BM, int BN, int WM, int WN, int BK, int MINW>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const WinoParams p) {
     constexpr int NCH = BK / 2;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -373,19 +374,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_fused_kernel(const WinoP
             const float r0 = wi < 3 ? 1.f : 0.f, r1 = wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f);
             const float c0 = wj < 3 ? 1.f : 0.f, c1 = wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f);
             const float k00 = r0 * c0, k01 = r0 * c1, k10 = r1 * c0, k11 = r1 * c1;
+            // coefficients are 0 / +-1 and wave-uniform: skip the accumulators xi does not reach
+#define WINO_FOLD(Q, KQ)                                                                            \
+            if ((KQ) != 0.f) {                                                                      \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                      \
+                    Y[Q][i][j][r] = fmaf((KQ), acc[i][j][r], Y[Q][i][j][r]);                        \
+            }
+            WINO_FOLD(0, k00)
+            WINO_FOLD(1, k01)
+            WINO_FOLD(2, k10)
+            WINO_FOLD(3, k11)
+#undef WINO_FOLD
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float m = acc[i][j][r];
-                        Y[0][i][j][r] = fmaf(k00, m, Y[0][i][j][r]);
-                        Y[1][i][j][r] = fmaf(k01, m, Y[1][i][j][r]);
-                        Y[2][i][j][r] = fmaf(k10, m, Y[2][i][j][r]);
-                        Y[3][i][j][r] = fmaf(k11, m, Y[3][i][j][r]);
-                        acc[i][j][r] = 0.f;
-                    }
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
         xi = nxi;
         kt = nkt1;
@@ -598,7 +605,14 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
             hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
         if (stages & IISEG_WINO_GEMM) {
             p.n_mtiles = g.Mpad / 128;
-            hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 32>),
+            // short K loops (<= 128 channels): two independent 4-wave workgroups per CU hide the
+            // per-xi fold better than one 8-wave workgroup (scripts/bench_wino.py)
+            if (g.Kc <= 128) {
+                p.n_ttiles = g.Tpad / 64;
+                hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 2, 32, 2>),
+                                   dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+            } else
+            hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 32, 2>),
                                dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
         }
         return iiseg_check_launch();

@@ -1,0 +1,80 @@
+"""Turn rocprofv3 outputs (CSV) into the summaries committed under profiles/.
+
+  python scripts/make_profiles.py stats <dir with *kernel_trace.csv> <out.csv>
+  python scripts/make_profiles.py pmc <fetch dir> <write dir> <out.md>
+
+PMC units follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE count KiB; on gfx950
+FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled; WRITE_SIZE is exact."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r'(\w+_kernel)(I[^E]*E)?', name)
+    if not m:
+        return name[:60]
+    tmpl = m.group(2) or ''
+    args = re.findall(r'L[ib](\d+)E', tmpl)
+    return m.group(1) + ('<' + ','.join(args) + '>' if args else '')
+
+
+def find(d, pat):
+    f = glob.glob(d + '/**/*' + pat, recursive=True)
+    if not f:
+        raise SystemExit('no %s under %s' % (pat, d))
+    return f[0]
+
+
+def stats(d, out):
+    per = collections.OrderedDict()
+    for r in csv.DictReader(open(find(d, 'kernel_trace.csv'))):
+        e = per.setdefault(short(r['Kernel_Name']), [0, 0.0])
+        e[0] += 1
+        e[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+    tot = sum(v[1] for v in per.values())
+    with open(out, 'w') as f:
+        f.write('kernel,calls,total_ms,avg_ms,percent\n')
+        for k, (n, ms) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            f.write('%s,%d,%.3f,%.4f,%.2f\n' % (k, n, ms, ms / n, 100 * ms / tot))
+        f.write('TOTAL,%d,%.3f,,100\n' % (sum(v[0] for v in per.values()), tot))
+    print(open(out).read())
+
+
+def pmc(fd, wd, out):
+    def load(d, counter):
+        per = collections.OrderedDict()
+        seen = collections.defaultdict(set)
+        for r in csv.DictReader(open(find(d, 'counter_collection.csv'))):
+            if r['Counter_Name'] != counter:
+                continue
+            k = short(r['Kernel_Name'])
+            e = per.setdefault(k, [0, 0.0])
+            if r['Dispatch_Id'] not in seen[k]:
+                seen[k].add(r['Dispatch_Id'])
+                e[0] += 1
+            e[1] += float(r['Counter_Value'])
+        return per
+    fe, wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
+    rows = []
+    for k in fe:
+        n = fe[k][0]
+        rd = 2 * fe[k][1] * 1024 / n / 1e9
+        w = wr.get(k, [n, 0.0])
+        rows.append((k, n, fe[k][1], rd, w[1], w[1] * 1024 / max(w[0], 1) / 1e9))
+    rows.sort(key=lambda r: -(r[3] + r[5]) * r[1])
+    with open(out, 'w') as f:
+        f.write('| kernel | launches | FETCH_SIZE sum (KiB) | read GB/launch (x2) | WRITE_SIZE sum (KiB) '
+                '| write GB/launch | total GB/launch |\n|---|---:|---:|---:|---:|---:|---:|\n')
+        for k, n, fs, rd, ws, wg in rows:
+            f.write('| %s | %d | %.4g | %.3f | %.4g | %.3f | %.3f |\n' % (k, n, fs, rd, ws, wg, rd + wg))
+    print(open(out).read())
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'stats':
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
