@@ -203,7 +203,7 @@ def main():
         line['executed_gflop_per_image'] = round(rl['all_conv_gflop_per_step'] / B, 1)
     if not args.no_full_recompute:
         # same timing protocol with the exact work eliminations switched off
-        ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = False
+        ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = False
         one_step(ii, X, T, args.num_iter, args.step_size)
         torch.cuda.synchronize()
         iidist.barrier()
@@ -217,13 +217,14 @@ def main():
             tmax = torch.tensor([dt_full], dtype=torch.float64, device=device)
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
             dt_full = float(tmax.item())
-        ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = True
+        ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
         v_full = world * B * args.steps / dt_full
         line['full_recompute'] = {
             'value': round(v_full, 3), 'unit': 'images/s',
             'ms_per_step': round(dt_full / args.steps * 1e3, 2),
             'nominal_tflops': round(v_full * GFLOP_PER_IMAGE / 1e3, 2),
-            'note': 'IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0: all 872.3 '
+            'note': 'IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
+                    'IISEG_DAE_BORDER_FOLD=0: all 872.3 '
                     'GFLOP/image executed'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -111,7 +111,7 @@ class IterativeInference:
             per_iter = torch.zeros((int(num_iter), nb), dtype=torch.int64, device=y.device)
             scratch = torch.zeros(2, dtype=torch.float64, device=y.device)
         # h is fixed and only y evolves: the DAE may keep loop-invariant parts of its maps
-        sess = self.dae.new_session() if hasattr(self.dae, 'new_session') else None
+        sess = self.dae.new_session(H, y) if hasattr(self.dae, 'new_session') else None
         for it in range(int(num_iter)):
             score = self.dae.scores(H, y, session=sess) if sess is not None \
                 else self.dae.scores(H, y)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
 }
 
 // ---- 2. the 16 GEMMs ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoParams p) {
     constexpr int BK = 16, NCH = BK / 2;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoPa
     constexpr int APT = AV / NA, BPT = BV / 256;
     static_assert((NW == 4 || NW == 8) && AV % NA == 0 && BV % 256 == 0, "tile config");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK][BN];
 
     // XCD-aware order: each XCD (bid % 8) walks a contiguous run of (xi, tile) work, inside a
     // run groups of 8 pixel-tiles x all channel-tiles share U and V rows in that XCD's L2
@@ -219,13 +219,38 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoPa
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = p.Kc / BK;
+    // NBUF-deep ring of LDS tiles: tile kt+NBUF-1 is requested while tile kt is multiplied, so a
+    // global -> LDS transfer has NBUF-1 tiles of MFMA work to land.  vmcnt counts this wave's
+    // own outstanding DMA ops, in order: leaving one stage's worth in flight means every older
+    // stage has landed.
+    constexpr int OPS_A = APT, OPS_B = BPT;
+#define WINO_WAIT_ONE_STAGE_IN_FLIGHT()                                                            \
+    {                                                                                              \
+        if constexpr (NW == 8) {                                                                   \
+            if (astager) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS_A) : "memory");              \
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS_B) : "memory");                      \
+        } else {                                                                                   \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS_A + OPS_B) : "memory");                   \
+        }                                                                                          \
+    }
     WINO_STAGE(0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NBUF == 3) {
+        if (nkt > 1) {
+            WINO_STAGE(1, 1)
+            WINO_WAIT_ONE_STAGE_IN_FLIGHT()
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
+    int buf = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nkt;
+        const bool more = kt + NBUF - 1 < nkt;
+        int sbuf = buf + NBUF - 1;               // ring slot of the tile requested now
+        if (sbuf >= NBUF) sbuf -= NBUF;
         float a[2][TM], b[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lh][wm * WTM + i * 32 + l31];
@@ -247,14 +272,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoPa
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ch & 1][i], b[ch & 1][j],
                                                                      acc[i][j], 0, 0, 0);
             if constexpr (ch == 0) {
-                if (more) WINO_STAGE(kt + 1, buf ^ 1)
+                if (more) WINO_STAGE(kt + NBUF - 1, sbuf)
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NBUF == 3 && more) {
+            WINO_WAIT_ONE_STAGE_IN_FLIGHT()
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
+        if (++buf == NBUF) buf = 0;
     }
 #undef WINO_STAGE
+#undef WINO_WAIT_ONE_STAGE_IN_FLIGHT
 
     // M[xi][co][t]: rows of the C/D layout are channels, columns (lane & 31) are tiles
     float* Mx = p.M + (size_t)xi * p.Mpad * p.Tpad;
@@ -621,10 +652,15 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
     const int grid = 16 * p.n_ttiles * p.n_mtiles;
     if (stages & IISEG_WINO_GEMM) {
-        if (g.bm == 256)
-            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2>), dim3(grid), dim3(512), 0, s, p);
+        static const int nbuf = getenv("IISEG_WINO_NBUF") ? atoi(getenv("IISEG_WINO_NBUF")) : 2;
+        if (g.bm == 256 && nbuf == 3)
+            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 3>), dim3(grid), dim3(512), 0, s, p);
+        else if (g.bm == 256)
+            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
+        else if (nbuf == 3)
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 3>), dim3(grid), dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
     }
     if (stages & IISEG_WINO_OUTPUT)
         hipLaunchKernelGGL(wino_output_kernel, dim3(tb, (d->Cout + OCH - 1) / OCH), dim3(256), 0, s,

@@ -110,10 +110,30 @@ class StandardDAE:
         self.dce = os.environ.get('IISEG_DECODER_DCE', '1') != '0'
         # inside a refinement loop recompute only the y-dependent part of the encoder maps
         self.licm = os.environ.get('IISEG_ENCODER_LICM', '1') != '0'
+        # keep the weights-only border of the encoder maps across batches (see new_session)
+        self.fold_border = os.environ.get('IISEG_DAE_BORDER_FOLD', '1') != '0'
+        self._store = None
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
 
-    def new_session(self):
-        """State of one refinement loop (h fixed, y evolving): see `scores`."""
+    def new_session(self, h_list=None, y=None):
+        """State of one refinement loop (h fixed, y evolving): see `scores`.
+
+        When every h carries the provenance tag of a border-folding FCN-8 (fcn8.py: outside the
+        tagged region the map depends on that net's weights and the geometry only), the encoder
+        maps of this DAE have a batch-independent border too: the session of the previous batch
+        of the same geometry is handed out again and the first step recomputes only the region
+        that y or the image-dependent part of h can reach."""
+        tags = [getattr(h, '_iiseg_border', None) for h in (h_list or [])]
+        if self.licm and self.fold_border and y is not None and tags and \
+                all(t is not None for t in tags):
+            key = (tuple(t[0] for t in tags), tuple(y.shape), y.dtype)
+            st = self._store
+            if st is not None and st.get('key') == key and st.get('primed'):
+                st['h_fresh'] = True
+                st['h_dep'] = [t[1] for t in tags]
+                return st
+            self._store = {'primed': False, 'key': key}
+            return self._store
         return {'primed': False}
 
     def conv_layers(self):
@@ -133,6 +153,7 @@ class StandardDAE:
             raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
         pos = 0
         pending_h = None
+        h_fresh = session is not None and session.get('h_fresh', False)
         if self.concat_h[pos] == 'input':                # model_helpers.py:86-94 at the input
             pending_h, pos = h_list[pos], pos + 1
         t = y
@@ -153,6 +174,13 @@ class StandardDAE:
                 name = 'conv%d_%d' % (p + 1, i)
                 conv = self.enc[name]
                 kw = {}
+                if primed and pending_h is not None and h_fresh:
+                    # a new batch in a reused session: h changed inside its tagged region
+                    hd = session['h_dep'][pos - 1]
+                    y1 = max(dep[0] + dep[2], hd[0] + hd[2])
+                    x1 = max(dep[1] + dep[3], hd[1] + hd[3])
+                    dep = (min(dep[0], hd[0]), min(dep[1], hd[1]), 0, 0)
+                    dep = (dep[0], dep[1], y1 - dep[0], x1 - dep[1])
                 if primed:
                     buf = session[name]
                     fh, fw = buf.shape[2], buf.shape[3]
@@ -168,6 +196,13 @@ class StandardDAE:
                         hb = conv_h(pending_h)
                         if keep:
                             session['hb_' + name] = hb
+                    elif h_fresh:                        # reused session: only where h changed
+                        hd = session['h_dep'][pos - 1]
+                        hy0, hh = clip(hd[0] + conv_h.pad - (conv_h.KH - 1), hd[0] + hd[2] + conv_h.pad,
+                                       hb.shape[2])
+                        hx0, hw = clip(hd[1] + conv_h.pad - (conv_h.KW - 1), hd[1] + hd[3] + conv_h.pad,
+                                       hb.shape[3])
+                        conv_h(pending_h, window=(hy0, hx0, hh, hw), out=hb, place=(hy0, hx0))
                     off = kw['place'] if 'place' in kw else (0, 0)
                     t = conv_y(t, add=hb, add_off=off, **kw)
                     pending_h = None
@@ -196,6 +231,7 @@ class StandardDAE:
                 pending_h, pos = h_list[pos], pos + 1
         if session is not None:
             session['primed'] = True
+            session['h_fresh'] = False
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')

@@ -105,15 +105,16 @@ class FCN8:
         net = {'input': x}
         t = x
         dep = (0, 0, x.shape[2], x.shape[3])       # region of `t` that depends on x
+        deps = {}
         pending = hs.get('input')
         for bi, names in enumerate(_BLOCKS):
             for name in names:
                 conv = self.convs[name]
+                fh, fw = conv.out_hw(t.shape[2], t.shape[3])
+                dep = _conv_region(dep, conv, fh, fw)
                 kw = {}
                 if primed:
-                    buf = session[name]
-                    dep = _conv_region(dep, conv, buf.shape[2], buf.shape[3])
-                    kw = dict(window=dep, out=buf, place=(dep[0], dep[1]))
+                    kw = dict(window=dep, out=session[name], place=(dep[0], dep[1]))
                 if pending is not None:
                     t = self._conv(name, pending, x2=t, **kw)
                     pending = None
@@ -122,15 +123,15 @@ class FCN8:
                 if session is not None and not primed:
                     session[name] = t
             pname = 'pool%d' % (bi + 1)
+            dep = _pool_region(dep, t.shape[2] // 2, t.shape[3] // 2)
             if primed:
-                buf = session[pname]
-                dep = _pool_region(dep, buf.shape[2], buf.shape[3])
-                t = ops.maxpool2x2(t, out=buf, window=dep)             # :38,45,54,63,72
+                t = ops.maxpool2x2(t, out=session[pname], window=dep)   # :38,45,54,63,72
             else:
                 t = ops.maxpool2x2(t)
                 if session is not None:
                     session[pname] = t
             net[pname] = t
+            deps[pname] = dep
             pending = hs.get(pname)
         if session is not None:
             session['primed'] = True
@@ -151,9 +152,18 @@ class FCN8:
         score = self.upsample(t, window=(_center(uh, oh), _center(uw, ow), oh, ow))
         net['score'] = score
         net['probs_dimshuffle'] = ops.crop_softmax(score, oh, ow, off=(0, 0))  # :122-130,187-191
-        # maps owned by the internal border store are overwritten by the next call: hand out copies
-        return [net[el].clone() if own and el.startswith('pool') else net[el]
-                for el in self.layer]
+        # maps owned by the internal border store are overwritten by the next call: hand out
+        # copies, tagged with their provenance -- outside `deps[el]` such a map is a function of
+        # this net's weights and the geometry alone, which lets a consumer (the DAE's encoder)
+        # keep ITS weights-only border across batches as well
+        res = []
+        for el in self.layer:
+            t = net[el]
+            if own and el.startswith('pool'):
+                t = t.clone()
+                t._iiseg_border = ((id(self), session['key']), deps[el])
+            res.append(t)
+        return res
 
     def new_session(self):
         """State for consecutive forwards that differ only in x (see `forward`)."""
@@ -194,7 +204,7 @@ class FCN8DAE:
     def conv_layers(self):
         return self.net.convs
 
-    def new_session(self):
+    def new_session(self, h_list=None, y=None):
         """State of one refinement loop (h fixed, y evolving)."""
         return self.net.new_session() if self.licm else None
 

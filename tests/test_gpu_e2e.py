@@ -308,6 +308,47 @@ def test_fcn8_border_fold_is_bit_identical(built_lib, size, div, dtype):
         assert np.array_equal(host(g), host(r))
 
 
+@pytest.mark.parametrize('size,div,nf,dtype', [((224, 224), 1, 64, torch.float32),
+                                               ((40, 52), 16, 16, torch.float32),
+                                               ((36, 44), 16, 4, torch.float64)])
+def test_border_fold_across_batches_is_bit_identical(built_lib, size, div, nf, dtype):
+    """FCN-8 -> refine over three DIFFERENT batches: with the border stores on (FCN-8 encoder
+    border folded per geometry; the DAE session reused across batches because h carries the
+    FCN's provenance tag) every refined map, iteration count and norm must equal the run that
+    recomputes every map in full for every batch."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    concat_h = ['pool4']
+    fp = S.make_fcn8_params(width_div=div, fc_channels=4096 // div, seed=81)
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=nf, seed=82)
+    B = 1 if div == 1 else 2
+
+    def make(fold):
+        fcn = FCN8(fp, 11, layer=concat_h + ['probs_dimshuffle'], dtype=dtype)
+        dae = StandardDAE(dp, 11, concat_h=concat_h, n_filters=nf, dtype=dtype)
+        fcn.fold_border = dae.fold_border = fold
+        return IterativeInference(fcn, dae, 11, [11], dtype=dtype)
+    ii_fold, ii_full = make(True), make(False)
+    for i in range(3):
+        X = S.make_images(B, size[0], size[1], seed=90 + i)
+        res = []
+        for ii in (ii_fold, ii_full):
+            out = ii.pred_fcn_fn(X)
+            y, iters, norms = ii.refine(out[:-1], out[-1], 0.3, 3)
+            res.append((host(y), host(iters), host(norms)))
+        for a, b in zip(*res):
+            assert np.array_equal(a, b), 'batch %d differs' % i
+    assert ii_fold.dae._store is not None and ii_fold.dae._store['primed']
+    assert ii_full.dae._store is None
+    # an untagged h (e.g. numpy from disk) must not touch the store
+    out = ii_fold.pred_fcn_fn(X)
+    h_np = host(out[0])
+    y1, _, _ = ii_fold.refine([h_np], out[-1], 0.3, 2)
+    y2, _, _ = ii_full.refine([h_np], out[-1], 0.3, 2)
+    assert np.array_equal(host(y1), host(y2))
+
+
 def test_fcn8_kind_dae_session_is_bit_identical(built_lib):
     """dae kind 'fcn8' inside refine(): only the y-dependent region of the encoder maps is
     recomputed after the first step; refined maps identical to full recomputation."""
