@@ -225,7 +225,7 @@ def main():
             'nominal_tflops': round(v_full * GFLOP_PER_IMAGE / 1e3, 2),
             'note': 'IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
                     'IISEG_DAE_BORDER_FOLD=0: all 872.3 '
-                    'GFLOP/image executed'}
+                    'nominal GFLOP/image recomputed in full every step and batch (same kernels)'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(fp, dp, args.num_iter, args.step_size, concat_h)
