@@ -638,7 +638,11 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
             p.n_mtiles = g.Mpad / 128;
             // short K loops (<= 128 channels): two independent 4-wave workgroups per CU hide the
             // per-xi fold better than one 8-wave workgroup (scripts/bench_wino.py)
-            if (g.Kc <= 128) {
+            // ... and, for any K, when the 8-wave kernel's few long workgroups would leave CUs idle
+            // in the last round (work per CU is quantised in whole workgroups)
+            const int w0 = p.n_ttiles * p.n_mtiles, w2 = (g.Tpad / 64) * p.n_mtiles;
+            const double cost0 = (w0 + 255) / 256, cost2 = 0.5 * 1.03 * ((w2 + 255) / 256);
+            if (g.Kc <= 128 || cost2 < cost0) {
                 p.n_ttiles = g.Tpad / 64;
                 hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 2, 32, 2>),
                                    dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
@@ -653,14 +657,23 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
     const int grid = 16 * p.n_ttiles * p.n_mtiles;
     if (stages & IISEG_WINO_GEMM) {
         static const int nbuf = getenv("IISEG_WINO_NBUF") ? atoi(getenv("IISEG_WINO_NBUF")) : 2;
-        if (g.bm == 256 && nbuf == 3)
+        int bm = g.bm;
+        if (bm == 256) {
+            // few, long 256x128 workgroups quantise badly over 256 CUs: fall back to 128x128
+            // tiles (about 6 % less MFMA-efficient) when that fills the last round better
+            const int w256 = grid, w128 = 2 * grid;
+            if (0.5 * 1.06 * ((w128 + 255) / 256) < (double)((w256 + 255) / 256)) bm = 128;
+        }
+        const int grid2 = 16 * p.n_ttiles * (g.Mpad / bm);
+        p.n_mtiles = g.Mpad / bm;
+        if (bm == 256 && nbuf == 3)
             hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 3>), dim3(grid), dim3(512), 0, s, p);
-        else if (g.bm == 256)
+        else if (bm == 256)
             hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
         else if (nbuf == 3)
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 3>), dim3(grid), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 3>), dim3(grid2), dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid2), dim3(256), 0, s, p);
     }
     if (stages & IISEG_WINO_OUTPUT)
         hipLaunchKernelGGL(wino_output_kernel, dim3(tb, (d->Cout + OCH - 1) / OCH), dim3(256), 0, s,
