@@ -236,6 +236,16 @@ int iiseg_bn_stats_f32(void* stream, const float* x, int64_t bstride, int32_t B,
 int iiseg_bn_relu_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
                       int32_t HW, const float* beta, const float* gamma, const float* mean,
                       const float* inv_std, float* out);
+/* Stored-average BatchNorm of the DAE's bn=1 layers (lasagne BatchNormLayer at deterministic=True:
+ * models/fcn_down.py:112-114, models/fcn_up.py:91-93 under iterative_inference.py:189), in place on
+ * the window [y0,y0+wh) x [x0,x0+ww) of the (H,W) planes of x (B,C,H,W):
+ *   x = (x - mean[c]) * (gamma[c] * inv_std[c]) + beta[c] */
+int iiseg_bn_affine_window_f32(void* stream, float* x, int32_t B, int32_t C, int32_t H, int32_t W,
+                               int32_t y0, int32_t x0, int32_t wh, int32_t ww, const float* beta,
+                               const float* gamma, const float* mean, const float* inv_std);
+int iiseg_bn_affine_window_f64(void* stream, double* x, int32_t B, int32_t C, int32_t H, int32_t W,
+                               int32_t y0, int32_t x0, int32_t wh, int32_t ww, const double* beta,
+                               const double* gamma, const double* mean, const double* inv_std);
 int iiseg_bn_stats_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,
                        int32_t HW, double eps, double* mean, double* inv_std);
 int iiseg_bn_relu_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,

@@ -99,7 +99,8 @@ def build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_se
             dae_params = S.make_dae_params(
                 n_classes, tuple(h_channels[c] for c in dae_dict['concat_h']),
                 dae_dict['concat_h'], dae_dict['n_filters'], dae_dict['conv_before_pool'],
-                dae_dict['additional_pool'], dae_dict['unpool_type'], seed=4321)
+                dae_dict['additional_pool'], dae_dict['unpool_type'], seed=4321,
+                bn=dae_dict['bn'])
         dae = buildDAE(n_classes=n_classes,
                        nb_features_to_concat=h_channels[dae_dict['concat_h'][0]],
                        padding=padding, trainable=True, void_labels=void_labels,

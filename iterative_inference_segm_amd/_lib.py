@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -68,6 +68,8 @@ SIGNATURES = {
     'iiseg_bn_relu_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
     'iiseg_bn_stats_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _vp]),
     'iiseg_bn_relu_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
+    'iiseg_bn_affine_window_f32': (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp] * 4),
+    'iiseg_bn_affine_window_f64': (C.c_int, [_vp, _vp] + [_i32] * 8 + [_vp] * 4),
     # float64 (strict-parity) variants
     'iiseg_conv_plan_f64': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pack_f64': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),

@@ -58,6 +58,43 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const T* __restrict__ x, i
     }
 }
 
+// stored-average BatchNorm (deterministic=True with running averages: the DAE's bn=1 layers,
+// reference iterative_inference.py:189, models/fcn_down.py:112-114), in place on a window of the
+// (H, W) planes: x = (x - mean) * (gamma * inv_std) + beta
+template <typename T>
+__global__ __launch_bounds__(256) void bn_affine_window_kernel(T* __restrict__ x, int C, int H, int W,
+                                                               int y0, int x0, int wh, int ww,
+                                                               const T* __restrict__ beta,
+                                                               const T* __restrict__ gamma,
+                                                               const T* __restrict__ mean,
+                                                               const T* __restrict__ inv_std) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const T m = mean[c], g = gamma[c] * inv_std[c], be = beta[c];
+    T* xp = x + ((size_t)b * C + c) * H * W;
+    const int n = wh * ww;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int yy = i / ww, xx = i - yy * ww;
+        T* e = xp + (size_t)(y0 + yy) * W + x0 + xx;
+        *e = (*e - m) * g + be;
+    }
+}
+
+template <typename T>
+int bn_affine_window(void* stream, T* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t y0,
+                     int32_t x0, int32_t wh, int32_t ww, const T* beta, const T* gamma, const T* mean,
+                     const T* inv_std) {
+    if (!x || !beta || !gamma || !mean || !inv_std) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || y0 < 0 || x0 < 0 || wh <= 0 || ww <= 0 ||
+        y0 + wh > H || x0 + ww > W)
+        return IISEG_ERR_SHAPE;
+    if (C > 65535 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    int gx = (wh * ww + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_affine_window_kernel<T>, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream,
+                       x, C, H, W, y0, x0, wh, ww, beta, gamma, mean, inv_std);
+    return iiseg_check_launch();
+}
+
 template <typename T>
 int bn_stats(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, int32_t HW, double eps,
              T* mean, T* inv_std) {
@@ -100,4 +137,16 @@ extern "C" int iiseg_bn_relu_f64(void* stream, const double* x, int64_t bstride,
                                  int32_t HW, const double* beta, const double* gamma,
                                  const double* mean, const double* inv_std, double* out) {
     return bn_relu<double>(stream, x, bstride, B, C, HW, beta, gamma, mean, inv_std, out);
+}
+extern "C" int iiseg_bn_affine_window_f32(void* stream, float* x, int32_t B, int32_t C, int32_t H,
+                                          int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                          const float* beta, const float* gamma, const float* mean,
+                                          const float* inv_std) {
+    return bn_affine_window<float>(stream, x, B, C, H, W, y0, x0, wh, ww, beta, gamma, mean, inv_std);
+}
+extern "C" int iiseg_bn_affine_window_f64(void* stream, double* x, int32_t B, int32_t C, int32_t H,
+                                          int32_t W, int32_t y0, int32_t x0, int32_t wh, int32_t ww,
+                                          const double* beta, const double* gamma,
+                                          const double* mean, const double* inv_std) {
+    return bn_affine_window<double>(stream, x, B, C, H, W, y0, x0, wh, ww, beta, gamma, mean, inv_std);
 }

@@ -9,6 +9,8 @@ so the unpooled tensors, the concatenated tensor and the cropped score are never
 """
 import os
 
+import numpy as np
+
 import torch
 
 from . import ops
@@ -21,13 +23,20 @@ def _n_pool(concat_h, additional_pool):
 
 
 def param_order(concat_h=('pool4',), conv_before_pool=1, additional_pool=2,
-                unpool_type='trackind'):
-    """get_all_param_values order of dae_model_best.npz, bn=0."""
+                unpool_type='trackind', bn=0):
+    """get_all_param_values order of dae_model_best.npz; with bn=1 every conv is
+    followed by its BatchNormLayer entry `<name>_bn` (fcn_down.py:112-114, fcn_up.py:91-93)."""
     _, total = _n_pool(list(concat_h), additional_pool)
-    names = ['conv%d_%d' % (p + 1, i) for p in range(total)
-             for i in range(1, conv_before_pool + 1)]
-    names += [('up%d' if unpool_type == 'standard' else 'up_conv%d') % p
-              for p in range(total, 0, -1)]
+    names = []
+    for p in range(total):
+        for i in range(1, conv_before_pool + 1):
+            names.append('conv%d_%d' % (p + 1, i))
+            if bn:
+                names.append('conv%d_%d_bn' % (p + 1, i))
+    for p in range(total, 0, -1):
+        names.append(('up%d' if unpool_type == 'standard' else 'up_conv%d') % p)
+        if bn and unpool_type != 'standard':
+            names.append('up_conv%d_bn' % p)
     return names
 
 
@@ -51,8 +60,8 @@ class StandardDAE:
         if unpool_type == 'standard' and dtype != torch.float32:
             raise NotImplementedError("unpool_type='standard' (4x4/2 transposed conv) is float32 "
                                       "only")
-        if bn:
-            raise NotImplementedError('bn=1 DAE has no HIP kernel yet')
+        self.bn = bool(bn)
+        self.enc_bn = {}
         self.unpool_type = unpool_type
         self.concat_h, self.padding, self.skip = concat_h, padding, skip
         self.conv_before_pool = conv_before_pool
@@ -69,6 +78,10 @@ class StandardDAE:
                 self.enc[name] = ops.Conv(params[name][0], params[name][1],
                                           pad=padding if first_pad else 1, relu=True,
                                           device=device, dtype=dtype)                 # :102-104
+                if bn:   # BatchNormLayer on the rectified conv, stored averages (:112-114)
+                    self.enc_bn[name] = tuple(
+                        torch.as_tensor(np.asarray(a)).to(dtype).contiguous().to(device)
+                        for a in params[name + '_bn'])
         # The conv that follows a concat point computes W_h*h + W_y*features.  h does not change
         # during a refinement loop, so the h half (a per-pixel bias map) is loop-invariant
         # (SURVEY section 7): it is kept as its own linear conv whose output the y half adds in its
@@ -98,8 +111,16 @@ class StandardDAE:
                                           dtype=dtype)
                 continue
             name = 'up_conv%d' % p
-            self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=1, relu=False,
-                                      device=device, dtype=dtype)                     # fcn_up.py:83-86
+            W, b = params[name]
+            if bn:
+                # fcn_up.py:91-93: BatchNormLayer (stored averages) on the LINEAR up_conv, before
+                # the skip sum -- an affine per output channel, folded into W and b in float64
+                beta, gamma, mean, inv_std = (np.asarray(a, np.float64) for a in params[name + '_bn'])
+                sc = gamma * inv_std
+                W = np.asarray(W, np.float64) * sc[:, None, None, None]
+                b = (np.asarray(b, np.float64) - mean) * sc + beta
+            self.dec[name] = ops.Conv(W, b, pad=1, relu=False, device=device,
+                                      dtype=dtype)                                    # fcn_up.py:83-86
         self.conv_log = None
         # DePool2D fused into the conv's input load or materialised first.  None (auto): fused for
         # the layers that run on the direct halo-tile kernel (the mask costs 3 loads per PATCH
@@ -211,6 +232,8 @@ class StandardDAE:
                     pending_h = None
                 else:
                     t = conv(t, **kw)
+                if self.bn:
+                    ops.bn_affine(t, self.enc_bn[name], window=dep if primed else None)
                 if session is not None and not primed:
                     session[name] = t
                 self._count(name, conv, t, computed=(dep[2], dep[3]) if primed else None)
@@ -346,7 +369,7 @@ def buildDAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
     if params is None:
         if not (load_weights and path_weights):
             raise ValueError('buildDAE needs `params` or `path_weights`')
-        order = param_order(concat_h, conv_before_pool, additional_pool, unpool_type)
+        order = param_order(concat_h, conv_before_pool, additional_pool, unpool_type, bn)
         params = load_param_list(os.path.join(path_weights, model_name), order)  # DAE_h.py:52-57
     if out_nonlin not in ('softmax',):
         raise NotImplementedError('inference uses out_nonlin=softmax (iterative_inference.py:158)')

@@ -444,3 +444,18 @@ def bn_relu(buf, n, beta, gamma, mean, inv_std, out=None):
                              _ptr(gamma, dt), _ptr(mean, dt), _ptr(inv_std, dt), _ptr(out, dt)),
           'iiseg_bn_relu')
     return out
+
+
+def bn_affine(x, bnp, window=None):
+    """In place x = (x - mean) * (gamma * inv_std) + beta per channel (stored-average BatchNorm),
+    on the window (y0, x0, h, w) of x's planes or everywhere.  bnp = (beta, gamma, mean, inv_std)."""
+    B, Cc, H, W = x.shape
+    dt = x.dtype
+    y0, x0, wh, ww = window if window is not None else (0, 0, H, W)
+    if wh <= 0 or ww <= 0:
+        return x
+    beta, gamma, mean, inv_std = bnp
+    check(_fn('bn_affine_window', dt)(_stream(), _ptr(x, dt), B, Cc, H, W, y0, x0, wh, ww,
+                                      _ptr(beta, dt), _ptr(gamma, dt), _ptr(mean, dt),
+                                      _ptr(inv_std, dt)), 'iiseg_bn_affine_window')
+    return x

@@ -73,9 +73,18 @@ def make_fcn8_params(nb_in_channels=3, n_classes=11, seed=1234, width_div=1, fc_
     return p
 
 
+def _bn_params(rng, c):
+    """(beta, gamma, mean, inv_std) of a BatchNormLayer; a few negative gammas so that the affine
+    is not monotone in every channel."""
+    gamma = rng.uniform(0.6, 1.4, c).astype(np.float32)
+    gamma[::5] *= -1.0
+    return (rng.uniform(-0.1, 0.1, c).astype(np.float32), gamma,
+            rng.uniform(0.0, 0.3, c).astype(np.float32), rng.uniform(0.7, 1.5, c).astype(np.float32))
+
+
 def make_dae_params(n_classes=11, h_channels=(512,), concat_h=('pool4',), n_filters=64,
                     conv_before_pool=1, additional_pool=2, unpool_type='trackind', seed=4321,
-                    out_gain=4.0):
+                    out_gain=4.0, bn=0):
     """Standard-DAE parameters (models/fcn_down.py:77-136, models/fcn_up.py:26-86).
 
     Channel bookkeeping mirrors the builders: encoder conv p has n_filters*2^min(p,5) filters
@@ -97,6 +106,8 @@ def make_dae_params(n_classes=11, h_channels=(512,), concat_h=('pool4',), n_filt
         for i in range(1, conv_before_pool + 1):
             p['conv%d_%d' % (lvl + 1, i)] = (_he_uniform(rng, (f, cprev, 3, 3), cprev * 9),
                                              _bias(rng, f))
+            if bn:
+                p['conv%d_%d_bn' % (lvl + 1, i)] = _bn_params(rng, f)
             cprev = f
         enc_out.append(f)
         if lvl < n_pool:
@@ -112,6 +123,8 @@ def make_dae_params(n_classes=11, h_channels=(512,), concat_h=('pool4',), n_filt
             gain = out_gain if lvl == 1 else 1.0
             p['up_conv%d' % lvl] = (gain * _he_uniform(rng, (cout, cin, 3, 3), cin * 9),
                                     _bias(rng, cout))
+            if bn:
+                p['up_conv%d_bn' % lvl] = _bn_params(rng, cout)
         cin = cout
     return p
 

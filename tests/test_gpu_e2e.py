@@ -374,6 +374,47 @@ def test_fcn8_kind_dae_session_is_bit_identical(built_lib):
     assert np.array_equal(res[True][1], res[False][1])
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, TOL), (torch.float64, 1e-11)])
+def test_dae_bn1(built_lib, dtype, tol, tmp_path):
+    """dae_dict bn=1: BatchNormLayer with stored averages after every encoder conv (in place,
+    window-aware) and after every linear up_conv (folded into its weights); r, de and a 3-step
+    refinement (windowed encoder after step 1) against the oracle, from an `arr_%d` checkpoint."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import buildDAE, param_order
+    from iterative_inference_segm_amd.weights import save_param_list
+    concat_h = ['pool3']
+    rng = np.random.default_rng(31)
+    size, hc, nf = (36, 44), 6, 8
+    dp = S.make_dae_params(h_channels=(hc,), concat_h=concat_h, n_filters=nf, additional_pool=1,
+                           seed=32, bn=1)
+    order = param_order(concat_h, 1, 1, 'trackind', bn=1)
+    assert [n for n in order if n.endswith('_bn')] and set(order) == set(dp)
+    save_param_list(str(tmp_path / 'dae_model_best.npz'), dp, order)
+    dae = buildDAE(n_classes=11, concat_h=concat_h, n_filters=nf, additional_pool=1, skip=True,
+                   unpool_type='trackind', bn=1, load_weights=True, path_weights=str(tmp_path),
+                   model_name='dae_model_best.npz', dtype=dtype)
+    ii = IterativeInference(None, dae, 11, [11], dtype=dtype)
+    y = rng.random((2, 11) + size); y /= y.sum(1, keepdims=True)
+    h = rng.random((2, hc, (size[0] + 198) // 8, (size[1] + 198) // 8))
+    if dtype == torch.float32:
+        y, h = y.astype(np.float32), h.astype(np.float32)
+    dp64 = to64(dp)
+    dae_fn = lambda hh, yy: odae.dae_forward(dp64, hh, yy, concat_h=concat_h, n_filters=nf,
+                                             additional_pool=1, bn=1)
+    h64, y64 = h.astype(np.float64), y.astype(np.float64)
+    r_ref = dae_fn([h64], y64)
+    assert np.abs(host(ii.pred_dae_fn(h, y)) - r_ref).max() <= tol
+    assert np.abs(host(ii.de_fn(h, y)) - (y64 - r_ref)).max() <= tol
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, [h64], y64, 0.2, 3)
+    Yii, iters, _ = ii.refine([h], y, 0.2, 3)
+    assert list(host(iters)) == list(it_ref)
+    assert np.abs(host(Yii) - yii_ref).max() <= tol
+    # windowed (loop-invariant) encoder == full recomputation, bit for bit
+    dae.licm = False
+    Yfull, _, _ = ii.refine([h], y, 0.2, 3)
+    assert np.array_equal(host(Yfull), host(Yii))
+
+
 def test_unpool_type_standard_and_inverse(built_lib):
     """dae_dict['unpool_type'] knobs: 'standard' = 4x4 stride-2 Deconv2DLayer + crop-sum
     (fcn_up.py:37-63) on the static-tap conv kernel; 'inverse' = InverseLayer of the pool

@@ -123,6 +123,15 @@ def test_checkpoint_roundtrip_in_reference_arr_order(tmp_path):
         assert len(f.files) == 24
     with pytest.raises(ValueError, match='expected'):
         weights.load_param_list(str(tmp_path / 'dae.npz'), order[:-1])
+    # bn=1: every conv is followed by beta, gamma, mean, inv_std (fcn_down.py:112-114)
+    dpb = S.make_dae_params(n_filters=2, h_channels=(4,), bn=1)
+    ob = pdae.param_order(bn=1)
+    assert ob == odae.param_order(bn=1) and ob[1] == 'conv1_1_bn' and ob[-1] == 'up_conv1_bn'
+    weights.save_param_list(str(tmp_path / 'dae_bn.npz'), dpb, ob)
+    with np.load(str(tmp_path / 'dae_bn.npz')) as f:
+        assert len(f.files) == 24 + 12 * 4
+    back = weights.load_param_list(str(tmp_path / 'dae_bn.npz'), ob)
+    assert len(back['conv3_1_bn']) == 4 and np.array_equal(back['conv3_1_bn'][1], dpb['conv3_1_bn'][1])
 
 
 def test_synthetic_data_contract():
