@@ -49,7 +49,7 @@ class StandardDAE:
 
     def __init__(self, params, n_classes, concat_h=('pool4',), padding=100, n_filters=64,
                  conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind', bn=0,
-                 device='cuda', dtype=torch.float32):
+                 device='cuda', dtype=torch.float32, pad_multi_concat=False):
         concat_h = list(concat_h)
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
                    for el in concat_h)                                   # fcn_down.py:39-41
@@ -72,8 +72,10 @@ class StandardDAE:
         for p in range(self.total):
             for i in range(1, conv_before_pool + 1):
                 # pad-100 rule of fcn_down.py:90-94
-                first_pad = (p == 0 and i == 1 and len(concat_h) == 1 and concat_h[-1] != 'input'
-                             and padding > 0)
+                # pad_multi_concat: build-defined generalisation for several concat points
+                # (SURVEY A9', config 5); the reference applies pad-100 only with ONE concat point
+                first_pad = (p == 0 and i == 1 and (len(concat_h) == 1 or pad_multi_concat)
+                             and concat_h[-1] != 'input' and padding > 0)
                 name = 'conv%d_%d' % (p + 1, i)
                 self.enc[name] = ops.Conv(params[name][0], params[name][1],
                                           pad=padding if first_pad else 1, relu=True,

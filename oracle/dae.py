@@ -45,7 +45,7 @@ def _bn_avg(x, bnp):
 
 def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=64,
                 conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind',
-                bn=0, out_softmax=True, return_net=False):
+                bn=0, out_softmax=True, return_net=False, pad_multi_concat=False):
     """pred_dae_fn(h..., y) -> r  (iterative_inference.py:189-190) for dae kind 'standard'.
 
     Deterministic: GaussianNoiseLayer and DropoutLayer are identities (P8, P9) and the
@@ -71,8 +71,10 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
     pre = {}     # input of pool p (post conv/dropout/bn), the `pool2d_layer_in` of DePool2D
     for p in range(total):                                   # fcn_down.py:77
         for i in range(1, conv_before_pool + 1):
-            if p == 0 and i == 1 and len(concat_h) == 1 and concat_h[-1] != 'input' \
-                    and padding > 0:
+            # pad_multi_concat: BUILD-DEFINED generalisation (SURVEY A9', config 5): the pad-100
+            # rule also with several concat points, so that h maps of a pad-100 FCN-8 fit
+            if p == 0 and i == 1 and (len(concat_h) == 1 or pad_multi_concat) \
+                    and concat_h[-1] != 'input' and padding > 0:
                 pad = padding                                # fcn_down.py:90-92
             else:
                 pad = 1                                      # 'same' for 3x3

@@ -1,7 +1,11 @@
 """Times the non-headline BASELINE configs on one MI355X (parity-test cases, not bench lines):
   c3: FC-DenseNet103 + standard DAE (padding 0, h = pool4 464 ch @14^2), 224x224, batch 32, 10 steps
   c2_f64: configs[1] network in the float64 strict-parity mode, batch 16
-Usage: python scripts/bench_configs.py [c3|c2_f64] [reps]"""
+  c4: FCN-8 + standard DAE at 360x480, batch 32 per GPU, 10 steps
+  c5: FCN-8 + generalised standard DAE, concat_h=[pool3, pool4] (256 + 512 ch), pad-100, 50 steps,
+      224x224, batch 64 (SURVEY A9' variant (ii), build-defined)
+  c5ctx: FCN-8 + contextmod DAE with concat_h=[input], 50 steps (A9' variant (i))
+Usage: python scripts/bench_configs.py [c3|c2_f64|c4|c5|c5ctx] [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,7 +15,23 @@ from iterative_inference_segm_amd.dae import StandardDAE
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-if which == 'c3':
+size, steps = (224, 224), 10
+if which in ('c4', 'c5', 'c5ctx'):
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    dt = torch.float32
+    if which == 'c4':
+        B, gflop, size, concat_h = 32, 1867.8, (360, 480), ['pool4']
+        dae = StandardDAE(S.make_dae_params(), 11)
+    elif which == 'c5':
+        B, gflop, steps, concat_h = 64, float('nan'), 50, ['pool3', 'pool4']
+        dae = StandardDAE(S.make_dae_params(h_channels=(256, 512), concat_h=concat_h), 11,
+                          concat_h=concat_h, pad_multi_concat=True)
+    else:
+        from iterative_inference_segm_amd.contextmod import ContextModDAE
+        B, gflop, steps, concat_h = 64, float('nan'), 50, ['input']
+        dae = ContextModDAE(S.make_contextmod_params(), 11)
+    net = FCN8(S.make_fcn8_params(), 11, layer=concat_h + ['probs_dimshuffle'])
+elif which == 'c3':
     from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
     B, dt, gflop = 32, torch.float32, 254.6
     net = FCDenseNet(S.make_densenet_params(layer_plan()), 11, layer=['pool4'])
@@ -22,15 +42,17 @@ else:
     net = FCN8(S.make_fcn8_params(), 11, layer=['pool4', 'probs_dimshuffle'], dtype=dt)
     dae = StandardDAE(S.make_dae_params(), 11, dtype=dt)
 ii = IterativeInference(net, dae, 11, [11], dtype=dt)
-X = torch.from_numpy(S.make_images(B, 224, 224)).to(dt).cuda()
+Xs = [torch.from_numpy(S.make_images(B, size[0], size[1], seed=7 + i)).to(dt).cuda() for i in range(3)]
+state = {'i': 0}
 def step():
+    X = Xs[state['i'] % 3]; state['i'] += 1      # a different image batch every step
     out = ii.pred_fcn_fn(X)
-    ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)
+    ii.refine(out[:-1], out[-1], 0.1, steps, early_stop=False)
 step(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):
     step()
 torch.cuda.synchronize()
 dt_s = (time.perf_counter() - t0) / reps
-print('%s: batch %d, %.1f ms/batch, %.2f images/s, %.1f TFLOP/s nominal' %
-      (which, B, dt_s * 1e3, B / dt_s, B / dt_s * gflop / 1e3), flush=True)
+print('%s: %dx%d, %d steps, batch %d, %.1f ms/batch, %.2f images/s, %.1f TFLOP/s nominal' %
+      (which, size[0], size[1], steps, B, dt_s * 1e3, B / dt_s, B / dt_s * gflop / 1e3), flush=True)

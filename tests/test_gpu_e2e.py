@@ -415,6 +415,44 @@ def test_dae_bn1(built_lib, dtype, tol, tmp_path):
     assert np.array_equal(host(Yfull), host(Yii))
 
 
+def test_multi_concat_standard_dae(built_lib):
+    """Config-5 variant (SURVEY A9', build-defined): standard DAE with h concatenated after pool3
+    AND pool4 (per-concat channel counts), pad-100 applied (`pad_multi_concat`), conv_before_pool=2;
+    FCN-8 -> r, de, 3 refinement steps against the oracle with the same generalisation."""
+    concat_h = ['pool3', 'pool4']
+    fp = S.make_fcn8_params(width_div=16, fc_channels=32, seed=61)
+    hch = (fp['conv3_3'][0].shape[0], fp['conv4_3'][0].shape[0])
+    dp = S.make_dae_params(h_channels=hch, concat_h=concat_h, n_filters=4, conv_before_pool=2,
+                           additional_pool=1, seed=62)
+    ii = build(built_lib, fp, dp, concat_h, 4, conv_before_pool=2, additional_pool=1,
+               pad_multi_concat=True)
+    X = S.make_images(2, 40, 48, seed=63)
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    assert len(H) == 2
+    dp64 = to64(dp)
+    dae_fn = lambda hh, yy: odae.dae_forward(dp64, hh, yy, concat_h=concat_h, n_filters=4,
+                                             conv_before_pool=2, additional_pool=1,
+                                             pad_multi_concat=True)
+    h64 = [host(h).astype(np.float64) for h in H]
+    y64 = host(Y).astype(np.float64)
+    assert np.abs(host(ii.pred_dae_fn(*(H + [Y]))) - dae_fn(h64, y64)).max() <= TOL
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, h64, y64, 0.2, 3)
+    Yii, iters, _ = ii.refine(H, Y, 0.2, 3)
+    assert list(host(iters)) == list(it_ref)
+    assert np.abs(host(Yii) - yii_ref).max() <= TOL
+    # second batch through the reused border stores == from-scratch nets
+    X2 = S.make_images(2, 40, 48, seed=64)
+    out2 = ii.pred_fcn_fn(X2)
+    y_a, _, _ = ii.refine(out2[:-1], out2[-1], 0.2, 3)
+    jj = build(built_lib, fp, dp, concat_h, 4, conv_before_pool=2, additional_pool=1,
+               pad_multi_concat=True)
+    jj.fcn.fold_border = jj.dae.fold_border = False
+    o3 = jj.pred_fcn_fn(X2)
+    y_b, _, _ = jj.refine(o3[:-1], o3[-1], 0.2, 3)
+    assert np.array_equal(host(y_a), host(y_b))
+
+
 def test_unpool_type_standard_and_inverse(built_lib):
     """dae_dict['unpool_type'] knobs: 'standard' = 4x4 stride-2 Deconv2DLayer + crop-sum
     (fcn_up.py:37-63) on the static-tap conv kernel; 'inverse' = InverseLayer of the pool
