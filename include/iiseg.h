@@ -80,6 +80,10 @@ typedef struct iiseg_conv_desc {
      * Used to compute only the part of a decoder level that reaches the final center crop
      * (models/fcn_up.py:104-113) while every tensor keeps its full-size addressing. */
     int32_t out_H, out_W, out_y0, out_x0;
+    /* Winograd path only: parity (0 or 1) of the absolute output row / column at which the 2x2
+     * tiles start.  Must be the same for every launch of a layer whose windows are expected to
+     * agree bit for bit; pick the parity of the most frequent window origin. */
+    int32_t tile_y0, tile_x0;
 } iiseg_conv_desc;
 
 /* Number of int32x4 entries of the gather table for `d` (== d->Kpad). */
@@ -106,8 +110,8 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
  * 3x3, dil 1, stride 1 layers with (C1+C2) % 16 == 0, no IISEG_CONV_UNPOOL / TRANSPOSED2):
  * 2.25x fewer fp32 multiplies on the matrix pipe.  Same descriptor (window, placement, channel
  * slice, add, ReLU; Kpad/Mpad are ignored), results equal to iiseg_conv_f32 up to fp32 rounding,
- * and bit-identical between any two windows of one layer (tiles are anchored at even absolute
- * output coordinates).
+ * and bit-identical between any two windows of one layer launched with the same tile anchor
+ * parity (tile_y0 / tile_x0 of the descriptor).
  *   iiseg_conv_wino_supported      1 if `d` can run on this path, else 0
  *   iiseg_conv_wino_weight_elems   floats of the transformed weights U = G g G^T
  *   iiseg_conv_wino_workspace_elems floats of the caller-owned workspace one call needs

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -24,7 +24,7 @@ class ConvDesc(C.Structure):
                [('flags', C.c_uint32), ('Kpad', C.c_int32), ('Mpad', C.c_int32),
                 ('out_ctot', C.c_int32), ('out_c0', C.c_int32),
                 ('out_H', C.c_int32), ('out_W', C.c_int32), ('out_y0', C.c_int32),
-                ('out_x0', C.c_int32)]
+                ('out_x0', C.c_int32), ('tile_y0', C.c_int32), ('tile_x0', C.c_int32)]
 
 
 class DeconvDesc(C.Structure):

@@ -11,10 +11,12 @@
 //   3. wino_output_kernel  out = relu(A^T M A + bias + add), cropped to the window
 // U = G g G^T is packed once per layer (wino_weight_kernel, computed in double).
 //
-// Tiles are anchored at EVEN ABSOLUTE output coordinates, so a pixel is produced by the same
-// tile, the same 4x4 patch and the same fixed-order sums whatever window of the layer is being
-// computed: windowed / placed launches stay bit-identical to full-map launches (the property the
-// decoder dead-code elimination and the loop-invariant encoder borders rely on).
+// Tiles are anchored at ABSOLUTE output coordinates of a fixed parity (desc.tile_y0 / tile_x0, a
+// per-layer constant chosen by the caller), so a pixel is produced by the same tile, the same 4x4
+// patch and the same fixed-order sums whatever window of the layer is being computed: windowed /
+// placed launches stay bit-identical to full-map launches (the property the decoder dead-code
+// elimination and the loop-invariant encoder borders rely on).  The caller picks the parity of
+// the window it launches most: a 10x10 window at an odd origin is 5x5 tiles instead of 6x6.
 //
 // Replaces the same Lasagne Conv2DLayer(3x3, stride 1) call sites as conv_taps.hip for layers
 // with Cin % 16 == 0 (models/fcn8.py:41-71, models/fcn_down.py:102-104, models/fcn_up.py:83-86);
@@ -42,7 +44,7 @@ struct WinoParams {
     int B, C1, C2, H, W;
     int Cout, pad;
     int oy0, ox0, OH, OW;    // output window in conv-output coordinates
-    int ty0, tx0, nty, ntx;  // tile grid (absolute tile coordinates = output coordinate / 2)
+    int ty0, tx0, nty, ntx;  // first tile's output row / column (absolute), tile counts
     int T, Tpad;             // B*nty*ntx, padded to the GEMM pixel tile
     int Kc, Mpad;            // channels (multiple of 16), output channels padded to the GEMM tile
     int AH, AW, ay0, ax0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     const int b = t / ntt;
     const int r = t - b * ntt;
     const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
-    const int iy0 = 2 * (p.ty0 + tyl) - p.pad, ix0 = 2 * (p.tx0 + txl) - p.pad;
+    const int iy0 = p.ty0 + 2 * tyl - p.pad, ix0 = p.tx0 + 2 * txl - p.pad;
     int rowoff[4];
     bool rok[4], cok[4];
 #pragma unroll
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const Wi
         const int b = t / ntt;
         const int rr = t - b * ntt;
         const int tyl = rr / p.ntx, txl = rr - tyl * p.ntx;
-        const int wy = 2 * (p.ty0 + tyl) - p.oy0, wx = 2 * (p.tx0 + txl) - p.ox0;
+        const int wy = p.ty0 + 2 * tyl - p.oy0, wx = p.tx0 + 2 * txl - p.ox0;
         const bool ok[4] = {(unsigned)wy < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
                             (unsigned)wy < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW,
                             (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     const int b = t / ntt;
     const int r = t - b * ntt;
     const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
-    const int wy = 2 * (p.ty0 + tyl) - p.oy0, wx = 2 * (p.tx0 + txl) - p.ox0;  // window coords
+    const int wy = p.ty0 + 2 * tyl - p.oy0, wx = p.tx0 + 2 * txl - p.ox0;  // window coords
     const bool okr[2] = {(unsigned)wy < (unsigned)p.OH, (unsigned)(wy + 1) < (unsigned)p.OH};
     const bool okc[2] = {(unsigned)wx < (unsigned)p.OW, (unsigned)(wx + 1) < (unsigned)p.OW};
     const size_t xis = (size_t)p.Mpad * p.Tpad;
@@ -542,10 +544,13 @@ int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
     g.Kc = d->C1 + d->C2;
     g.bm = d->Cout > 128 ? 256 : 128;
     g.Mpad = round_up(d->Cout, g.bm);
-    g.ty0 = d->oy0 >> 1;
-    g.tx0 = d->ox0 >> 1;
-    g.nty = ((d->oy0 + d->OH - 1) >> 1) - g.ty0 + 1;
-    g.ntx = ((d->ox0 + d->OW - 1) >> 1) - g.tx0 + 1;
+    // tiles cover output rows r, r+1 with r = tile_y0 (mod 2): the first one is the last such row
+    // at or before the window origin
+    if ((d->tile_y0 | d->tile_x0) & ~1) return IISEG_ERR_SHAPE;
+    g.ty0 = d->oy0 - ((d->oy0 - d->tile_y0) & 1);
+    g.tx0 = d->ox0 - ((d->ox0 - d->tile_x0) & 1);
+    g.nty = (d->oy0 + d->OH - g.ty0 + 1) >> 1;
+    g.ntx = (d->ox0 + d->OW - g.tx0 + 1) >> 1;
     const int64_t T = (int64_t)d->B * g.nty * g.ntx;
     const int64_t Tpad = (T + 127) / 128 * 128;
     // buffer descriptors address one xi-slice of U / V with 32-bit byte offsets

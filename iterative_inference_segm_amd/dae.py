@@ -187,6 +187,7 @@ class StandardDAE:
         # carries the full-size buffers; `dep` is the y-dependent region (y0, x0, h, w) of `t`.
         primed = session is not None and session.get('primed', False) and self.licm
         dep = (0, 0, y.shape[2], y.shape[3])
+        ydep = dep    # the region y alone reaches: its origin parity anchors the Winograd tiles
 
         def clip(lo, hi, size):
             lo, hi = max(lo, 0), min(hi, size)
@@ -196,7 +197,11 @@ class StandardDAE:
             for i in range(1, self.conv_before_pool + 1):
                 name = 'conv%d_%d' % (p + 1, i)
                 conv = self.enc[name]
-                kw = {}
+                fh, fw = conv.out_hw(t.shape[2], t.shape[3])
+                ydep = (clip(ydep[0] + conv.pad - (conv.KH - 1), ydep[0] + ydep[2] + conv.pad, fh) +
+                        clip(ydep[1] + conv.pad - (conv.KW - 1), ydep[1] + ydep[3] + conv.pad, fw))
+                ydep = (ydep[0], ydep[2], ydep[1], ydep[3])
+                kw = dict(anchor=(ydep[0], ydep[1]))
                 if primed and pending_h is not None and h_fresh:
                     # a new batch in a reused session: h changed inside its tagged region
                     hd = session['h_dep'][pos - 1]
@@ -210,7 +215,7 @@ class StandardDAE:
                     wy0, wh = clip(dep[0] + conv.pad - (conv.KH - 1), dep[0] + dep[2] + conv.pad, fh)
                     wx0, ww = clip(dep[1] + conv.pad - (conv.KW - 1), dep[1] + dep[3] + conv.pad, fw)
                     dep = (wy0, wx0, wh, ww)
-                    kw = dict(window=dep, out=buf, place=(wy0, wx0))
+                    kw.update(window=dep, out=buf, place=(wy0, wx0))
                 if pending_h is not None and name in self.hsplit:
                     conv_h, conv_y = self.hsplit[name]
                     keep = session is not None and self.licm
@@ -240,6 +245,9 @@ class StandardDAE:
                     session[name] = t
                 self._count(name, conv, t, computed=(dep[2], dep[3]) if primed else None)
             pre[p + 1] = t
+            ydep = (ydep[0] // 2, ydep[1] // 2,
+                    min((ydep[0] + ydep[2] + 1) // 2, t.shape[2] // 2) - ydep[0] // 2,
+                    min((ydep[1] + ydep[3] + 1) // 2, t.shape[3] // 2) - ydep[1] // 2)
             if primed:
                 buf = session['pool%d' % (p + 1)]
                 qy0, qh = clip(dep[0] // 2, (dep[0] + dep[2] + 1) // 2, buf.shape[2])
@@ -288,16 +296,19 @@ class StandardDAE:
             other = pool[p - 1]                          # pre-concat pool (or the input for p=1)
             oh, ow = min(ph, other.shape[2]), min(pw, other.shape[3])
             geom[p] = (ph, pw, oh, ow, _center(ph, oh), _center(pw, ow))
-        need = {1: (0, 0, geom[1][2], geom[1][3])}       # (y0, x0, h, w) in fused_up_p coords
+        win = {1: (0, 0, geom[1][2], geom[1][3])}        # (y0, x0, h, w) in fused_up_p coords
         for p in range(1, self.total):
             ph, pw, oh, ow, cy, cx = geom[p]
-            y0, x0, nh, nw = need[p] if self.dce else (0, 0, oh, ow)
+            y0, x0, nh, nw = win[p]
             uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)          # unpooled input rows/cols
             uy1, ux1 = min(cy + y0 + nh + 1, ph), min(cx + x0 + nw + 1, pw)
             qh, qw = geom[p + 1][2], geom[p + 1][3]                      # fused_up_{p+1} dims
             ny0, nx0 = uy0 // 2, ux0 // 2
             ny1, nx1 = min((uy1 + 1) // 2, qh), min((ux1 + 1) // 2, qw)
-            need[p + 1] = (ny0, nx0, ny1 - ny0, nx1 - nx0) if self.dce else (0, 0, qh, qw)
+            win[p + 1] = (ny0, nx0, ny1 - ny0, nx1 - nx0)
+        # with DCE off the full maps are computed, but the Winograd tiles stay anchored at the
+        # parity of the DCE windows so that both modes agree bit for bit
+        need = win if self.dce else {p: (0, 0, geom[p][2], geom[p][3]) for p in geom}
         for p in range(self.total, 0, -1):
             name = 'up_conv%d' % p
             conv = self.dec[name]
@@ -323,7 +334,8 @@ class StandardDAE:
             out = None if full else torch.empty((y.shape[0], conv.Cout, oh, ow), dtype=y.dtype,
                                                 device=y.device)
             kw = dict(pre=mpre, pooled=mpool, window=window, out=out,
-                      place=None if full else (y0, x0))
+                      place=None if full else (y0, x0),
+                      anchor=(cy + win[p][0], cx + win[p][1]))
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
                 kw.update(add=other, add_off=(_center(other.shape[2], oh) + y0,
                                               _center(other.shape[3], ow) + x0))

@@ -112,9 +112,10 @@ class FCN8:
                 conv = self.convs[name]
                 fh, fw = conv.out_hw(t.shape[2], t.shape[3])
                 dep = _conv_region(dep, conv, fh, fw)
-                kw = {}
+                # Winograd tiles anchored at the parity of the region recomputed per batch
+                kw = dict(anchor=(dep[0], dep[1]))
                 if primed:
-                    kw = dict(window=dep, out=session[name], place=(dep[0], dep[1]))
+                    kw.update(window=dep, out=session[name], place=(dep[0], dep[1]))
                 if pending is not None:
                     t = self._conv(name, pending, x2=t, **kw)
                     pending = None

@@ -122,8 +122,9 @@ class Conv:
         """Nominal 2*Cin*Cout*k*k*OH*OW*B (SURVEY 6.2 convention)."""
         return 2.0 * self.Cin * self.Cout * self.KH * self.KW * OH * OW * B
 
-    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool, out_slice=None, place=None):
-        key = (B, C1, C2, H, W, window, add_geom, unpool, out_slice, place)
+    def _plan(self, B, C1, C2, H, W, window, add_geom, unpool, out_slice=None, place=None,
+              anchor=(0, 0)):
+        key = (B, C1, C2, H, W, window, add_geom, unpool, out_slice, place, anchor)
         plan = self._plans.get(key)
         if plan is not None:
             return plan
@@ -143,6 +144,7 @@ class Conv:
             d.out_ctot, d.out_c0 = out_slice
         if place is not None:
             d.out_H, d.out_W, d.out_y0, d.out_x0 = place
+        d.tile_y0, d.tile_x0 = int(anchor[0]) & 1, int(anchor[1]) & 1
         so, sc = self.so, self.sc
         if self.via_im2col:
             # logical layer: 1x1 over C*KH*KW channels of the im2col'd tensor (OH x OW)
@@ -167,14 +169,16 @@ class Conv:
         return plan
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
-                 window=None, out=None, out_c0=None, place=None):
+                 window=None, out=None, out_c0=None, place=None, anchor=(0, 0)):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
         `window` = (oy0, ox0, OH, OW) restricts the computed output region.  With `out_c0`
         the result is written into channels [out_c0, out_c0+Cout) of the wider tensor `out`; with
         `place` = (y0, x0) the (OH, OW) result is written at that offset of the larger planes of
-        `out` (everything else in `out` is left untouched)."""
+        `out` (everything else in `out` is left untouched).  `anchor` = parity of the output
+        row / column where the Winograd 2x2 tiles start (a per-layer constant for the caller:
+        launches of one layer agree bit for bit only under the same anchor)."""
         dt = self.dtype
         unpool = pre is not None
         B, C1 = x1.shape[0], x1.shape[1]
@@ -208,7 +212,8 @@ class Conv:
         else:
             out_slice = None if out_c0 is None else (out.shape[1], int(out_c0))
             pl = None if place is None else (out.shape[2], out.shape[3], int(place[0]), int(place[1]))
-            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool, out_slice, pl)
+            d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool, out_slice, pl,
+                                     (int(anchor[0]) & 1, int(anchor[1]) & 1))
         if place is not None:
             if self.via_im2col or out is None or out.shape[0] != B or out.dtype != dt or \
                     (out_c0 is None and out.shape[1] != self.Cout):
@@ -264,7 +269,8 @@ class Conv:
         stages = (1 | fused, 2 | fused) if fused else (1, 2, 4)
         names = ('wino_input_kernel', 'wino_fused_kernel' if fused else 'wino_gemm_kernel',
                  'wino_output_kernel')
-        T = d.B * ((d.oy0 + d.OH + 1) // 2 - d.oy0 // 2) * ((d.ox0 + d.OW + 1) // 2 - d.ox0 // 2)
+        r0, c0 = d.oy0 - ((d.oy0 - d.tile_y0) & 1), d.ox0 - ((d.ox0 - d.tile_x0) & 1)
+        T = d.B * ((d.oy0 + d.OH - r0 + 1) // 2) * ((d.ox0 + d.OW - c0 + 1) // 2)
         gemm_flops = 16 * 2.0 * self.Cin * self.Cout * T      # multiplies actually issued
         for i, stage in enumerate(stages):
             check(lib.iiseg_conv_wino_f32(_stream(), *args, stage), 'iiseg_conv_wino_f32')

@@ -129,13 +129,14 @@ def test_conv_winograd_matches_oracle(ops, case, fused_max, monkeypatch):
     assert np.abs(got - ref).max() <= 4 * conv_tol(ref, Cin * 9)
 
 
+@pytest.mark.parametrize('anchor', [(0, 0), (1, 1), (0, 1)])
 @pytest.mark.parametrize('fused_max', [0, 4096])
-def test_conv_winograd_windows_are_bit_identical(ops, fused_max, monkeypatch):
+def test_conv_winograd_windows_are_bit_identical(ops, fused_max, anchor, monkeypatch):
     monkeypatch.setattr(ops, 'WINO_FUSED_MAX_CIN', fused_max)
-    _winograd_windows(ops)
+    _winograd_windows(ops, anchor)
 
 
-def _winograd_windows(ops):
+def _winograd_windows(ops, anchor):
     """Any window of a layer (odd/even origins, placement into a larger plane, channel slice,
     two-source concat, skip add) gives exactly the values of the full-map launch."""
     rng = np.random.default_rng(77)
@@ -146,7 +147,7 @@ def _winograd_windows(ops):
     add = rnd(rng, B, Cout, OH + 3, OW + 2)
     conv = ops.Conv(w, b, pad=pad, relu=True)
     conv.wino = True
-    full = host(conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2, 1)))
+    full = host(conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2, 1), anchor=anchor))
     direct = ops.Conv(w, b, pad=pad, relu=True)
     direct.wino = False
     ref = host(direct(dev(x1), x2=dev(x2), add=dev(add), add_off=(2, 1)))
@@ -154,11 +155,11 @@ def _winograd_windows(ops):
     for (y0, x0, h, ww) in [(0, 0, OH, OW), (1, 1, 5, 7), (2, 3, 4, 4), (3, 0, OH - 3, 1),
                             (OH - 1, OW - 1, 1, 1), (0, 5, 2, OW - 5)]:
         win = host(conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2 + y0, 1 + x0),
-                        window=(y0, x0, h, ww)))
+                        window=(y0, x0, h, ww), anchor=anchor))
         assert np.array_equal(win, full[:, :, y0:y0 + h, x0:x0 + ww]), (y0, x0, h, ww)
         big = torch.full((B, Cout + 3, OH + 4, OW + 5), -7.0, device='cuda')
         conv(dev(x1), x2=dev(x2), add=dev(add), add_off=(2 + y0, 1 + x0), window=(y0, x0, h, ww),
-             out=big, out_c0=2, place=(y0 + 1, x0 + 2))
+             out=big, out_c0=2, place=(y0 + 1, x0 + 2), anchor=anchor)
         bigh = host(big)
         assert np.array_equal(bigh[:, 2:2 + Cout, y0 + 1:y0 + 1 + h, x0 + 2:x0 + 2 + ww], win)
         bigh[:, 2:2 + Cout, y0 + 1:y0 + 1 + h, x0 + 2:x0 + 2 + ww] = -7.0
