@@ -107,7 +107,9 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
                    const float* bias, const float* add, float* out);
 
 /* Winograd F(2x2,3x3) form of the same convolution (same call sites as iiseg_conv_f32 for
- * 3x3, dil 1, stride 1 layers with (C1+C2) % 16 == 0, no IISEG_CONV_UNPOOL / TRANSPOSED2):
+ * 3x3, dil 1, stride 1 layers with (C1+C2) % 16 == 0, no TRANSPOSED2; with IISEG_CONV_UNPOOL the
+ * DePool2D mask is applied while the input transform loads its 4x4 patches, operands as in
+ * iiseg_conv_f32):
  * 2.25x fewer fp32 multiplies on the matrix pipe.  Same descriptor (window, placement, channel
  * slice, add, ReLU; Kpad/Mpad are ignored), results equal to iiseg_conv_f32 up to fp32 rounding,
  * and bit-identical between any two windows of one layer launched with the same tile anchor
@@ -134,8 +136,8 @@ int64_t iiseg_conv_wino_workspace_elems(const iiseg_conv_desc* d);
 int iiseg_conv_wino_pack_f32(void* stream, const iiseg_conv_desc* d, const float* w,
                              int64_t stride_o, int64_t stride_c, float* U);
 int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
-                        const float* U, const float* bias, const float* add, float* workspace,
-                        float* out, uint32_t stages);
+                        const float* pre, const float* pooled, const float* U, const float* bias,
+                        const float* add, float* workspace, float* out, uint32_t stages);
 
 /* ---------------------------------------------------------------------------------------
  * 2x2/2 max-pool, ignore_border (floor).  Replaces Pool2DLayer(x, 2): models/fcn8.py:38-72,

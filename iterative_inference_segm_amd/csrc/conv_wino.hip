@@ -35,6 +35,9 @@ namespace {
 struct WinoParams {
     const float* x1;
     const float* x2;
+    const float* pre;     // unpool mode: x1 = up, pre, pooled (DePool2D operands)
+    const float* pooled;
+    int h2, w2;
     const float* U;
     const float* bias;
     const float* add;
@@ -93,7 +96,12 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, int64_t so, int6
 
 // ---- 1. input transform ------------------------------------------------------------------------
 // One thread = one tile x ICH channels; lanes run along tiles (coalesced V stores).
+// UNPOOL: the logical input is DePool2D(up = x1, pre, pooled) (layers/mylayers.py:88-115), formed
+// while loading the patch: element (iy, ix) = pre == pooled[iy/2, ix/2] ? up[iy/2, ix/2] : 0 inside
+// the 2h x 2w region, 0 outside.  PY / PX = parity of the patch origin (uniform over a launch), so
+// the 3x3 block of pooled/up values a 4x4 patch touches is indexed at compile time.
 constexpr int ICH = 4;
+template <bool UNPOOL, int PY, int PX>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.T) return;
@@ -110,20 +118,60 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
         cok[i] = (unsigned)(ix0 + i) < (unsigned)p.W;
         rowoff[i] = (iy0 + i) * p.W + ix0;
     }
-    const size_t HW = (size_t)p.H * p.W;
+    // unpool: pooled-plane block rows/cols q = 0..2 cover patch rows (PY + i) >> 1
+    constexpr int NQY = UNPOOL ? (PY ? 3 : 2) : 1, NQX = UNPOOL ? (PX ? 3 : 2) : 1;
+    const int qy0 = (iy0 - PY) >> 1, qx0 = (ix0 - PX) >> 1;   // floor(iy0 / 2) for either parity
+    bool qrok[NQY], qcok[NQX];
+    int qoff[NQY];
+    if constexpr (UNPOOL) {
+#pragma unroll
+        for (int i = 0; i < NQY; ++i) {
+            qrok[i] = (unsigned)(qy0 + i) < (unsigned)p.h2;
+            qoff[i] = (qy0 + i) * p.w2 + qx0;
+        }
+#pragma unroll
+        for (int j = 0; j < NQX; ++j) qcok[j] = (unsigned)(qx0 + j) < (unsigned)p.w2;
+    }
+    const size_t HW = (size_t)p.H * p.W, hw2 = (size_t)p.h2 * p.w2;
     const size_t xis = (size_t)p.Kc * p.Tpad;
     const int c0 = blockIdx.y * ICH;
 #pragma unroll
     for (int cc = 0; cc < ICH; ++cc) {
         const int c = c0 + cc;
         if (c >= p.Kc) break;
-        const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
-                                    : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
         float d[4][4];
+        if constexpr (UNPOOL) {
+            const float* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
+            const float* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
+            const float* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
+            float pq[NQY][NQX], uq[NQY][NQX];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NQY; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = (rok[i] && cok[j]) ? src[rowoff[i] + j] : 0.f;
+                for (int j = 0; j < NQX; ++j) {
+                    const bool ok = qrok[i] && qcok[j];
+                    pq[i][j] = ok ? poolp[qoff[i] + j] : 0.f;
+                    uq[i][j] = ok ? upp[qoff[i] + j] : 0.f;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    constexpr int dummy = 0;
+                    const int qi = (PY + i) >> 1, qj = (PX + j) >> 1;
+                    const bool ok = rok[i] && cok[j] && qrok[qi] && qcok[qj];
+                    const float pv = ok ? prep[rowoff[i] + j] : 0.f;
+                    d[i][j] = (ok && pv == pq[qi][qj]) ? uq[qi][qj] : 0.f;
+                    (void)dummy;
+                }
+        } else {
+            const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
+                                        : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = (rok[i] && cok[j]) ? src[rowoff[i] + j] : 0.f;
+        }
         float e[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // B^T d
@@ -532,9 +580,9 @@ struct WinoGeom {
 
 int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
     if (!d) return IISEG_ERR_NULL;
-    if (d->KH != 3 || d->KW != 3 || d->dil != 1 ||
-        (d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2)))
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2))
         return IISEG_ERR_UNSUPPORTED;
+    if ((d->flags & IISEG_CONV_UNPOOL) && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
     if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
         d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
         return IISEG_ERR_SHAPE;
@@ -542,7 +590,7 @@ int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
     if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
     if ((d->C1 + d->C2) % 16) return IISEG_ERR_UNSUPPORTED;
     g.Kc = d->C1 + d->C2;
-    g.bm = d->Cout > 128 ? 256 : 128;
+    g.bm = d->Cout > 128 ? 256 : (d->Cout > 64 ? 128 : 64);
     g.Mpad = round_up(d->Cout, g.bm);
     // tiles cover output rows r, r+1 with r = tile_y0 (mod 2): the first one is the last such row
     // at or before the window origin
@@ -559,6 +607,19 @@ int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
     g.T = (int)T;
     g.Tpad = (int)Tpad;
     return IISEG_OK;
+}
+
+void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
+    const dim3 grid((p.T + 255) / 256, (p.Kc + ICH - 1) / ICH), block(256);
+    if (!unpool) {
+        hipLaunchKernelGGL((wino_input_kernel<false, 0, 0>), grid, block, 0, s, p);
+        return;
+    }
+    const int py = (p.ty0 - p.pad) & 1, px = (p.tx0 - p.pad) & 1;  // patch-origin parity
+    if (py && px) hipLaunchKernelGGL((wino_input_kernel<true, 1, 1>), grid, block, 0, s, p);
+    else if (py) hipLaunchKernelGGL((wino_input_kernel<true, 1, 0>), grid, block, 0, s, p);
+    else if (px) hipLaunchKernelGGL((wino_input_kernel<true, 0, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((wino_input_kernel<true, 0, 0>), grid, block, 0, s, p);
 }
 
 }  // namespace
@@ -594,7 +655,8 @@ extern "C" int iiseg_conv_wino_pack_f32(void* stream, const iiseg_conv_desc* d, 
 }
 
 extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
-                                   const float* x2, const float* U, const float* bias,
+                                   const float* x2, const float* pre, const float* pooled,
+                                   const float* U, const float* bias,
                                    const float* add, float* workspace, float* out,
                                    uint32_t stages) {
     WinoGeom g;
@@ -602,10 +664,16 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
     if (st) return st;
     if (!x1 || !U || !workspace || !out) return IISEG_ERR_NULL;
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
     if (((uintptr_t)U & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
     WinoParams p;
     p.x1 = x1;
     p.x2 = x2;
+    p.pre = pre;
+    p.pooled = pooled;
+    p.h2 = d->H / 2;
+    p.w2 = d->W / 2;
     p.U = U;
     p.bias = bias;
     p.add = add;
@@ -638,8 +706,14 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         if (g.Kc % 32) return IISEG_ERR_UNSUPPORTED;  // the fused kernel's k-tile is 32 channels
         // input transform, then GEMMs + output transform in one kernel (M stays in registers)
         if (stages & IISEG_WINO_INPUT)
-            hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
+            launch_wino_input(s, p, unpool);
         if (stages & IISEG_WINO_GEMM) {
+            if (g.bm == 64) {   // narrow layers (Cout <= 64): 64-channel tiles, 4 waves of 64 x 32
+                p.n_mtiles = g.Mpad / 64;
+                hipLaunchKernelGGL((wino_fused_kernel<64, 128, 1, 4, 32, 2>),
+                                   dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+                return iiseg_check_launch();
+            }
             p.n_mtiles = g.Mpad / 128;
             // short K loops (<= 128 channels): two independent 4-wave workgroups per CU hide the
             // per-xi fold better than one 8-wave workgroup (scripts/bench_wino.py)
@@ -658,20 +732,25 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         return iiseg_check_launch();
     }
     if (stages & IISEG_WINO_INPUT)
-        hipLaunchKernelGGL(wino_input_kernel, dim3(tb, (g.Kc + ICH - 1) / ICH), dim3(256), 0, s, p);
+        launch_wino_input(s, p, unpool);
     const int grid = 16 * p.n_ttiles * p.n_mtiles;
     if (stages & IISEG_WINO_GEMM) {
         static const int nbuf = getenv("IISEG_WINO_NBUF") ? atoi(getenv("IISEG_WINO_NBUF")) : 2;
         int bm = g.bm;
+        if (bm == 64) {
+            hipLaunchKernelGGL((wino_gemm_kernel<64, 128, 1, 4, 2>), dim3(grid), dim3(256), 0, s, p);
+            bm = 0;
+        }
         if (bm == 256) {
             // few, long 256x128 workgroups quantise badly over 256 CUs: fall back to 128x128
             // tiles (about 6 % less MFMA-efficient) when that fills the last round better
             const int w256 = grid, w128 = 2 * grid;
             if (0.5 * 1.06 * ((w128 + 255) / 256) < (double)((w256 + 255) / 256)) bm = 128;
         }
-        const int grid2 = 16 * p.n_ttiles * (g.Mpad / bm);
-        p.n_mtiles = g.Mpad / bm;
-        if (bm == 256 && nbuf == 3)
+        const int grid2 = bm ? 16 * p.n_ttiles * (g.Mpad / bm) : 0;
+        if (bm) p.n_mtiles = g.Mpad / bm;
+        if (bm == 0) {
+        } else if (bm == 256 && nbuf == 3)
             hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 3>), dim3(grid), dim3(512), 0, s, p);
         else if (bm == 256)
             hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);

@@ -124,9 +124,9 @@ class StandardDAE:
             self.dec[name] = ops.Conv(W, b, pad=1, relu=False, device=device,
                                       dtype=dtype)                                    # fcn_up.py:83-86
         self.conv_log = None
-        # DePool2D fused into the conv's input load or materialised first.  None (auto): fused for
-        # the layers that run on the direct halo-tile kernel (the mask costs 3 loads per PATCH
-        # element there), materialised for the Winograd layers; True / False force either form.
+        # DePool2D fused into the conv's input load (halo kernel: 3 loads per PATCH element;
+        # Winograd: applied by the input transform) or materialised first.  None (auto): fused in
+        # float32, materialised in float64; True / False force either form.
         env = os.environ.get('IISEG_FUSE_UNPOOL', 'auto')
         self.fuse_unpool = None if env == 'auto' else env != '0'
         # compute each decoder level only on the window that reaches the final crop
@@ -321,10 +321,9 @@ class StandardDAE:
                 mpre, mpool = mask_override[p]
             fuse = self.fuse_unpool
             if fuse is None:
-                fuse = conv.dtype == torch.float32 and not conv.wino
+                fuse = conv.dtype == torch.float32
             if not fuse:
-                # materialise DePool2D with the HBM-bound kernel and run the plain conv (Winograd
-                # form for the wide layers)
+                # materialise DePool2D with the HBM-bound kernel and run the plain conv
                 uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)
                 uy1, ux1 = min(cy + y0 + nh + 1, ph), min(cx + x0 + nw + 1, pw)
                 u = torch.empty_like(mpre)

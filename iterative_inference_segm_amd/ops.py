@@ -230,8 +230,9 @@ class Conv:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if self.wino and not unpool and self.lib.iiseg_conv_wino_supported(C.byref(d)):
-            return self._call_wino(d, x1, x2, add, out, prof, ev0 if prof is not None else None)
+        if self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
+            return self._call_wino(d, x1, x2, pre, pooled, add, out, prof,
+                                   ev0 if prof is not None else None)
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
                                           _ptr(pre, dt), _ptr(pooled, dt), _ptr(wp, dt),
@@ -250,7 +251,7 @@ class Conv:
         return out
 
 
-    def _call_wino(self, d, x1, x2, add, out, prof, ev0):
+    def _call_wino(self, d, x1, x2, pre, pooled, add, out, prof, ev0):
         """Winograd F(2x2,3x3) form of the layer (include/iiseg.h, iiseg_conv_wino_f32)."""
         lib = self.lib
         if self._U is None:
@@ -259,8 +260,8 @@ class Conv:
             check(lib.iiseg_conv_wino_pack_f32(_stream(), C.byref(d), _ptr(self.W), self.so, self.sc,
                                                _ptr(self._U)), 'iiseg_conv_wino_pack_f32')
         ws = _wino_workspace(lib.iiseg_conv_wino_workspace_elems(C.byref(d)), x1.device)
-        args = (C.byref(d), _ptr(x1), _ptr(x2), _ptr(self._U), _ptr(self.b), _ptr(add), _ptr(ws),
-                _ptr(out))
+        args = (C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre), _ptr(pooled), _ptr(self._U),
+                _ptr(self.b), _ptr(add), _ptr(ws), _ptr(out))
         fused = 8 if (self.Cin <= WINO_FUSED_MAX_CIN and self.Cin % 32 == 0) else 0
         if prof is None:
             check(lib.iiseg_conv_wino_f32(_stream(), *args, 7 | fused), 'iiseg_conv_wino_f32')

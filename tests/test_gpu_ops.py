@@ -187,6 +187,33 @@ def test_conv_fused_unpool(ops, shape):
     assert np.array_equal(un_gpu, un.astype(np.float32))
 
 
+@pytest.mark.parametrize('fused_max', [0, 4096])
+@pytest.mark.parametrize('shape,cout', [((2, 32, 13, 12), 40), ((1, 64, 9, 7), 64), ((2, 16, 10, 11), 130)])
+def test_conv_winograd_fused_unpool(ops, shape, cout, fused_max, monkeypatch):
+    """DePool2D applied by the Winograd input transform (all four patch-origin parities via
+    windows and tile anchors) == oracle depool + conv == the window of the full launch."""
+    monkeypatch.setattr(ops, 'WINO_FUSED_MAX_CIN', fused_max)
+    B, C, H, W = shape
+    rng = np.random.default_rng(H * 100 + W)
+    pre = np.maximum(rnd(rng, B, C, H, W), 0)
+    pre[:, :, :2, :2] = 0.75
+    pooled = onn.maxpool2(pre)
+    up = rnd(rng, *pooled.shape)
+    Wt, b = rnd(rng, cout, C, 3, 3) / np.sqrt(9 * C), rnd(rng, cout)
+    un = onn.depool_eqmask(up.astype(np.float64), pre.astype(np.float64), pooled.astype(np.float64))
+    ref = onn.conv2d(un, Wt.astype(np.float64), b.astype(np.float64), pad=1)
+    conv = ops.Conv(Wt, b, pad=1, relu=False)
+    conv.wino = True
+    for anchor in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+        full = host(conv(dev(up), pre=dev(pre), pooled=dev(pooled), anchor=anchor))
+        assert conv._U is not None
+        assert np.abs(full - ref).max() <= 4 * conv_tol(ref, 9 * C)
+        for (y0, x0, h, w) in [(1, 2, 5, 4), (2, 1, H - 2, W - 1), (H - 1, W - 1, 1, 1)]:
+            win = host(conv(dev(up), pre=dev(pre), pooled=dev(pooled), window=(y0, x0, h, w),
+                            anchor=anchor))
+            assert np.array_equal(win, full[:, :, y0:y0 + h, x0:x0 + w]), (anchor, y0, x0)
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 9, 7), (3, 2, 211, 13), (1, 1, 2, 2)])
 def test_maxpool_bit_exact(ops, shape):
     rng = np.random.default_rng(11)
