@@ -260,6 +260,205 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
     return iiseg_check_launch();
 }
 
+// ---- 16-channel variant (Cout <= 16: the DAE's last layer, FC-DenseNet's growth-rate-16 convs) ----
+// Same patch staging; the matrix step is v_mfma_f32_16x16x4_f32 (16 output channels x 16 pixels
+// x 4 k), so a layer with 11 or 16 output channels fills 11/16 or 16/16 of the MFMA rows instead of
+// 11/32 or 16/32.  Lane = (pixel n = lane & 15, k sub-step kq = lane >> 4); the accumulation over k
+// is still sequential in k (4 at a time), results agree with the 32-row kernels to fp32 rounding.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int TH, bool UNPOOL>
+__global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParams p, const int tiles_y,
+                                                                 const int tiles_x) {
+    constexpr int BM = 16, CPT = 4, BK = 9 * CPT, NS = BK / 4;
+    constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int PE = CPT * PP, NE = (PE + 255) / 256;
+    constexpr int RW = TH / 4, TN = 2 * RW;     // 16-pixel column tiles per wave
+    constexpr int WVEC = BK * BM / 4;           // 144 float4 per weight tile
+    static_assert(TH % 4 == 0 && WVEC <= 256, "tile config");
+
+    __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Ps[2][NE * 256];
+
+    int pt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
+    const int m0 = mt * BM;
+    const int tpi = tiles_y * tiles_x;
+    const int b = pt / tpi;
+    const int tr = pt - b * tpi;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int wy0 = ty * TH, wx0 = tx * TW;
+    const int iy0 = p.oy0 + wy0 - p.pad, ix0 = p.ox0 + wx0 - p.pad;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int HW = p.H * p.W, hw2 = p.h2 * p.w2;
+    const int C1 = p.C1, Ctot = p.C1 + p.C2;
+
+    unsigned voff[NE], voff2[UNPOOL ? NE : 1];
+    int cl[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = i * 256 + tid;
+        const int c = e / PP, rr = e - c * PP;
+        const int py = rr / PW, px = rr - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        bool ok = e < PE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        cl[i] = c;
+        voff[i] = ok ? 4u * (unsigned)(c * HW + iy * p.W + ix) : OOB;
+        if constexpr (UNPOOL) {
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+            voff2[i] = ok ? 4u * (unsigned)(c * hw2 + (iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+        }
+    }
+    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
+    const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
+    const float* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
+    const float* baseu = UNPOOL ? p.x1 + (size_t)b * C1 * hw2 : nullptr;
+    const int nq = C1 * hw2 * 4;
+
+    f32x4 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+
+    float xv[UNPOOL ? NE : 1], xq[UNPOOL ? NE : 1], xu[UNPOOL ? NE : 1];
+    const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, p.Kpad * p.Mpad * 4);
+    const int wrow = tid / 4, wc4 = tid % 4;
+
+#define H16_LOAD_X(KT, BUF)                                                                        \
+    {                                                                                              \
+        const int c0 = (KT) * CPT;                                                                 \
+        if constexpr (UNPOOL) {                                                                    \
+            const int crem = C1 - c0;                                                              \
+            static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const bool cok = cl[i] < crem;                                                     \
+                const unsigned vo = cok ? voff[i] : OOB, vo2 = cok ? voff2[i] : OOB;               \
+                xv[i] = buf_ld(mk_rsrc(base1, n1), vo, (unsigned)(c0 * HW) * 4u);                  \
+                xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+                xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+            });                                                                                    \
+        } else {                                                                                   \
+            const bool s1 = c0 < C1;                                                               \
+            const int crem = (s1 ? C1 : Ctot) - c0;                                                \
+            const unsigned so = (unsigned)((s1 ? c0 : c0 - C1) * HW) * 4u;                         \
+            static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const unsigned vo = cl[i] < crem ? voff[i] : OOB;                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                          \
+                    mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2),                                     \
+                    (__attribute__((address_space(3))) void*)(&Ps[BUF][i * 256 + wave * 64]), 4,   \
+                    (int)vo, (int)so, 0, 0);                                                       \
+            });                                                                                    \
+        }                                                                                          \
+    }
+#define H16_STORE_X(BUF)                                                                           \
+    if constexpr (UNPOOL) {                                                                        \
+        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            Ps[BUF][i * 256 + tid] = (xv[i] == xq[i]) ? xu[i] : 0.f;                               \
+        });                                                                                        \
+    }
+#define H16_LOAD_W(KT, BUF)                                                                        \
+    if (tid < WVEC)                                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(                                                  \
+            wrsrc, (__attribute__((address_space(3))) void*)(&Ws[BUF][0][0] + wave * 64 * 4), 16,   \
+            (int)(4u * (unsigned)(((KT) * BK + wrow) * p.Mpad + m0 + wc4 * 4)), 0, 0, 0);
+
+    const int nkt = p.Kpad / BK;
+    H16_LOAD_X(0, 0)
+    H16_LOAD_W(0, 0)
+    H16_STORE_X(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // patch offset of this lane's k = 4*s + kq for every k-step s of a k-tile (loop-invariant)
+    int koff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * s + kq;
+        const int c = k / 9, tap = k - 9 * c;
+        koff[s] = c * PP + (tap / 3) * PW + tap % 3;
+    }
+    const int lbase = wave * RW * PW + n;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        float a[2], bq[2][TN];
+        a[0] = Ws[buf][kq][n];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bq[0][j] = Ps[buf][lbase + koff[0] + (j >> 1) * PW + (j & 1) * 16];
+        static_for<0, NS>([&](auto S) __attribute__((always_inline)) {
+            constexpr int st = decltype(S)::value;
+            if constexpr (st + 1 < NS) {
+                a[(st + 1) & 1] = Ws[buf][4 * (st + 1) + kq][n];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bq[(st + 1) & 1][j] = Ps[buf][lbase + koff[st + 1] + (j >> 1) * PW + (j & 1) * 16];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st & 1], bq[st & 1][j], acc[j], 0, 0, 0);
+            if constexpr (st == 0) {
+                if (more) {
+                    H16_LOAD_W(kt + 1, buf ^ 1)
+                    H16_LOAD_X(kt + 1, buf ^ 1)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more) H16_STORE_X(buf ^ 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef H16_LOAD_X
+#undef H16_STORE_X
+#undef H16_LOAD_W
+
+    // C/D layout of the 16x16 MFMA: column = lane & 15 (pixel), row = 4 * (lane >> 4) + r (channel)
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int wy = wy0 + wave * RW + (j >> 1), wx = wx0 + (j & 1) * 16 + n;
+        if (wy >= p.OH || wx >= p.OW) continue;
+        float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                      (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        const float* addp = p.add ? p.add + (size_t)b * p.Cout * APL +
+                                        (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
+                                  : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + 4 * kq + r;
+            if (co < p.Cout) {
+                float v = acc[j][r];
+                if (p.bias) v += p.bias[co];
+                if (addp) v += addp[(size_t)co * APL];
+                if (p.relu) v = fmaxf(v, 0.f);
+                outp[(size_t)co * OPL] = v;
+            }
+        }
+    }
+}
+
+int launch_halo16(hipStream_t s, const ConvParams& cp, bool unpool) {
+    ConvParams p = cp;
+    constexpr int TH = 8;
+    const int tiles_y = (p.OH + TH - 1) / TH, tiles_x = (p.OW + 31) / 32;
+    p.n_ptiles = p.B * tiles_y * tiles_x;
+    p.n_mtiles = (p.Cout + 15) / 16;
+    const int grid = p.n_ptiles * p.n_mtiles;
+    if (unpool)
+        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, true>), dim3(grid), dim3(256), 0, s, p, tiles_y,
+                           tiles_x);
+    else
+        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, false>), dim3(grid), dim3(256), 0, s, p,
+                           tiles_y, tiles_x);
+    return iiseg_check_launch();
+}
+
 }  // namespace
 
 // 1 if the halo kernel can run this (already validated) 3x3 request
@@ -274,6 +473,8 @@ bool iiseg_conv_halo_ok(const ConvParams& p, int KH, int KW) {
 }
 
 int iiseg_launch_conv_halo(hipStream_t s, const ConvParams& p, int bm, bool unpool) {
+    static const int h16 = getenv("IISEG_CONV_HALO16") ? atoi(getenv("IISEG_CONV_HALO16")) : 1;
+    if (h16 && p.Cout <= 16) return launch_halo16(s, p, unpool);
     switch (bm) {
         case 128: return launch_halo<128, 4, 2, 2>(s, p, unpool);
         case 64: return launch_halo<64, 8, 1, 4>(s, p, unpool);
