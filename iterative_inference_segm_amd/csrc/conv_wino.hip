@@ -764,3 +764,140 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
                            p);
     return iiseg_check_launch();
 }
+
+// ================================================================================================
+// im2col + split-K GEMM for 'valid' KxK convolutions with a small output map (FCN-8's fc6: 7x7 over
+// 13x13 -> 7x7, K = 25088): the table-driven gather of conv_igemm.hip tops out at 78 TFLOP/s there,
+// the gather-free GEMM kernel above runs at 125-134.  The S split-K slices ride on the kernel's
+// batch index (slice s = rows [s*Kc, (s+1)*Kc) of Wp and of the im2col matrix, contiguous in both),
+// so that S * tiles fills the 256 CUs evenly; the output kernel sums the S partial products in a
+// fixed order, adds bias, applies ReLU and writes NCHW.
+// ================================================================================================
+namespace {
+
+struct GemmConvGeom {
+    int K, Kpad, Mpad, bm, T, Tpad, S, Kc;
+};
+
+__global__ __launch_bounds__(256) void gemm_im2col_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ V, int B, int C, int H,
+                                                          int W, int KH, int KW, int OH, int OW, int K,
+                                                          int Kpad, int T, int Tpad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int OHW = OH * OW;
+    const int b = t / OHW, r = t - b * OHW;
+    const int oy = r / OW, ox = r - oy * OW;
+    const int KK = KH * KW;
+    const float* xb = x + (size_t)b * C * H * W + (size_t)oy * W + ox;
+    for (int k = blockIdx.y; k < Kpad; k += gridDim.y) {
+        float v = 0.f;
+        if (k < K) {
+            const int c = k / KK, tap = k - c * KK;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            v = xb[(size_t)c * H * W + ky * W + kx];
+        }
+        V[(size_t)k * Tpad + t] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_output_kernel(const float* __restrict__ M,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ out, int Cout, int OHW,
+                                                          int T, int Tpad, int Mpad, int S, int relu) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int b = t / OHW, px = t - b * OHW;
+    const size_t ss = (size_t)Mpad * Tpad;
+    for (int co = blockIdx.y; co < Cout; co += gridDim.y) {
+        const float* m = M + (size_t)co * Tpad + t;
+        float v = m[0];
+        for (int s = 1; s < S; ++s) v += m[(size_t)s * ss];   // fixed order: deterministic
+        if (bias) v += bias[co];
+        if (relu) v = fmaxf(v, 0.f);
+        out[((size_t)b * Cout + co) * OHW + px] = v;
+    }
+}
+
+int gemm_conv_geom(const iiseg_conv_desc* d, GemmConvGeom& g) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->pad != 0 || d->dil != 1 || d->C2 != 0 ||
+        (d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2)))
+        return IISEG_ERR_UNSUPPORTED;
+    const int fullH = d->H - d->KH + 1, fullW = d->W - d->KW + 1;
+    if (fullH <= 0 || fullW <= 0) return IISEG_ERR_SHAPE;
+    // full, dense output only
+    if (d->oy0 != 0 || d->ox0 != 0 || d->OH != fullH || d->OW != fullW || d->out_ctot != 0 ||
+        d->out_H != 0)
+        return IISEG_ERR_UNSUPPORTED;
+    g.K = d->C1 * d->KH * d->KW;
+    g.Kpad = d->Kpad;
+    g.Mpad = d->Mpad;
+    if (g.Kpad < g.K || g.Kpad % 16 || g.Mpad % 128 || g.Mpad < d->Cout) return IISEG_ERR_UNSUPPORTED;
+    g.bm = g.Mpad % 256 == 0 ? 256 : 128;
+    const int64_t T = (int64_t)d->B * fullH * fullW;
+    const int64_t Tpad = (T + 127) / 128 * 128;
+    if (Tpad * g.Kpad * 4 >= (int64_t)1 << 31 || (int64_t)g.Kpad * g.Mpad * 4 >= (int64_t)1 << 31)
+        return IISEG_ERR_UNSUPPORTED;
+    g.T = (int)T;
+    g.Tpad = (int)Tpad;
+    // split-K: the divisor S of Kpad/16 (<= 16) that wastes the least of the last round of 256 CUs
+    const int tiles = (g.Tpad / 128) * (g.Mpad / g.bm), units = g.Kpad / 16;
+    double best = 1e30;
+    g.S = 1;
+    for (int S = 1; S <= 16; ++S) {
+        if (units % S || units / S < 8) continue;
+        const double cost = (double)((S * tiles + 255) / 256) / S + 0.002 * S;  // + reduce traffic
+        if (cost < best) { best = cost; g.S = S; }
+    }
+    g.Kc = g.Kpad / g.S;
+    return IISEG_OK;
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_gemm_supported(const iiseg_conv_desc* d) {
+    GemmConvGeom g;
+    return gemm_conv_geom(d, g) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int64_t iiseg_conv_gemm_workspace_elems(const iiseg_conv_desc* d) {
+    GemmConvGeom g;
+    if (gemm_conv_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)g.Tpad * ((int64_t)g.Kpad + (int64_t)g.S * g.Mpad);
+}
+
+extern "C" int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const float* x,
+                                   const float* wp, const float* bias, float* workspace,
+                                   float* out) {
+    GemmConvGeom g;
+    const int st = gemm_conv_geom(d, g);
+    if (st) return st;
+    if (!x || !wp || !workspace || !out) return IISEG_ERR_NULL;
+    if (((uintptr_t)wp & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    float* V = workspace;
+    float* M = workspace + (size_t)g.Kpad * g.Tpad;
+    const int OH = d->OH, OW = d->OW, tb = (g.T + 255) / 256;
+    hipLaunchKernelGGL(gemm_im2col_kernel, dim3(tb, g.Kpad < 1024 ? g.Kpad : 1024), dim3(256), 0, s, x,
+                       V, d->B, d->C1, d->H, d->W, d->KH, d->KW, OH, OW, g.K, g.Kpad, g.T, g.Tpad);
+    WinoParams p = {};
+    p.U = wp;
+    p.V = V;
+    p.M = M;
+    p.Kc = g.Kc;
+    p.Mpad = g.Mpad;
+    p.Tpad = g.Tpad;
+    p.T = g.T;
+    p.n_ttiles = g.Tpad / 128;
+    p.n_mtiles = g.Mpad / g.bm;
+    const int grid = g.S * p.n_ttiles * p.n_mtiles;
+    if (g.bm == 256)
+        hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
+    else
+        hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+    const int cy = d->Cout < 1024 ? d->Cout : 1024;
+    hipLaunchKernelGGL(gemm_output_kernel, dim3(tb, cy), dim3(256), 0, s, M, bias, out, d->Cout,
+                       OH * OW, g.T, g.Tpad, g.Mpad, g.S, (d->flags & IISEG_CONV_RELU) ? 1 : 0);
+    return iiseg_check_launch();
+}

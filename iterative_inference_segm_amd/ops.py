@@ -28,6 +28,8 @@ WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
 # transform (products stay in registers, no M round trip through HBM); deeper layers are
 # MFMA-bound and run faster on the plain 256x128 GEMM + separate output transform.  0: never.
 WINO_FUSED_MAX_CIN = int(os.environ.get('IISEG_WINO_FUSED_MAX_CIN', '256'))
+# 'valid' KxK layers without a static-tap variant (7x7 fc6) as im2col + split-K GEMM
+CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
 
 
@@ -233,6 +235,16 @@ class Conv:
         if self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof,
                                    ev0 if prof is not None else None)
+        if self.kernel == 'conv_igemm_f32_kernel' and CONV_GEMM and x2 is None and not unpool and \
+                add is None and self.lib.iiseg_conv_gemm_supported(C.byref(d)):
+            ws = _wino_workspace(self.lib.iiseg_conv_gemm_workspace_elems(C.byref(d)), x1.device)
+            check(self.lib.iiseg_conv_gemm_f32(_stream(), C.byref(d), _ptr(x1), _ptr(wp), _ptr(self.b),
+                                               _ptr(ws), _ptr(out)), 'iiseg_conv_gemm_f32')
+            if prof is not None:
+                ev1.record()
+                prof.append(('conv_gemm (im2col + wino_gemm_kernel)', self.flops(B, d.OH, d.OW),
+                             ev0, ev1))
+            return out
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
                                           _ptr(pre, dt), _ptr(pooled, dt), _ptr(wp, dt),
