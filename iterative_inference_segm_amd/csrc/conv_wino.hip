@@ -191,6 +191,104 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     }
 }
 
+
+// LDS-staged input transform for maps with >= 128 tiles per image: a workgroup takes 256
+// consecutive tiles of ONE image, stages the input rows they touch (whole rows of the tile grid:
+// coalesced loads, ~1.3 loads per tile and channel instead of 16; the DePool2D mask is applied per
+// staged element, 3 loads instead of 34 per tile) and every thread reads its 4x4 patch from LDS.
+constexpr int ILDS_CAP = 3072, ILDS_E = ILDS_CAP / 256, ILDS_CH = 8;
+template <bool UNPOOL>
+__global__ __launch_bounds__(256) void wino_input_lds_kernel(const WinoParams p, const int chunks) {
+    __shared__ __attribute__((aligned(16))) float Ls[2][ILDS_CAP];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int ntt = p.nty * p.ntx;
+    const int tl0 = chunk * 256, tl = tl0 + tid;
+    const bool tvalid = tl < ntt;
+    const int row_first = tl0 / p.ntx;
+    const int row_last = min(ntt - 1, tl0 + 255) / p.ntx;
+    const int NR = 2 * (row_last - row_first + 1) + 2, NC = 2 * p.ntx + 2, NE = NR * NC;
+    const int iyb = p.ty0 + 2 * row_first - p.pad, ixb = p.tx0 - p.pad;
+    int goff[ILDS_E], qoff[UNPOOL ? ILDS_E : 1];
+#pragma unroll
+    for (int i = 0; i < ILDS_E; ++i) {
+        const int e = i * 256 + tid;
+        const int r = e / NC, c = e - r * NC;
+        const int iy = iyb + r, ix = ixb + c;
+        bool ok = e < NE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        goff[i] = ok ? iy * p.W + ix : -1;
+        if constexpr (UNPOOL) {
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+            qoff[i] = ok ? (iy >> 1) * p.w2 + (ix >> 1) : -1;
+        }
+    }
+    const int tyl = tl / p.ntx, txl = tl - tyl * p.ntx;
+    const int lbase = 2 * (tyl - row_first) * NC + 2 * txl;
+    const size_t HW = (size_t)p.H * p.W, hw2 = (size_t)p.h2 * p.w2;
+    const size_t xis = (size_t)p.Kc * p.Tpad;
+    const int t = b * ntt + tl;
+    const int c0 = blockIdx.y * ILDS_CH;
+    float v[ILDS_E];
+
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+        if constexpr (UNPOOL) {
+            const float* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
+            const float* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
+            const float* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
+#pragma unroll
+            for (int i = 0; i < ILDS_E; ++i) {
+                float r = 0.f;
+                if (qoff[i] >= 0) {
+                    const float pv = prep[goff[i]], pq = poolp[qoff[i]], uq = upp[qoff[i]];
+                    r = pv == pq ? uq : 0.f;
+                }
+                v[i] = r;
+            }
+        } else {
+            const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
+                                        : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+#pragma unroll
+            for (int i = 0; i < ILDS_E; ++i) v[i] = goff[i] >= 0 ? src[goff[i]] : 0.f;
+        }
+    };
+
+    fetch(c0);
+    for (int cc = 0; cc < ILDS_CH; ++cc) {
+        const int c = c0 + cc;   // Kc is a multiple of 16: always a real (possibly zero-weight) channel
+        float* L = Ls[cc & 1];
+#pragma unroll
+        for (int i = 0; i < ILDS_E; ++i)
+            if (i * 256 + tid < NE) L[i * 256 + tid] = v[i];
+        if (cc + 1 < ILDS_CH) fetch(c + 1);
+        __syncthreads();
+        if (tvalid) {
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 lo = *reinterpret_cast<const float2*>(L + lbase + i * NC);
+                const float2 hi = *reinterpret_cast<const float2*>(L + lbase + i * NC + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
+            float e[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // B^T d
+                e[0][j] = d[0][j] - d[2][j];
+                e[1][j] = d[1][j] + d[2][j];
+                e[2][j] = d[2][j] - d[1][j];
+                e[3][j] = d[1][j] - d[3][j];
+            }
+            float* vo = p.V + (size_t)c * p.Tpad + t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // (B^T d) B
+                vo[(size_t)(i * 4 + 0) * xis] = e[i][0] - e[i][2];
+                vo[(size_t)(i * 4 + 1) * xis] = e[i][1] + e[i][2];
+                vo[(size_t)(i * 4 + 2) * xis] = e[i][2] - e[i][1];
+                vo[(size_t)(i * 4 + 3) * xis] = e[i][1] - e[i][3];
+            }
+        }
+    }
+}
+
 // ---- 2. the 16 GEMMs ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoParams p) {
@@ -610,6 +708,20 @@ int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
 }
 
 void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
+    static const int lds = getenv("IISEG_WINO_INPUT_LDS") ? atoi(getenv("IISEG_WINO_INPUT_LDS")) : 1;
+    const int ntt = p.nty * p.ntx;
+    // rows of the tile grid a 256-tile chunk can span, and the staged region they need
+    const int span = (255 + p.ntx - 1) / p.ntx + 1;
+    const int rows = span < p.nty ? span : p.nty;
+    if (lds && ntt >= 128 && (2 * rows + 2) * (2 * p.ntx + 2) <= ILDS_CAP && p.Kc % ILDS_CH == 0) {
+        const int chunks = (ntt + 255) / 256;
+        const dim3 g2(p.B * chunks, p.Kc / ILDS_CH);
+        if (unpool)
+            hipLaunchKernelGGL((wino_input_lds_kernel<true>), g2, dim3(256), 0, s, p, chunks);
+        else
+            hipLaunchKernelGGL((wino_input_lds_kernel<false>), g2, dim3(256), 0, s, p, chunks);
+        return;
+    }
     const dim3 grid((p.T + 255) / 256, (p.Kc + ICH - 1) / ICH), block(256);
     if (!unpool) {
         hipLaunchKernelGGL((wino_input_kernel<false, 0, 0>), grid, block, 0, s, p);
