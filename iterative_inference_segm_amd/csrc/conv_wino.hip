@@ -196,23 +196,24 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
 // consecutive tiles of ONE image, stages the input rows they touch (whole rows of the tile grid:
 // coalesced loads, ~1.3 loads per tile and channel instead of 16; the DePool2D mask is applied per
 // staged element, 3 loads instead of 34 per tile) and every thread reads its 4x4 patch from LDS.
-constexpr int ILDS_CAP = 3072, ILDS_E = ILDS_CAP / 256, ILDS_CH = 8;
-template <bool UNPOOL>
-__global__ __launch_bounds__(256) void wino_input_lds_kernel(const WinoParams p, const int chunks) {
+constexpr int ILDS_E = 12, ILDS_CH = 8;   // staged elements per thread, channels per workgroup
+template <bool UNPOOL, int NT>
+__global__ __launch_bounds__(NT) void wino_input_lds_kernel(const WinoParams p, const int chunks) {
+    constexpr int ILDS_CAP = ILDS_E * NT;
     __shared__ __attribute__((aligned(16))) float Ls[2][ILDS_CAP];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
     const int ntt = p.nty * p.ntx;
-    const int tl0 = chunk * 256, tl = tl0 + tid;
+    const int tl0 = chunk * NT, tl = tl0 + tid;
     const bool tvalid = tl < ntt;
     const int row_first = tl0 / p.ntx;
-    const int row_last = min(ntt - 1, tl0 + 255) / p.ntx;
+    const int row_last = min(ntt - 1, tl0 + NT - 1) / p.ntx;
     const int NR = 2 * (row_last - row_first + 1) + 2, NC = 2 * p.ntx + 2, NE = NR * NC;
     const int iyb = p.ty0 + 2 * row_first - p.pad, ixb = p.tx0 - p.pad;
     int goff[ILDS_E], qoff[UNPOOL ? ILDS_E : 1];
 #pragma unroll
     for (int i = 0; i < ILDS_E; ++i) {
-        const int e = i * 256 + tid;
+        const int e = i * NT + tid;
         const int r = e / NC, c = e - r * NC;
         const int iy = iyb + r, ix = ixb + c;
         bool ok = e < NE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void wino_input_lds_kernel(const WinoParams p,
         float* L = Ls[cc & 1];
 #pragma unroll
         for (int i = 0; i < ILDS_E; ++i)
-            if (i * 256 + tid < NE) L[i * 256 + tid] = v[i];
+            if (i * NT + tid < NE) L[i * NT + tid] = v[i];
         if (cc + 1 < ILDS_CH) fetch(c + 1);
         __syncthreads();
         if (tvalid) {
@@ -710,16 +711,24 @@ int wino_geom(const iiseg_conv_desc* d, WinoGeom& g) {
 void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
     static const int lds = getenv("IISEG_WINO_INPUT_LDS") ? atoi(getenv("IISEG_WINO_INPUT_LDS")) : 1;
     const int ntt = p.nty * p.ntx;
-    // rows of the tile grid a 256-tile chunk can span, and the staged region they need
-    const int span = (255 + p.ntx - 1) / p.ntx + 1;
-    const int rows = span < p.nty ? span : p.nty;
-    if (lds && ntt >= 128 && (2 * rows + 2) * (2 * p.ntx + 2) <= ILDS_CAP && p.Kc % ILDS_CH == 0) {
-        const int chunks = (ntt + 255) / 256;
+    // tiles per workgroup (one image per workgroup): the size that leaves the fewest idle lanes
+    int nt = 0;
+    double best = 0.0;
+    for (int cand = 256; cand >= 128; cand >>= 1) {
+        // rows of the tile grid a chunk can span, and the staged region they need
+        const int span = (cand - 1 + p.ntx - 1) / p.ntx + 1;
+        const int rows = span < p.nty ? span : p.nty;
+        if ((2 * rows + 2) * (2 * p.ntx + 2) > ILDS_E * cand) continue;
+        const double util = (double)ntt / (((ntt + cand - 1) / cand) * cand);
+        if (util > best + 0.02) { best = util; nt = cand; }
+    }
+    if (lds && nt && best >= 0.8 && p.Kc % ILDS_CH == 0) {
+        const int chunks = (ntt + nt - 1) / nt;
         const dim3 g2(p.B * chunks, p.Kc / ILDS_CH);
-        if (unpool)
-            hipLaunchKernelGGL((wino_input_lds_kernel<true>), g2, dim3(256), 0, s, p, chunks);
-        else
-            hipLaunchKernelGGL((wino_input_lds_kernel<false>), g2, dim3(256), 0, s, p, chunks);
+#define WINO_ILDS(U, N) hipLaunchKernelGGL((wino_input_lds_kernel<U, N>), g2, dim3(N), 0, s, p, chunks)
+        if (unpool) { if (nt == 256) WINO_ILDS(true, 256); else if (nt == 128) WINO_ILDS(true, 128); else WINO_ILDS(true, 64); }
+        else { if (nt == 256) WINO_ILDS(false, 256); else if (nt == 128) WINO_ILDS(false, 128); else WINO_ILDS(false, 64); }
+#undef WINO_ILDS
         return;
     }
     const dim3 grid((p.T + 255) / 256, (p.Kc + ICH - 1) / ICH), block(256);
