@@ -142,11 +142,12 @@ int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,
  * d->Mpad from iiseg_conv_plan), the gather-free MFMA GEMM kernel of the Winograd path, partial
- * sums of the K slices added in a fixed order.  workspace: iiseg_conv_gemm_workspace_elems floats. */
+ * sums of the K slices added in a fixed order.  workspace: iiseg_conv_gemm_workspace_elems floats;
+ * stages: IISEG_WINO_INPUT (im2col) | IISEG_WINO_GEMM | IISEG_WINO_OUTPUT, IISEG_WINO_ALL normally. */
 int iiseg_conv_gemm_supported(const iiseg_conv_desc* d);
 int64_t iiseg_conv_gemm_workspace_elems(const iiseg_conv_desc* d);
 int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const float* x, const float* wp,
-                        const float* bias, float* workspace, float* out);
+                        const float* bias, float* workspace, float* out, uint32_t stages);
 
 /* ---------------------------------------------------------------------------------------
  * 2x2/2 max-pool, ignore_border (floor).  Replaces Pool2DLayer(x, 2): models/fcn8.py:38-72,

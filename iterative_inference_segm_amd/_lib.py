@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -52,7 +52,7 @@ SIGNATURES = {
     'iiseg_conv_wino_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9 + [C.c_uint32]),
     'iiseg_conv_gemm_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
-    'iiseg_conv_gemm_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5),
+    'iiseg_conv_gemm_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5 + [C.c_uint32]),
     'iiseg_maxpool2x2_f32': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
     'iiseg_unpool_eqmask_f32': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]),
     'iiseg_maxpool2x2_window_f32': (C.c_int, [_vp] * 3 + [_i32] * 7),

@@ -990,7 +990,7 @@ extern "C" int64_t iiseg_conv_gemm_workspace_elems(const iiseg_conv_desc* d) {
 
 extern "C" int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const float* x,
                                    const float* wp, const float* bias, float* workspace,
-                                   float* out) {
+                                   float* out, uint32_t stages) {
     GemmConvGeom g;
     const int st = gemm_conv_geom(d, g);
     if (st) return st;
@@ -1000,8 +1000,10 @@ extern "C" int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const
     float* V = workspace;
     float* M = workspace + (size_t)g.Kpad * g.Tpad;
     const int OH = d->OH, OW = d->OW, tb = (g.T + 255) / 256;
-    hipLaunchKernelGGL(gemm_im2col_kernel, dim3(tb, g.Kpad < 1024 ? g.Kpad : 1024), dim3(256), 0, s, x,
-                       V, d->B, d->C1, d->H, d->W, d->KH, d->KW, OH, OW, g.K, g.Kpad, g.T, g.Tpad);
+    if (stages & IISEG_WINO_INPUT)
+        hipLaunchKernelGGL(gemm_im2col_kernel, dim3(tb, g.Kpad < 1024 ? g.Kpad : 1024), dim3(256), 0,
+                           s, x, V, d->B, d->C1, d->H, d->W, d->KH, d->KW, OH, OW, g.K, g.Kpad, g.T,
+                           g.Tpad);
     WinoParams p = {};
     p.U = wp;
     p.V = V;
@@ -1013,12 +1015,15 @@ extern "C" int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const
     p.n_ttiles = g.Tpad / 128;
     p.n_mtiles = g.Mpad / g.bm;
     const int grid = g.S * p.n_ttiles * p.n_mtiles;
-    if (g.bm == 256)
-        hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
-    else
-        hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+    if (stages & IISEG_WINO_GEMM) {
+        if (g.bm == 256)
+            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
+        else
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+    }
     const int cy = d->Cout < 1024 ? d->Cout : 1024;
-    hipLaunchKernelGGL(gemm_output_kernel, dim3(tb, cy), dim3(256), 0, s, M, bias, out, d->Cout,
-                       OH * OW, g.T, g.Tpad, g.Mpad, g.S, (d->flags & IISEG_CONV_RELU) ? 1 : 0);
+    if (stages & IISEG_WINO_OUTPUT)
+        hipLaunchKernelGGL(gemm_output_kernel, dim3(tb, cy), dim3(256), 0, s, M, bias, out, d->Cout,
+                           OH * OW, g.T, g.Tpad, g.Mpad, g.S, (d->flags & IISEG_CONV_RELU) ? 1 : 0);
     return iiseg_check_launch();
 }

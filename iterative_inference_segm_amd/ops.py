@@ -238,12 +238,17 @@ class Conv:
         if self.kernel == 'conv_igemm_f32_kernel' and CONV_GEMM and x2 is None and not unpool and \
                 add is None and self.lib.iiseg_conv_gemm_supported(C.byref(d)):
             ws = _wino_workspace(self.lib.iiseg_conv_gemm_workspace_elems(C.byref(d)), x1.device)
-            check(self.lib.iiseg_conv_gemm_f32(_stream(), C.byref(d), _ptr(x1), _ptr(wp), _ptr(self.b),
-                                               _ptr(ws), _ptr(out)), 'iiseg_conv_gemm_f32')
-            if prof is not None:
+            args = (C.byref(d), _ptr(x1), _ptr(wp), _ptr(self.b), _ptr(ws), _ptr(out))
+            if prof is None:
+                check(self.lib.iiseg_conv_gemm_f32(_stream(), *args, 7), 'iiseg_conv_gemm_f32')
+                return out
+            names = ('gemm_im2col_kernel', 'wino_gemm_kernel', 'gemm_output_kernel')
+            for i, stage in enumerate((1, 2, 4)):        # the three kernels separately
+                check(self.lib.iiseg_conv_gemm_f32(_stream(), *args, stage), 'iiseg_conv_gemm_f32')
+                ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                prof.append(('conv_gemm (im2col + wino_gemm_kernel)', self.flops(B, d.OH, d.OW),
-                             ev0, ev1))
+                prof.append((names[i], self.flops(B, d.OH, d.OW) if i == 1 else 0.0, ev0, ev1))
+                ev0 = ev1
             return out
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),

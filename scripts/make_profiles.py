@@ -1,6 +1,7 @@
 """Turn rocprofv3 outputs (CSV) into the summaries committed under profiles/.
 
   python scripts/make_profiles.py stats <dir with *kernel_trace.csv> <out.csv>
+  python scripts/make_profiles.py steady <dir with *kernel_trace.csv> <out.csv>   (first batch dropped)
   python scripts/make_profiles.py pmc <fetch dir> <write dir> <out.md>
 
 PMC units follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE count KiB; on gfx950
@@ -28,9 +29,22 @@ def find(d, pat):
     return f[0]
 
 
-def stats(d, out):
+def stats(d, out, steady=False):
+    """steady=True drops the first batch of the run (every dispatch up to the second
+    confusion_kernel = the end of batch 1): that batch computes the weights-only borders in full and
+    packs the weights, so it is not what bench.py's timed steps (and its roofline leg) run."""
+    rows = sorted(csv.DictReader(open(find(d, 'kernel_trace.csv'))),
+                  key=lambda r: int(r['Start_Timestamp']))
+    if steady:
+        seen = 0
+        for i, r in enumerate(rows):
+            if 'confusion_kernel' in r['Kernel_Name']:
+                seen += 1
+                if seen == 2:
+                    rows = rows[i + 1:]
+                    break
     per = collections.OrderedDict()
-    for r in csv.DictReader(open(find(d, 'kernel_trace.csv'))):
+    for r in rows:
         e = per.setdefault(short(r['Kernel_Name']), [0, 0.0])
         e[0] += 1
         e[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
@@ -76,5 +90,7 @@ def pmc(fd, wd, out):
 if __name__ == '__main__':
     if sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == 'steady':
+        stats(sys.argv[2], sys.argv[3], steady=True)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
