@@ -225,21 +225,31 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
         if (wy >= p.OH) continue;
         float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
                       (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-        const float* addp = p.add ? p.add + (size_t)b * p.Cout * APL +
-                                        (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
-                                  : nullptr;
+        // skip-add / bias values first, all loads in flight together (unconditional, channel index
+        // clamped), then the stores: out and add may alias as far as the compiler knows, so loads
+        // interleaved with stores would serialise into one round trip each
+        float addv[TM][16];
+        if (p.add) {
+            const float* addp = p.add + (size_t)b * p.Cout * APL + (size_t)(p.ay0 + wy) * p.AW +
+                                p.ax0 + wx;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    addv[i][r] = addp[(size_t)min(co, p.Cout - 1) * APL];
+                }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < p.Cout) {
-                    float v = acc[i][j][r];
-                    if (p.bias) v += p.bias[co];
-                    if (addp) v += addp[(size_t)co * APL];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    outp[(size_t)co * OPL] = v;
-                }
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[min(co, p.Cout - 1)];
+                if (p.add) v += addv[i][r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (co < p.Cout) outp[(size_t)co * OPL] = v;
             }
     }
 }

@@ -635,35 +635,53 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoParams p) {
     const size_t xis = (size_t)p.Mpad * p.Tpad;
     const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
     const int co0 = blockIdx.y * OCH;
+    // All loads of the thread's OCH channels first (M, skip-add; channel index clamped instead of
+    // branching), then the stores: `out` may alias `M` / `add` as far as the compiler knows, so
+    // loads placed after a store could not be moved up and every channel would be a round trip.
+    float mv[OCH][16], av[OCH][4];
+#pragma unroll
+    for (int cc = 0; cc < OCH; ++cc) {
+        const int co = min(co0 + cc, p.Cout - 1);
+        const float* m = p.M + (size_t)co * p.Tpad + t;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) mv[cc][x] = m[(size_t)x * xis];
+        if (p.add) {
+            const float* ad = p.add + ((size_t)b * p.Cout + co) * APL;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = okr[i] && okc[j];
+                    const ptrdiff_t idx = (ptrdiff_t)(p.ay0 + wy + i) * p.AW + p.ax0 + wx + j;
+                    const float a = ad[ok ? idx : 0];
+                    av[cc][i * 2 + j] = ok ? a : 0.f;
+                }
+        }
+    }
 #pragma unroll
     for (int cc = 0; cc < OCH; ++cc) {
         const int co = co0 + cc;
         if (co >= p.Cout) break;
-        const float* m = p.M + (size_t)co * p.Tpad + t;
-        float s[2][4];
+        float s2[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // A^T m
-            const float m0 = m[(size_t)j * xis], m1 = m[(size_t)(4 + j) * xis],
-                        m2 = m[(size_t)(8 + j) * xis], m3 = m[(size_t)(12 + j) * xis];
-            s[0][j] = m0 + m1 + m2;
-            s[1][j] = m1 - m2 - m3;
+            const float m0 = mv[cc][j], m1 = mv[cc][4 + j], m2 = mv[cc][8 + j], m3 = mv[cc][12 + j];
+            s2[0][j] = m0 + m1 + m2;
+            s2[1][j] = m1 - m2 - m3;
         }
         const float bias = p.bias ? p.bias[co] : 0.f;
         float* o = p.out + ((size_t)b * p.out_ctot + p.out_c0 + co) * OPL +
-                   (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-        const float* ad = p.add ? p.add + ((size_t)b * p.Cout + co) * APL +
-                                      (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
-                                : nullptr;
+                   (ptrdiff_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // (A^T m) A
-            float y[2] = {s[i][0] + s[i][1] + s[i][2], s[i][1] - s[i][2] - s[i][3]};
+            float y[2] = {s2[i][0] + s2[i][1] + s2[i][2], s2[i][1] - s2[i][2] - s2[i][3]};
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (okr[i] && okc[j]) {
                     float v = y[j] + bias;
-                    if (ad) v += ad[(size_t)i * p.AW + j];
+                    if (p.add) v += av[cc][i * 2 + j];
                     if (p.relu) v = fmaxf(v, 0.f);
-                    o[(size_t)i * p.out_W + j] = v;
+                    o[(ptrdiff_t)i * p.out_W + j] = v;
                 }
             }
         }

@@ -279,7 +279,9 @@ class Conv:
         ws = _wino_workspace(lib.iiseg_conv_wino_workspace_elems(C.byref(d)), x1.device)
         args = (C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre), _ptr(pooled), _ptr(self._U),
                 _ptr(self.b), _ptr(add), _ptr(ws), _ptr(out))
-        fused = 8 if (self.Cin <= WINO_FUSED_MAX_CIN and self.Cin % 32 == 0) else 0
+        # (a skip-add would be read by the fused kernel's epilogue, uncoalesced and with nothing to
+        # hide its latency: such layers keep the separate, coalesced output transform)
+        fused = 8 if (self.Cin <= WINO_FUSED_MAX_CIN and self.Cin % 32 == 0 and add is None) else 0
         if prof is None:
             check(lib.iiseg_conv_wino_f32(_stream(), *args, 7 | fused), 'iiseg_conv_wino_f32')
             return out
