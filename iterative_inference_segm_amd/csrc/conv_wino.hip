@@ -134,44 +134,59 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoParams p) {
     }
     const size_t HW = (size_t)p.H * p.W, hw2 = (size_t)p.h2 * p.w2;
     const size_t xis = (size_t)p.Kc * p.Tpad;
-    const int c0 = blockIdx.y * ICH;
+    // Phase 1: every load of the thread's channels, unconditional (offsets of elements outside the
+    // image are clamped to element 0 of the plane and masked afterwards) so that all are in
+    // flight together; phase 2: transform + store.  (Loads placed after a store could not be
+    // moved up: V and the inputs may alias as far as the compiler knows.)
+    constexpr int NC_ = UNPOOL ? ICH / 2 : ICH;
+    const int c0 = blockIdx.y * NC_;
+    float pv[NC_][4][4];
+    float pq[UNPOOL ? NC_ : 1][NQY][NQX], uq[UNPOOL ? NC_ : 1][NQY][NQX];
 #pragma unroll
-    for (int cc = 0; cc < ICH; ++cc) {
-        const int c = c0 + cc;
-        if (c >= p.Kc) break;
-        float d[4][4];
+    for (int cc = 0; cc < NC_; ++cc) {
+        const int c = min(c0 + cc, p.Kc - 1);
         if constexpr (UNPOOL) {
             const float* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
             const float* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
             const float* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
-            float pq[NQY][NQX], uq[NQY][NQX];
 #pragma unroll
             for (int i = 0; i < NQY; ++i)
 #pragma unroll
                 for (int j = 0; j < NQX; ++j) {
-                    const bool ok = qrok[i] && qcok[j];
-                    pq[i][j] = ok ? poolp[qoff[i] + j] : 0.f;
-                    uq[i][j] = ok ? upp[qoff[i] + j] : 0.f;
+                    const int o = (qrok[i] && qcok[j]) ? qoff[i] + j : 0;
+                    pq[cc][i][j] = poolp[o];
+                    uq[cc][i][j] = upp[o];
                 }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    constexpr int dummy = 0;
-                    const int qi = (PY + i) >> 1, qj = (PX + j) >> 1;
-                    const bool ok = rok[i] && cok[j] && qrok[qi] && qcok[qj];
-                    const float pv = ok ? prep[rowoff[i] + j] : 0.f;
-                    d[i][j] = (ok && pv == pq[qi][qj]) ? uq[qi][qj] : 0.f;
-                    (void)dummy;
-                }
+                for (int j = 0; j < 4; ++j) pv[cc][i][j] = prep[(rok[i] && cok[j]) ? rowoff[i] + j : 0];
         } else {
             const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
                                         : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = (rok[i] && cok[j]) ? src[rowoff[i] + j] : 0.f;
+                for (int j = 0; j < 4; ++j) pv[cc][i][j] = src[(rok[i] && cok[j]) ? rowoff[i] + j : 0];
         }
+    }
+#pragma unroll
+    for (int cc = 0; cc < NC_; ++cc) {
+        const int c = c0 + cc;
+        if (c >= p.Kc) break;
+        float d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (UNPOOL) {
+                    const int qi = (PY + i) >> 1, qj = (PX + j) >> 1;
+                    const bool ok = rok[i] && cok[j] && qrok[qi] && qcok[qj];
+                    d[i][j] = (ok && pv[cc][i][j] == pq[cc][qi][qj]) ? uq[cc][qi][qj] : 0.f;
+                } else {
+                    d[i][j] = (rok[i] && cok[j]) ? pv[cc][i][j] : 0.f;
+                }
+            }
         float e[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // B^T d
@@ -749,7 +764,8 @@ void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
 #undef WINO_ILDS
         return;
     }
-    const dim3 grid((p.T + 255) / 256, (p.Kc + ICH - 1) / ICH), block(256);
+    const int nc = unpool ? ICH / 2 : ICH;   // channels per thread
+    const dim3 grid((p.T + 255) / 256, (p.Kc + nc - 1) / nc), block(256);
     if (!unpool) {
         hipLaunchKernelGGL((wino_input_kernel<false, 0, 0>), grid, block, 0, s, p);
         return;
