@@ -240,6 +240,21 @@ int iiseg_confusion_masked_f64(void* stream, const double* y, const double* t,
                                int32_t C, int32_t HW);
 
 /* ---------------------------------------------------------------------------------------
+ * Element-wise helpers of the optional noise>0 mask emulation: with
+ * dae_dict['noise'] > 0 the reference's DePool2D masks come from a re-evaluation of the down path
+ * with GaussianNoiseLayer / DropoutLayer ACTIVE (layers/mylayers.py:91-93, models/fcn_down.py:60-63,
+ * 108-111).  The caller supplies the random tensors.
+ *   add_noise     : out = x + sigma * eps                       (GaussianNoiseLayer)
+ *   dropout_apply : x = x * keep / (1 - p), keep in {0, 1}       (DropoutLayer, rescale=True)
+ * ------------------------------------------------------------------------------------- */
+int iiseg_add_noise_f32(void* stream, const float* x, const float* eps, float sigma, float* out,
+                        int64_t n);
+int iiseg_add_noise_f64(void* stream, const double* x, const double* eps, double sigma, double* out,
+                        int64_t n);
+int iiseg_dropout_apply_f32(void* stream, float* x, const float* keep, float p, int64_t n);
+int iiseg_dropout_apply_f64(void* stream, double* x, const double* keep, double p, int64_t n);
+
+/* ---------------------------------------------------------------------------------------
  * Batch-statistics BatchNorm (+ReLU).  Replaces lasagne BatchNormLayer under
  * batch_norm_use_averages=False (iterative_inference.py:187) followed by the rectify
  * NonlinearityLayer of FC-DenseNet's BN_ReLU_Conv (models/FCDenseNet.py:12,90,109,123).

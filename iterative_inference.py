@@ -110,7 +110,9 @@ def build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_se
                        conv_before_pool=dae_dict['conv_before_pool'],
                        additional_pool=dae_dict['additional_pool'], dropout=dae_dict['dropout'],
                        skip=dae_dict['skip'], unpool_type=dae_dict['unpool_type'],
-                       bn=dae_dict['bn'], params=dae_params, device=device)
+                       bn=dae_dict['bn'], params=dae_params, device=device,
+                       # extra key of this build: the stochastic masks of noise > 0
+                       emulate_noise=bool(dae_dict.get('emulate_noise', False)))
     elif dae_dict['kind'] == 'fcn8':                             # :165-170
         from iterative_inference_segm_amd.fcn8 import buildFCN8_DAE
         dae_weights = os.path.join(loadpath, 'dae_model_best.npz')

@@ -184,3 +184,60 @@ extern "C" int iiseg_refine_finalize(void* stream, const double* partial, int32_
                        (hipStream_t)stream, partial, active, iters, last_norm, B, nblk, HW, eps);
     return iiseg_check_launch();
 }
+
+// ---- element-wise helpers of the noise>0 mask emulation ----------------------
+// The reference's DePool2D re-evaluates the down path WITHOUT deterministic=True
+// (layers/mylayers.py:91-93), so with dae_dict['noise'] > 0 its masks come from a forward with
+// GaussianNoiseLayer (models/fcn_down.py:60-63: x + sigma * eps) and DropoutLayer (p, rescaled:
+// x * keep / (1 - p)) active.  The random tensors are the caller's (any RNG); these kernels only
+// apply them.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ x, const T* __restrict__ e,
+                                                   T a, T* __restrict__ out, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = x[i] + a * e[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scale_mask_kernel(T* __restrict__ x, const T* __restrict__ keep,
+                                                         T scale, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        x[i] = x[i] * keep[i] * scale;
+}
+inline int ew_grid(size_t n) {
+    const size_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+template <typename T>
+int add_noise(void* stream, const T* x, const T* eps, T sigma, T* out, int64_t n) {
+    if (!x || !eps || !out) return IISEG_ERR_NULL;
+    if (n <= 0) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(axpy_kernel<T>, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x,
+                       eps, sigma, out, (size_t)n);
+    return iiseg_check_launch();
+}
+template <typename T>
+int dropout_apply(void* stream, T* x, const T* keep, T p, int64_t n) {
+    if (!x || !keep) return IISEG_ERR_NULL;
+    if (n <= 0 || !(p >= 0) || !(p < 1)) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(scale_mask_kernel<T>, dim3(ew_grid((size_t)n)), dim3(256), 0,
+                       (hipStream_t)stream, x, keep, (T)1 / ((T)1 - p), (size_t)n);
+    return iiseg_check_launch();
+}
+}  // namespace
+
+extern "C" int iiseg_add_noise_f32(void* stream, const float* x, const float* eps, float sigma,
+                                   float* out, int64_t n) {
+    return add_noise<float>(stream, x, eps, sigma, out, n);
+}
+extern "C" int iiseg_add_noise_f64(void* stream, const double* x, const double* eps, double sigma,
+                                   double* out, int64_t n) {
+    return add_noise<double>(stream, x, eps, sigma, out, n);
+}
+extern "C" int iiseg_dropout_apply_f32(void* stream, float* x, const float* keep, float p, int64_t n) {
+    return dropout_apply<float>(stream, x, keep, p, n);
+}
+extern "C" int iiseg_dropout_apply_f64(void* stream, double* x, const double* keep, double p,
+                                       int64_t n) {
+    return dropout_apply<double>(stream, x, keep, p, n);
+}

@@ -49,7 +49,8 @@ class StandardDAE:
 
     def __init__(self, params, n_classes, concat_h=('pool4',), padding=100, n_filters=64,
                  conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind', bn=0,
-                 device='cuda', dtype=torch.float32, pad_multi_concat=False):
+                 device='cuda', dtype=torch.float32, pad_multi_concat=False, noise=0.0,
+                 dropout=0.0, emulate_noise=False, seed=0):
         concat_h = list(concat_h)
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
                    for el in concat_h)                                   # fcn_down.py:39-41
@@ -62,6 +63,14 @@ class StandardDAE:
                                       "only")
         self.bn = bool(bn)
         self.enc_bn = {}
+        # noise>0 mask emulation (optional): DePool2D's masks from a hidden down-path
+        # re-forward with GaussianNoiseLayer / DropoutLayer active, one fresh sample per level.
+        # Off by default: the deterministic masks are the build's reference semantics.
+        self.noise, self.dropout = float(noise), float(dropout)
+        self.emulate_noise = bool(emulate_noise)
+        self.random_source = None     # callable(kind, level, name, shape) -> tensor, or None: torch RNG
+        self._seed, self._gen = int(seed), None
+        self.dtype = dtype
         self.unpool_type = unpool_type
         self.concat_h, self.padding, self.skip = concat_h, padding, skip
         self.conv_before_pool = conv_before_pool
@@ -268,6 +277,9 @@ class StandardDAE:
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')
+        if self.emulate_noise and self.noise > 0 and self.unpool_type == 'trackind' and \
+                mask_override is None:
+            mask_override = self.hidden_masks(h_list, y)
         if self.unpool_type == 'standard':
             # fcn_up.py:37-63: up_p = Deconv2DLayer(prev, n_cl, 4, stride=2, crop='valid', linear),
             # then ElemwiseSumLayer with pool_{p-1} (center crop) or CroppingLayer.  The 4x4/2
@@ -348,6 +360,49 @@ class StandardDAE:
             self.trace.update({'pool%d' % k: v for k, v in pool.items() if k > 0})
         return t
 
+    def _rand(self, kind, level, name, shape, like):
+        if self.random_source is not None:
+            t = self.random_source(kind, level, name, tuple(shape))
+            return torch.as_tensor(t).to(like.dtype).contiguous().to(like.device)
+        if self._gen is None:
+            self._gen = torch.Generator(device=like.device)
+            self._gen.manual_seed(self._seed)
+        if kind == 'noise':
+            return torch.randn(shape, generator=self._gen, device=like.device, dtype=like.dtype)
+        u = torch.rand(shape, generator=self._gen, device=like.device, dtype=like.dtype)
+        return (u >= self.dropout).to(like.dtype)     # keep mask
+
+    def hidden_masks(self, h_list, y):
+        """{level: (pre, pooled)} as DePool2D sees them when dae_dict['noise'] > 0: every DePool2D
+        calls lasagne.layers.get_output([pool_in, pool]) WITHOUT deterministic=True
+        (layers/mylayers.py:91-93), i.e. a fresh forward of the down path up to its level with
+        GaussianNoiseLayer (fcn_down.py:60-63) and the DropoutLayers (:108-111) active.  The
+        main path (the values that are unpooled) stays deterministic."""
+        if self.bn:
+            raise NotImplementedError('noise emulation with bn=1 (batch statistics in the hidden '
+                                      'forward) is not supported')
+        masks = {}
+        for p in range(self.total, 0, -1):
+            t = ops.add_noise(y, self._rand('noise', p, None, y.shape, y), self.noise)
+            pos, pending = 0, None
+            if self.concat_h[0] == 'input':
+                pending, pos = h_list[0], 1
+            for q in range(p):
+                for i in range(1, self.conv_before_pool + 1):
+                    name = 'conv%d_%d' % (q + 1, i)
+                    conv = self.enc[name]
+                    t = conv(pending, x2=t) if pending is not None else conv(t)
+                    pending = None
+                    if self.dropout > 0:
+                        ops.dropout_apply(t, self._rand('dropout', p, name, t.shape, t), self.dropout)
+                pre_q = t
+                t = ops.maxpool2x2(t)
+                if q < self.n_pool and pos < len(self.concat_h) and \
+                        self.concat_h[pos] == 'pool%d' % (q + 1):
+                    pending, pos = h_list[pos], pos + 1
+            masks[p] = (pre_q, t)
+        return masks
+
     def _count(self, name, conv, out, full=None, computed=None):
         # (name, nominal FLOPs of the FULL layer output (SURVEY 6.2), FLOPs of the computed window)
         if self.conv_log is not None:
@@ -374,9 +429,11 @@ def buildDAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
              path_weights=None, model_name='dae_model.npz', trainable=False, load_weights=False,
              out_nonlin='softmax', concat_h=('input',), noise=0.1, n_filters=64,
              conv_before_pool=1, additional_pool=0, dropout=0., skip=False,
-             unpool_type='standard', bn=0, params=None, device='cuda', dtype=torch.float32):
+             unpool_type='standard', bn=0, params=None, device='cuda', dtype=torch.float32,
+             emulate_noise=False):
     """Mirror of models/DAE_h.py:12-20.  Inference only: `noise`, `dropout` are identities at
-    deterministic=True (P8, P9; masks are the deterministic ones); the symbolic
+    deterministic=True (P8, P9); the DePool2D masks are the deterministic ones unless
+    `emulate_noise` asks for the reference's noisy hidden re-forward; the symbolic
     `input_*_var`, `trainable`, `ae_h`, `void_labels` are accepted and ignored."""
     import os
     if params is None:
@@ -388,4 +445,5 @@ def buildDAE(input_concat_h_vars=None, input_mask_var=None, n_classes=11,
         raise NotImplementedError('inference uses out_nonlin=softmax (iterative_inference.py:158)')
     return StandardDAE(params, n_classes, concat_h=concat_h, padding=padding, n_filters=n_filters,
                        conv_before_pool=conv_before_pool, additional_pool=additional_pool,
-                       skip=skip, unpool_type=unpool_type, bn=bn, device=device, dtype=dtype)
+                       skip=skip, unpool_type=unpool_type, bn=bn, device=device, dtype=dtype,
+                       noise=noise, dropout=dropout, emulate_noise=emulate_noise)

@@ -485,3 +485,20 @@ def bn_affine(x, bnp, window=None):
                                       _ptr(beta, dt), _ptr(gamma, dt), _ptr(mean, dt),
                                       _ptr(inv_std, dt)), 'iiseg_bn_affine_window')
     return x
+
+
+def add_noise(x, eps, sigma):
+    """x + sigma * eps (GaussianNoiseLayer with the caller's standard-normal sample eps)."""
+    dt = x.dtype
+    out = torch.empty_like(x)
+    check(_fn('add_noise', dt)(_stream(), _ptr(x, dt), _ptr(eps, dt), float(sigma), _ptr(out, dt),
+                               x.numel()), 'iiseg_add_noise')
+    return out
+
+
+def dropout_apply(x, keep, p):
+    """In place x * keep / (1 - p) (DropoutLayer, rescale=True, with the caller's 0/1 mask)."""
+    dt = x.dtype
+    check(_fn('dropout_apply', dt)(_stream(), _ptr(x, dt), _ptr(keep, dt), float(p), x.numel()),
+          'iiseg_dropout_apply')
+    return x

@@ -45,7 +45,8 @@ def _bn_avg(x, bnp):
 
 def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=64,
                 conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind',
-                bn=0, out_softmax=True, return_net=False, pad_multi_concat=False):
+                bn=0, out_softmax=True, return_net=False, pad_multi_concat=False, noise=0.0,
+                dropout=0.0, hidden_rand=None):
     """pred_dae_fn(h..., y) -> r  (iterative_inference.py:189-190) for dae kind 'standard'.
 
     Deterministic: GaussianNoiseLayer and DropoutLayer are identities (P8, P9) and the
@@ -87,6 +88,30 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
         net['pool%d' % (p + 1)] = t = nn.maxpool2(t)         # :122
         if p < n_pool:
             t, pos = maybe_concat('pool%d' % (p + 1), t, pos)  # :131-134
+    # noise > 0: every DePool2D re-evaluates the down path up to its pool WITHOUT
+    # deterministic=True (layers/mylayers.py:91-93): GaussianNoiseLayer on y (fcn_down.py:60-63)
+    # and the DropoutLayers after the convs (:108-111, rescale 1/(1-p)) are active, one fresh
+    # sample per DePool2D.  hidden_rand(kind, level, name, shape) supplies the samples.
+    hidden = {}
+    if noise > 0 and hidden_rand is not None and unpool_type == 'trackind':
+        assert not bn
+        for p in range(total, 0, -1):
+            u = y + noise * hidden_rand('noise', p, None, y.shape)
+            hpos = 0
+            u, hpos = maybe_concat('input', u, hpos)
+            for q in range(p):
+                for i in range(1, conv_before_pool + 1):
+                    pad = padding if (q == 0 and i == 1 and (len(concat_h) == 1 or pad_multi_concat)
+                                      and concat_h[-1] != 'input' and padding > 0) else 1
+                    name = 'conv%d_%d' % (q + 1, i)
+                    u = nn.conv2d(u, params[name][0], params[name][1], pad=pad, relu=True)
+                    if dropout > 0:
+                        u = u * hidden_rand('dropout', p, name, u.shape) / (1.0 - dropout)
+                pre_q = u
+                pool_q = u = nn.maxpool2(u)
+                if q < n_pool:
+                    u, hpos = maybe_concat('pool%d' % (q + 1), u, hpos)
+            hidden[p] = (pre_q, pool_q)
     # decoder, fcn_up.py:143-151 / UnpoolNet :11-115
     for p in range(total, 0, -1):
         if unpool_type == 'standard':
@@ -96,7 +121,8 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
             # trackind: DePool2D (:70-75); inverse: InverseLayer of the pool (:76-79) -- the
             # gradient of max-pooling w.r.t. its input with `t` as upstream, the same
             # equality-mask arithmetic when masks are deterministic.
-            u = nn.depool_eqmask(t, pre[p], net['pool%d' % p])
+            mpre, mpool = hidden.get(p, (pre[p], net['pool%d' % p]))
+            u = nn.depool_eqmask(t, mpre, mpool)
             name = 'up_conv%d' % p
             u = nn.conv2d(u, params[name][0], params[name][1], pad=1, relu=False)  # :83-86
             if bn:

@@ -415,6 +415,46 @@ def test_dae_bn1(built_lib, dtype, tol, tmp_path):
     assert np.array_equal(host(Yfull), host(Yii))
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-11), (torch.float32, TOL)])
+def test_noise_mask_emulation(built_lib, dtype, tol):
+    """Optional emulation of the reference's stochastic masks at dae_dict['noise'] > 0 (SURVEY
+    F4): DePool2D's equality masks come from a hidden re-forward of the down path with
+    GaussianNoiseLayer and DropoutLayer active, one fresh sample per level.  With the SAME
+    injected samples on both sides the HIP path must reproduce the oracle; with the emulation off
+    (default) the deterministic masks are used and the result differs."""
+    from iterative_inference_segm_amd.dae import StandardDAE
+    concat_h = ['pool2']
+    rng = np.random.default_rng(71)
+    size, hc, nf = (28, 36), 5, 4
+    dp = S.make_dae_params(h_channels=(hc,), concat_h=concat_h, n_filters=nf, additional_pool=1,
+                           seed=72)
+    y = rng.random((2, 11) + size); y /= y.sum(1, keepdims=True)
+    h = rng.random((2, hc, (size[0] + 198) // 4, (size[1] + 198) // 4))
+
+    def samples(kind, level, name, shape):
+        g = np.random.default_rng(abs(hash((kind, level, name))) % (2 ** 32))
+        if kind == 'noise':
+            return g.standard_normal(shape)
+        return (g.random(shape) >= 0.3).astype(np.float64)
+    kw = dict(concat_h=concat_h, n_filters=nf, additional_pool=1)
+    dae = StandardDAE(dp, 11, dtype=dtype, noise=0.5, dropout=0.3, emulate_noise=True, **kw)
+    dae.random_source = samples
+    yt = torch.from_numpy(y).to(dtype).cuda()
+    ht = torch.from_numpy(h).to(dtype).cuda()
+    got = host(dae(ht, yt))
+    ref = odae.dae_forward(to64(dp), [h], y, noise=0.5, dropout=0.3, hidden_rand=samples, **kw)
+    assert np.abs(got - ref).max() <= tol
+    det = odae.dae_forward(to64(dp), [h], y, **kw)
+    assert np.abs(ref - det).max() > 1e-3          # the noisy masks do change the output
+    dae.emulate_noise = False
+    assert np.abs(host(dae(ht, yt)) - det).max() <= tol
+    # default RNG path: runs, is reproducible per seed, and differs from the deterministic masks
+    a = StandardDAE(dp, 11, dtype=dtype, noise=0.5, dropout=0.3, emulate_noise=True, seed=5, **kw)
+    b = StandardDAE(dp, 11, dtype=dtype, noise=0.5, dropout=0.3, emulate_noise=True, seed=5, **kw)
+    ra, rb = host(a(ht, yt)), host(b(ht, yt))
+    assert np.array_equal(ra, rb) and np.abs(ra - det).max() > 1e-3
+
+
 def test_multi_concat_standard_dae(built_lib):
     """Config-5 variant (SURVEY A9', build-defined): standard DAE with h concatenated after pool3
     AND pool4 (per-concat channel counts), pad-100 applied (`pad_multi_concat`), conv_before_pool=2;
