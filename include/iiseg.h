@@ -240,6 +240,40 @@ int iiseg_confusion_masked_f64(void* stream, const double* y, const double* t,
                                int32_t C, int32_t HW);
 
 /* ---------------------------------------------------------------------------------------
+ * True-gradient mode (BASELINE north_star; NOT in the reference, whose
+ * "gradient" is the residual r - y):  E(y) = sum_{c,px} (r(y|h) - y)^2,
+ * dE/dy = J_r^T 2(r - y) - 2(r - y).  The convolutions' backward-data passes run on the forward
+ * conv entry points with channel-transposed, spatially flipped weights; these are the other
+ * adjoints.  All tensors dense NCHW.
+ *   sqerr_softmax_bwd : gscore = softmax backward of g_r = 2 (softmax(score window) - y)
+ *   depool_bwd        : adjoint of DePool2D w.r.t. its input: masked 2x2 sum (mask pre == pooled)
+ *   pool_relu_bwd     : adjoint of maxpool2x2(relu(z)) w.r.t. z given pre = relu(z): the gradient
+ *                       goes to every position equal to the window maximum (F4 mask), relu'(0) = 0
+ *   grad_update       : grad = gthrough - 2 (r - y); y <- clip(y - step * grad, 0, 1); norm
+ *                       partials of grad as in iiseg_refine_update_*
+ * ------------------------------------------------------------------------------------- */
+int iiseg_sqerr_softmax_bwd_f32(void* stream, const float* score, const float* y, float* gscore,
+                                int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0,
+                                int32_t sx0, int32_t H, int32_t W);
+int iiseg_sqerr_softmax_bwd_f64(void* stream, const double* score, const double* y, double* gscore,
+                                int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0,
+                                int32_t sx0, int32_t H, int32_t W);
+int iiseg_depool_bwd_f32(void* stream, const float* gout, const float* pre, const float* pooled,
+                         float* gup, int32_t BC, int32_t H, int32_t W);
+int iiseg_depool_bwd_f64(void* stream, const double* gout, const double* pre, const double* pooled,
+                         double* gup, int32_t BC, int32_t H, int32_t W);
+int iiseg_pool_relu_bwd_f32(void* stream, const float* gpool, const float* pre, const float* pooled,
+                            float* gz, int32_t BC, int32_t H, int32_t W);
+int iiseg_pool_relu_bwd_f64(void* stream, const double* gpool, const double* pre,
+                            const double* pooled, double* gz, int32_t BC, int32_t H, int32_t W);
+int iiseg_grad_update_f32(void* stream, const float* score, const float* gthrough, float* y,
+                          const int32_t* active, double* partial, int32_t B, int32_t C, int32_t SH,
+                          int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W, float step);
+int iiseg_grad_update_f64(void* stream, const double* score, const double* gthrough, double* y,
+                          const int32_t* active, double* partial, int32_t B, int32_t C, int32_t SH,
+                          int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W, double step);
+
+/* ---------------------------------------------------------------------------------------
  * Element-wise helpers of the optional noise>0 mask emulation: with
  * dae_dict['noise'] > 0 the reference's DePool2D masks come from a re-evaluation of the down path
  * with GaussianNoiseLayer / DropoutLayer ACTIVE (layers/mylayers.py:91-93, models/fcn_down.py:60-63,

@@ -151,7 +151,7 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
               training_dict={}, data_augmentation=False, which_set='test', ae_h=False,
               full_im_ft=False, savepath=None, loadpath=None, test_from_0_255=False,
               weights_path=None, synthetic=False, n_images=20, image_size=(224, 224),
-              batch_size=10, early_stop=True, save_npz=True, verbose=True):
+              batch_size=10, early_stop=True, save_npz=True, verbose=True, update='residual'):
     """Signature of reference iterative_inference.py:56-59 plus keyword-only extras.
     Returns a dict of the three summary lines (the reference returns None and only prints)."""
     # Update DAE parameters (:64-79)
@@ -212,7 +212,7 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
         Y_dae = ii.pred_dae_fn(*(H_test_batch + [Y_test_batch]))  # :250
         m_dae = ii.val_device(Y_dae, L_dev)                      # :251
         Y_ii, iters, _ = ii.refine(H_test_batch, Y_test_batch, learn_step, num_iter,
-                                   eps=_EPSILON, early_stop=early_stop)   # :257-284
+                                   eps=_EPSILON, early_stop=early_stop, mode=update)   # :257-284
         m_ii = ii.val_device(Y_ii, L_dev)                        # :287
         for key, m in (('fcn', m_fcn), ('dae', m_dae), ('ii', m_ii)):
             acc, _, mse = m.result()
@@ -290,6 +290,9 @@ def main():
     parser.add_argument('--image_size', type=int, nargs=2, default=[224, 224])
     parser.add_argument('--batch_size', type=int, default=10)
     parser.add_argument('--no_early_stop', action='store_true')
+    parser.add_argument('--update', choices=['residual', 'gradient'], default='residual',
+                        help="'residual': the reference's y += step*(r - y) (default); 'gradient': "
+                             "descend the true gradient of ||r(y|h) - y||^2 (extension)")
     args = parser.parse_args()
 
     inference(args.dataset, args.segmentation_net, float(args.step), int(args.num_iter),
@@ -299,7 +302,7 @@ def main():
               training_dict=args.training_dict, weights_path=args.weights_path,
               synthetic=args.synthetic, n_images=args.n_images,
               image_size=tuple(args.image_size), batch_size=args.batch_size,
-              early_stop=not args.no_early_stop)
+              early_stop=not args.no_early_stop, update=args.update)
 
 
 if __name__ == '__main__':

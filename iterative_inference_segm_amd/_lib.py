@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -71,6 +71,14 @@ SIGNATURES = {
     'iiseg_bn_relu_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
     'iiseg_bn_stats_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _vp]),
     'iiseg_bn_relu_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
+    'iiseg_sqerr_softmax_bwd_f32': (C.c_int, [_vp] * 4 + [_i32] * 8),
+    'iiseg_sqerr_softmax_bwd_f64': (C.c_int, [_vp] * 4 + [_i32] * 8),
+    'iiseg_depool_bwd_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_depool_bwd_f64': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_pool_relu_bwd_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_pool_relu_bwd_f64': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_grad_update_f32': (C.c_int, [_vp] * 6 + [_i32] * 8 + [C.c_float]),
+    'iiseg_grad_update_f64': (C.c_int, [_vp] * 6 + [_i32] * 8 + [C.c_double]),
     'iiseg_add_noise_f32': (C.c_int, [_vp, _vp, _vp, C.c_float, _vp, _i64]),
     'iiseg_add_noise_f64': (C.c_int, [_vp, _vp, _vp, C.c_double, _vp, _i64]),
     'iiseg_dropout_apply_f32': (C.c_int, [_vp, _vp, _vp, C.c_float, _i64]),

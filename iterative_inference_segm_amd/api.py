@@ -84,13 +84,19 @@ class IterativeInference:
 
     # ---- fused loop ---------------------------------------------------------------------
     def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
-               per_iter_target=None):
+               per_iter_target=None, mode='residual'):
         """Batched replacement of iterative_inference.py:258-284.
 
         for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
                                     y = clip(y - step*(y - softmax(score)), 0, 1)  # :270-273
                                     per image: stop once mean_px ||de||_2 < eps     # :275-277
         Returns (Y_ii, iters_used[B] int32, last_norm[B] float64), all on the device.
+
+        mode='gradient' (extension; the reference only has the residual form,
+        F1): descends the true gradient of E(y) = sum (r(y|h) - y)^2,
+            y = clip(y - step * (J_r^T 2(r - y) - 2(r - y)), 0, 1),
+        with a hand-written backward pass through the DAE (`StandardDAE.backward_y`); the stop
+        test uses mean_px ||grad||_2.
 
         `per_iter_target` (one-hot T): also returns a (num_iter, C*(C+1)) int64 tensor of
         per-iteration confusion counts over the images still iterating after that iteration --
@@ -115,7 +121,14 @@ class IterativeInference:
         for it in range(int(num_iter)):
             score = self.dae.scores(H, y, session=sess) if sess is not None \
                 else self.dae.scores(H, y)
-            ops.refine_update(score, y, st, step, off=(0, 0))
+            if mode == 'gradient':
+                g_score = ops.sqerr_softmax_bwd(score, y, off=(0, 0))
+                ops.grad_update(score, self.dae.backward_y(g_score, y.shape), y, st, step,
+                                off=(0, 0))
+            elif mode == 'residual':
+                ops.refine_update(score, y, st, step, off=(0, 0))
+            else:
+                raise ValueError('mode must be "residual" or "gradient"')
             ops.refine_finalize(st, eps_eff)
             if per_iter is not None:
                 ops.confusion_accumulate(y, T, per_iter[it], scratch, active=st.active)

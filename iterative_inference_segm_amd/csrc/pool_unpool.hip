@@ -90,6 +90,60 @@ __global__ __launch_bounds__(256) void unpool_eqmask_window_kernel(
     }
 }
 
+// ---- backward kernels of the true-gradient mode ----------------------------
+// DePool2D backward: the unpooled tensor is mask * repeat(up), so
+//   g_up[i,j] = sum over the 2x2 window of (pre == pooled[i,j]) ? g_out : 0   (no gradient through
+// the mask: it is piecewise constant).
+template <typename T>
+__global__ __launch_bounds__(256) void depool_bwd_kernel(const T* __restrict__ gout,
+                                                         const T* __restrict__ pre,
+                                                         const T* __restrict__ pooled,
+                                                         T* __restrict__ gup, int BC, int H, int W,
+                                                         int h, int w) {
+    const size_t n = (size_t)BC * h * w;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % w);
+        const size_t t = i / w;
+        const int oy = (int)(t % h);
+        const size_t bc = t / h;
+        const size_t o = (bc * H + 2 * oy) * (size_t)W + 2 * ox;
+        const T m = pooled[i];
+        T s = 0;
+        s += pre[o] == m ? gout[o] : (T)0;
+        s += pre[o + 1] == m ? gout[o + 1] : (T)0;
+        s += pre[o + W] == m ? gout[o + W] : (T)0;
+        s += pre[o + W + 1] == m ? gout[o + W + 1] : (T)0;
+        gup[i] = s;
+    }
+}
+
+// max-pool backward (every position equal to the window maximum receives the gradient, the
+// equality mask of SURVEY F4) fused with the backward of the ReLU in front of the pool
+// (relu'(0) = 0):  g_z[y,x] = (pre == pooled[y/2,x/2] && pre > 0) ? g_pool[y/2,x/2] : 0.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_relu_bwd_kernel(const T* __restrict__ gpool,
+                                                            const T* __restrict__ pre,
+                                                            const T* __restrict__ pooled,
+                                                            T* __restrict__ gz, int BC, int H, int W,
+                                                            int h, int w) {
+    const size_t n = (size_t)BC * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const size_t t = i / W;
+        const int y = (int)(t % H);
+        const size_t bc = t / H;
+        T v = 0;
+        if (y < 2 * h && x < 2 * w) {
+            const size_t j = (bc * h + (y >> 1)) * (size_t)w + (x >> 1);
+            const T pv = pre[i];
+            v = (pv == pooled[j] && pv > (T)0) ? gpool[j] : (T)0;
+        }
+        gz[i] = v;
+    }
+}
+
 inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -140,7 +194,47 @@ int unpool_window(void* stream, const T* up, const T* pre, const T* pooled, T* o
     return iiseg_check_launch();
 }
 
+template <typename T>
+int depool_bwd(void* stream, const T* gout, const T* pre, const T* pooled, T* gup, int32_t BC,
+               int32_t H, int32_t W) {
+    if (!gout || !pre || !pooled || !gup) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(depool_bwd_kernel<T>, dim3(grid_for((size_t)BC * (H / 2) * (W / 2))), dim3(256),
+                       0, (hipStream_t)stream, gout, pre, pooled, gup, BC, H, W, H / 2, W / 2);
+    return iiseg_check_launch();
+}
+
+template <typename T>
+int pool_relu_bwd(void* stream, const T* gpool, const T* pre, const T* pooled, T* gz, int32_t BC,
+                  int32_t H, int32_t W) {
+    if (!gpool || !pre || !pooled || !gz) return IISEG_ERR_NULL;
+    if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(pool_relu_bwd_kernel<T>, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
+                       (hipStream_t)stream, gpool, pre, pooled, gz, BC, H, W, H / 2, W / 2);
+    return iiseg_check_launch();
+}
+
 }  // namespace
+
+extern "C" int iiseg_depool_bwd_f32(void* stream, const float* gout, const float* pre,
+                                    const float* pooled, float* gup, int32_t BC, int32_t H, int32_t W) {
+    return depool_bwd<float>(stream, gout, pre, pooled, gup, BC, H, W);
+}
+extern "C" int iiseg_depool_bwd_f64(void* stream, const double* gout, const double* pre,
+                                    const double* pooled, double* gup, int32_t BC, int32_t H,
+                                    int32_t W) {
+    return depool_bwd<double>(stream, gout, pre, pooled, gup, BC, H, W);
+}
+extern "C" int iiseg_pool_relu_bwd_f32(void* stream, const float* gpool, const float* pre,
+                                       const float* pooled, float* gz, int32_t BC, int32_t H,
+                                       int32_t W) {
+    return pool_relu_bwd<float>(stream, gpool, pre, pooled, gz, BC, H, W);
+}
+extern "C" int iiseg_pool_relu_bwd_f64(void* stream, const double* gpool, const double* pre,
+                                       const double* pooled, double* gz, int32_t BC, int32_t H,
+                                       int32_t W) {
+    return pool_relu_bwd<double>(stream, gpool, pre, pooled, gz, BC, H, W);
+}
 
 extern "C" int iiseg_maxpool2x2_window_f32(void* stream, const float* x, float* out, int32_t BC,
                                            int32_t H, int32_t W, int32_t y0, int32_t x0,

@@ -99,6 +99,83 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
         partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// ---- true-gradient mode (not in the reference, F1) ----------------------------
+// E(y) = sum_{c,px} (r(y|h) - y)^2.  sqerr_softmax_bwd: g_score = dE/dscore through the softmax,
+// g_r = 2 (r - y):  g_score_c = r_c (g_r_c - sum_k r_k g_r_k).
+template <int CMAX, typename T>
+__global__ __launch_bounds__(256) void sqerr_softmax_bwd_kernel(const T* __restrict__ score,
+                                                                const T* __restrict__ yin,
+                                                                T* __restrict__ gscore, int C, int SH,
+                                                                int SW, int sy0, int sx0, int H, int W) {
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (pix >= HW) return;
+    const int y = pix / W, x = pix - y * W;
+    const size_t SHW = (size_t)SH * SW;
+    const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+    T r[CMAX], g[CMAX];
+    load_softmax<CMAX, T>(sp, SHW, C, r);
+    const T* yp = yin + (size_t)b * C * HW + pix;
+    T dot = 0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            g[c] = (T)2 * (r[c] - yp[(size_t)c * HW]);
+            dot = fma(r[c], g[c], dot);
+        }
+    T* gp = gscore + (size_t)b * C * HW + pix;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) gp[(size_t)c * HW] = r[c] * (g[c] - dot);
+}
+
+// grad = gthrough - 2 (r - y)  (gthrough = the part of dE/dy that flows back through the DAE);
+// y <- clip(y - step * grad, 0, 1); per-pixel ||grad||_2 reduced like refine_update_kernel.
+template <int CMAX, typename T>
+__global__ __launch_bounds__(256) void grad_update_kernel(const T* __restrict__ score,
+                                                          const T* __restrict__ gthrough,
+                                                          T* __restrict__ yio,
+                                                          const int* __restrict__ active,
+                                                          double* __restrict__ partial, int C, int SH,
+                                                          int SW, int sy0, int sx0, int H, int W,
+                                                          T step) {
+    __shared__ double red[4];
+    const int HW = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const bool act = active[b] != 0;
+    T nrm = 0;
+    if (pix < HW) {
+        const int y = pix / W, x = pix - y * W;
+        const size_t SHW = (size_t)SH * SW;
+        const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+        T r[CMAX];
+        load_softmax<CMAX, T>(sp, SHW, C, r);
+        T* yp = yio + (size_t)b * C * HW + pix;
+        const T* gp = gthrough + (size_t)b * C * HW + pix;
+        T ss = 0;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) {
+                const T yv = yp[(size_t)c * HW];
+                const T g = gp[(size_t)c * HW] - (T)2 * (r[c] - yv);
+                ss = fma(g, g, ss);
+                if (act) {
+                    T yn = yv - step * g;
+                    yn = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);
+                    yp[(size_t)c * HW] = yn;
+                }
+            }
+        nrm = sqrt_t(ss);
+    }
+    double d = wave_sum((double)nrm);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void refine_finalize_kernel(const double* __restrict__ partial, int* active, int* iters,
                                        double* last_norm, int B, int nblk, int HW, double eps) {
     for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
@@ -147,7 +224,67 @@ int refine_update(void* stream, const T* score, T* y, const int32_t* active, dou
     return iiseg_check_launch();
 }
 
+template <typename T>
+int sqerr_softmax_bwd(void* stream, const T* score, const T* y, T* gscore, int32_t B, int32_t C,
+                      int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+    if (!score || !y || !gscore) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
+        return IISEG_ERR_SHAPE;
+    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    const dim3 grid((H * W + 255) / 256, B);
+    if (C <= 16)
+        hipLaunchKernelGGL((sqerr_softmax_bwd_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
+                           score, y, gscore, C, SH, SW, sy0, sx0, H, W);
+    else
+        hipLaunchKernelGGL((sqerr_softmax_bwd_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
+                           score, y, gscore, C, SH, SW, sy0, sx0, H, W);
+    return iiseg_check_launch();
+}
+
+template <typename T>
+int grad_update(void* stream, const T* score, const T* gthrough, T* y, const int32_t* active,
+                double* partial, int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0,
+                int32_t sx0, int32_t H, int32_t W, T step) {
+    if (!score || !gthrough || !y || !active || !partial) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
+        return IISEG_ERR_SHAPE;
+    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    const dim3 grid((H * W + 255) / 256, B);
+    if (C <= 16)
+        hipLaunchKernelGGL((grad_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
+                           gthrough, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+    else
+        hipLaunchKernelGGL((grad_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
+                           gthrough, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+    return iiseg_check_launch();
+}
+
 }  // namespace
+
+extern "C" int iiseg_sqerr_softmax_bwd_f32(void* stream, const float* score, const float* y,
+                                           float* gscore, int32_t B, int32_t C, int32_t SH,
+                                           int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+    return sqerr_softmax_bwd<float>(stream, score, y, gscore, B, C, SH, SW, sy0, sx0, H, W);
+}
+extern "C" int iiseg_sqerr_softmax_bwd_f64(void* stream, const double* score, const double* y,
+                                           double* gscore, int32_t B, int32_t C, int32_t SH,
+                                           int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W) {
+    return sqerr_softmax_bwd<double>(stream, score, y, gscore, B, C, SH, SW, sy0, sx0, H, W);
+}
+extern "C" int iiseg_grad_update_f32(void* stream, const float* score, const float* gthrough, float* y,
+                                     const int32_t* active, double* partial, int32_t B, int32_t C,
+                                     int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
+                                     int32_t W, float step) {
+    return grad_update<float>(stream, score, gthrough, y, active, partial, B, C, SH, SW, sy0, sx0, H,
+                              W, step);
+}
+extern "C" int iiseg_grad_update_f64(void* stream, const double* score, const double* gthrough,
+                                     double* y, const int32_t* active, double* partial, int32_t B,
+                                     int32_t C, int32_t SH, int32_t SW, int32_t sy0, int32_t sx0,
+                                     int32_t H, int32_t W, double step) {
+    return grad_update<double>(stream, score, gthrough, y, active, partial, B, C, SH, SW, sy0, sx0, H,
+                               W, step);
+}
 
 extern "C" int iiseg_crop_softmax_f32(void* stream, const float* score, const float* minuend,
                                       float* out, int32_t B, int32_t C, int32_t SH, int32_t SW,

@@ -71,6 +71,7 @@ class StandardDAE:
         self.random_source = None     # callable(kind, level, name, shape) -> tensor, or None: torch RNG
         self._seed, self._gen = int(seed), None
         self.dtype = dtype
+        self._bwd, self._saved = None, None
         self.unpool_type = unpool_type
         self.concat_h, self.padding, self.skip = concat_h, padding, skip
         self.conv_before_pool = conv_before_pool
@@ -358,7 +359,82 @@ class StandardDAE:
         if self.trace is not None:
             self.trace.update({'pre%d' % k: v for k, v in pre.items()})
             self.trace.update({'pool%d' % k: v for k, v in pool.items() if k > 0})
+        self._saved = (mask_override, pre, pool)      # what backward_y needs (masks only)
         return t
+
+    # ---- true-gradient mode (not in the reference, F1) -----------------------
+    def _bwd_convs(self):
+        """Backward-data of a 3x3 stride-1 conv = the forward conv of the gradient with the
+        channel-transposed, spatially flipped filter ('same' for pad 1; for the pad-100 first layer
+        the window at offset pad-1 of that 'same' result).  After a concat only the filters of the
+        non-h channels are kept: h is a constant of the loop."""
+        if self._bwd is None:
+            if self.conv_before_pool != 1 or self.bn or self.unpool_type == 'standard':
+                raise NotImplementedError('gradient mode: conv_before_pool=1, bn=0, unpool_type in '
+                                          '{trackind, inverse}')
+            bwd = {}
+            prev = self.n_classes
+            for p in range(self.total):
+                name = 'conv%d_1' % (p + 1)
+                W = self.enc[name].W                     # (Cout, ch + prev, 3, 3), on the device
+                ch = W.shape[1] - prev
+                Wt = W[:, ch:].transpose(0, 1).flip(2, 3).contiguous()
+                bwd[name] = ops.Conv(Wt, None, pad=1, relu=False, device=W.device, dtype=self.dtype)
+                prev = W.shape[0]
+            for p in range(self.total, 0, -1):
+                name = 'up_conv%d' % p
+                W = self.dec[name].W
+                bwd[name] = ops.Conv(W.transpose(0, 1).flip(2, 3).contiguous(), None, pad=1,
+                                     relu=False, device=W.device, dtype=self.dtype)
+            self._bwd = bwd
+        return self._bwd
+
+    def backward_y(self, g_score, y_shape):
+        """dE/dy THROUGH the DAE for an upstream gradient g_score w.r.t. the (cropped) score map
+        of the latest `scores()` call; adjoint of that forward, level by level (oracle/dae_grad.py).
+        Full maps (the decoder / encoder windows of the forward are not exploited here)."""
+        bwd = self._bwd_convs()
+        override, pre, pool = self._saved
+        B = g_score.shape[0]
+        dev, dt = g_score.device, g_score.dtype
+        g_pool = {}
+        g_f = g_score
+        for p in range(1, self.total + 1):               # decoder, output to input
+            mpre, mpool = pre[p], pool[p]
+            if override and p in override:
+                mpre, mpool = override[p]
+            ph, pw = pre[p].shape[2], pre[p].shape[3]
+            other_hw = (pool[p - 1].shape[2], pool[p - 1].shape[3]) if p > 1 else \
+                (y_shape[2], y_shape[3])
+            oh, ow = min(ph, other_hw[0]), min(pw, other_hw[1])
+            cy, cx = _center(ph, oh), _center(pw, ow)
+            g_c = torch.zeros((B, g_f.shape[1], ph, pw), dtype=dt, device=dev)
+            g_c[:, :, cy:cy + oh, cx:cx + ow].copy_(g_f)           # adjoint of the center crop
+            if self.skip and p > 1:                                 # adjoint of the skip sum
+                gp = torch.zeros_like(pool[p - 1])
+                oy, ox = _center(other_hw[0], oh), _center(other_hw[1], ow)
+                gp[:, :, oy:oy + oh, ox:ox + ow].copy_(g_f)
+                g_pool[p - 1] = gp
+            g_u = bwd['up_conv%d' % p](g_c)
+            g_f = ops.depool_bwd(g_u, mpre, mpool)
+        g_pool[self.total] = g_f
+        g_in = None
+        for p in range(self.total, 0, -1):               # encoder, deep to shallow
+            gp = g_pool.get(p)
+            if gp is None:
+                gp = torch.zeros_like(pool[p])
+            g_z = ops.pool_relu_bwd(gp, pre[p], pool[p])
+            conv = bwd['conv%d_1' % p]
+            if p > 1:
+                acc = g_pool.get(p - 1)
+                g_pool[p - 1] = conv(g_z) if acc is None else conv(g_z, add=acc, out=acc)
+            else:
+                fwd = self.enc['conv1_1']
+                if fwd.pad != 1:      # pad-100 first layer: crop at offset pad - 1
+                    g_in = conv(g_z, window=(fwd.pad - 1, fwd.pad - 1, y_shape[2], y_shape[3]))
+                else:
+                    g_in = conv(g_z)
+        return g_in
 
     def _rand(self, kind, level, name, shape, like):
         if self.random_source is not None:

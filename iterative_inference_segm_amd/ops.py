@@ -419,6 +419,50 @@ def refine_update(score, y, state, step, off=None):
                                    H, W, float(step)), 'iiseg_refine_update')
 
 
+def sqerr_softmax_bwd(score, y, off=None):
+    """dE/dscore for E = sum (softmax(score window) - y)^2 (true-gradient mode)."""
+    B, Cc, SH, SW = score.shape
+    H, W = y.shape[2], y.shape[3]
+    sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
+    dt = y.dtype
+    g = torch.empty_like(y)
+    check(_fn('sqerr_softmax_bwd', dt)(_stream(), _ptr(score, dt), _ptr(y, dt), _ptr(g, dt), B, Cc,
+                                       SH, SW, sy0, sx0, H, W), 'iiseg_sqerr_softmax_bwd')
+    return g
+
+
+def depool_bwd(gout, pre, pooled):
+    """Adjoint of DePool2D w.r.t. its input: masked 2x2 sum of gout (B,C,H,W) -> (B,C,H/2,W/2)."""
+    dt = gout.dtype
+    B, Cc, H, W = pre.shape
+    out = torch.empty_like(pooled)
+    check(_fn('depool_bwd', dt)(_stream(), _ptr(gout, dt), _ptr(pre, dt), _ptr(pooled, dt),
+                                _ptr(out, dt), B * Cc, H, W), 'iiseg_depool_bwd')
+    return out
+
+
+def pool_relu_bwd(gpool, pre, pooled):
+    """Adjoint of maxpool2x2(relu(z)) w.r.t. z, given pre = relu(z) and pooled."""
+    dt = gpool.dtype
+    B, Cc, H, W = pre.shape
+    out = torch.empty_like(pre)
+    check(_fn('pool_relu_bwd', dt)(_stream(), _ptr(gpool, dt), _ptr(pre, dt), _ptr(pooled, dt),
+                                   _ptr(out, dt), B * Cc, H, W), 'iiseg_pool_relu_bwd')
+    return out
+
+
+def grad_update(score, gthrough, y, state, step, off=None):
+    """True-gradient step on y (in place): grad = gthrough - 2 (softmax(score) - y)."""
+    B, Cc, SH, SW = score.shape
+    H, W = y.shape[2], y.shape[3]
+    sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
+    dt = y.dtype
+    check(_fn('grad_update', dt)(_stream(), _ptr(score, dt), _ptr(gthrough, dt), _ptr(y, dt),
+                                 _ptr(state.active, torch.int32),
+                                 _ptr(state.partial, torch.float64), B, Cc, SH, SW, sy0, sx0, H, W,
+                                 float(step)), 'iiseg_grad_update')
+
+
 def refine_finalize(state, eps):
     lib = _lib.load()
     check(lib.iiseg_refine_finalize(_stream(), _ptr(state.partial, torch.float64),

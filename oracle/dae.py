@@ -81,6 +81,7 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
                 pad = 1                                      # 'same' for 3x3
             name = 'conv%d_%d' % (p + 1, i)
             t = nn.conv2d(t, params[name][0], params[name][1], pad=pad, relu=True)  # :102-104
+            net['_act_' + name] = t
             if bn:
                 t = _bn_avg(t, params[name + '_bn'])         # :112-114
         pre[p + 1] = t

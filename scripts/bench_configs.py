@@ -5,7 +5,8 @@
   c5: FCN-8 + generalised standard DAE, concat_h=[pool3, pool4] (256 + 512 ch), pad-100, 50 steps,
       224x224, batch 64 (SURVEY A9' variant (ii), build-defined)
   c5ctx: FCN-8 + contextmod DAE with concat_h=[input], 50 steps (A9' variant (i))
-Usage: python scripts/bench_configs.py [c3|c2_f64|c4|c5|c5ctx] [reps]"""
+  c2_grad: configs[1] in the true-gradient mode (extension): forward + hand-written backward per step
+Usage: python scripts/bench_configs.py [c3|c2_f64|c4|c5|c5ctx|c2_grad] [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,12 +16,15 @@ from iterative_inference_segm_amd.dae import StandardDAE
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-size, steps = (224, 224), 10
-if which in ('c4', 'c5', 'c5ctx'):
+size, steps, mode = (224, 224), 10, 'residual'
+if which in ('c4', 'c5', 'c5ctx', 'c2_grad'):
     from iterative_inference_segm_amd.fcn8 import FCN8
     dt = torch.float32
     if which == 'c4':
         B, gflop, size, concat_h = 32, 1867.8, (360, 480), ['pool4']
+        dae = StandardDAE(S.make_dae_params(), 11)
+    elif which == 'c2_grad':
+        B, gflop, concat_h, mode = 64, float('nan'), ['pool4'], 'gradient'
         dae = StandardDAE(S.make_dae_params(), 11)
     elif which == 'c5':
         B, gflop, steps, concat_h = 64, float('nan'), 50, ['pool3', 'pool4']
@@ -47,7 +51,8 @@ state = {'i': 0}
 def step():
     X = Xs[state['i'] % 3]; state['i'] += 1      # a different image batch every step
     out = ii.pred_fcn_fn(X)
-    ii.refine(out[:-1], out[-1], 0.1, steps, early_stop=False)
+    ii.refine(out[:-1], out[-1], 0.1 if mode == 'residual' else 0.01, steps, early_stop=False,
+              mode=mode)
 step(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(reps):

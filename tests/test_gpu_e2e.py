@@ -455,6 +455,52 @@ def test_noise_mask_emulation(built_lib, dtype, tol):
     assert np.array_equal(ra, rb) and np.abs(ra - det).max() > 1e-3
 
 
+@pytest.mark.parametrize('dtype,tol', [(torch.float64, 1e-10), (torch.float32, 2e-4)])
+@pytest.mark.parametrize('skip', [True, False])
+def test_true_gradient_mode(built_lib, dtype, tol, skip):
+    """Extension: dE/dy of E = sum (r(y|h) - y)^2 by the hand-written HIP
+    backward pass (flipped-filter convs, DePool2D / maxpool+ReLU adjoints, softmax backward) against
+    the oracle's backward (itself pinned by finite differences, tests/test_oracle_grad.py), and two
+    steps of the gradient-mode refinement loop."""
+    from oracle import dae_grad as G
+    from iterative_inference_segm_amd import ops
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    concat_h = ['pool2']
+    rng = np.random.default_rng(91)
+    size, hc, nf = (24, 32), 5, 16          # 16 filters: the deep backward convs take the Winograd path
+    kw = dict(concat_h=concat_h, n_filters=nf, additional_pool=1, skip=skip)
+    dp = S.make_dae_params(h_channels=(hc,), concat_h=concat_h, n_filters=nf, additional_pool=1,
+                           seed=92)
+    y = rng.random((2, 11) + size); y /= y.sum(1, keepdims=True)
+    h = rng.random((2, hc, (size[0] + 198) // 4, (size[1] + 198) // 4))
+    g_ref, r_ref = G.dae_sqerr_grad(to64(dp), [h], y, **kw)
+    dae = StandardDAE(dp, 11, dtype=dtype, **kw)
+    yt = torch.from_numpy(y).to(dtype).cuda()
+    ht = torch.from_numpy(h).to(dtype).cuda()
+    score = dae.scores([ht], yt)
+    r = ops.crop_softmax(score, size[0], size[1], off=(0, 0))
+    g_thr = dae.backward_y(ops.sqerr_softmax_bwd(score, yt, off=(0, 0)), yt.shape)
+    got = host(g_thr) - 2.0 * (host(r) - y)
+    scale = 1 + np.abs(g_ref).max()
+    assert np.abs(got - g_ref).max() <= tol * scale
+    # the loop: y <- clip(y - step * grad, 0, 1), stop on mean_px ||grad||_2
+    ii = IterativeInference(None, dae, 11, [11], dtype=dtype)
+    Yii, iters, norms = ii.refine([ht], yt, 0.05, 2, mode='gradient')
+    yy = y.copy()
+    for _ in range(2):
+        g, _ = G.dae_sqerr_grad(to64(dp), [h], yy, **kw)
+        last = np.linalg.norm(g, axis=1).mean(axis=(1, 2))
+        yy = np.clip(yy - 0.05 * g, 0.0, 1.0)
+    assert list(host(iters)) == [2, 2]
+    assert np.abs(host(Yii) - yy).max() <= tol * scale
+    assert np.abs(host(norms) - last).max() <= tol * scale
+    # the descent direction lowers the reconstruction error
+    e0 = ((r_ref - y) ** 2).sum()
+    e2 = G.sqerr(to64(dp), [h], host(Yii).astype(np.float64), **kw)
+    assert e2 < e0
+
+
 def test_multi_concat_standard_dae(built_lib):
     """Config-5 variant (SURVEY A9', build-defined): standard DAE with h concatenated after pool3
     AND pool4 (per-concat channel counts), pad-100 applied (`pad_multi_concat`), conv_before_pool=2;
