@@ -996,13 +996,16 @@ int gemm_conv_geom(const iiseg_conv_desc* d, GemmConvGeom& g) {
         return IISEG_ERR_UNSUPPORTED;
     g.T = (int)T;
     g.Tpad = (int)Tpad;
-    // split-K: the divisor S of Kpad/16 (<= 16) that wastes the least of the last round of 256 CUs
+    // split-K: the divisor S of Kpad/16 (<= 16) minimising  GEMM time (rounds of 256 CUs at the
+    // measured 131 TFLOP/s) + the traffic of writing and re-reading the S partial products (5 TB/s)
     const int tiles = (g.Tpad / 128) * (g.Mpad / g.bm), units = g.Kpad / 16;
+    const double tile_s = 2.0 * g.Kpad * g.bm * 128 / (131e12 / 256);
+    const double red_s = 8.0 * g.Mpad * g.Tpad / 5e12;
     double best = 1e30;
     g.S = 1;
     for (int S = 1; S <= 16; ++S) {
         if (units % S || units / S < 8) continue;
-        const double cost = (double)((S * tiles + 255) / 256) / S + 0.002 * S;  // + reduce traffic
+        const double cost = (double)((S * tiles + 255) / 256) / S * tile_s + S * red_s;
         if (cost < best) { best = cost; g.S = S; }
     }
     g.Kc = g.Kpad / g.S;

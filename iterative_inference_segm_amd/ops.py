@@ -235,7 +235,11 @@ class Conv:
         if self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof,
                                    ev0 if prof is not None else None)
-        if self.kernel == 'conv_igemm_f32_kernel' and CONV_GEMM and x2 is None and not unpool and \
+        gemm_shape = self.kernel == 'conv_igemm_f32_kernel' or (
+            # deep 1x1 layers on few pixels (fc7): the same split-K GEMM beats the 1x1 tap kernel
+            dt == torch.float32 and (self.KH, self.KW) == (1, 1) and self.Cin >= 1024 and
+            self.Cout >= 128)
+        if gemm_shape and CONV_GEMM and x2 is None and not unpool and \
                 add is None and self.lib.iiseg_conv_gemm_supported(C.byref(d)):
             ws = _wino_workspace(self.lib.iiseg_conv_gemm_workspace_elems(C.byref(d)), x1.device)
             args = (C.byref(d), _ptr(x1), _ptr(wp), _ptr(self.b), _ptr(ws), _ptr(out))
