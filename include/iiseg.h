@@ -296,8 +296,9 @@ int iiseg_dropout_apply_f64(void* stream, double* x, const double* keep, double 
  *   stats : mean[c], inv_std[c] = 1/sqrt(biased_var + eps) over (B,H,W) for c < C
  *   apply : out[b,c] = max((x[b,c] - mean[c]) * (gamma[c] * inv_std[c]) + beta[c], 0), out dense
  * ------------------------------------------------------------------------------------- */
+int64_t iiseg_bn_stats_workspace_elems(int32_t C); /* doubles of caller-owned workspace */
 int iiseg_bn_stats_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
-                       int32_t HW, float eps, float* mean, float* inv_std);
+                       int32_t HW, float eps, float* mean, float* inv_std, double* workspace);
 int iiseg_bn_relu_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
                       int32_t HW, const float* beta, const float* gamma, const float* mean,
                       const float* inv_std, float* out);
@@ -312,7 +313,7 @@ int iiseg_bn_affine_window_f64(void* stream, double* x, int32_t B, int32_t C, in
                                int32_t y0, int32_t x0, int32_t wh, int32_t ww, const double* beta,
                                const double* gamma, const double* mean, const double* inv_std);
 int iiseg_bn_stats_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,
-                       int32_t HW, double eps, double* mean, double* inv_std);
+                       int32_t HW, double eps, double* mean, double* inv_std, double* workspace);
 int iiseg_bn_relu_f64(void* stream, const double* x, int64_t bstride, int32_t B, int32_t C,
                       int32_t HW, const double* beta, const double* gamma, const double* mean,
                       const double* inv_std, double* out);

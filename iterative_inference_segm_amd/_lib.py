@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -67,9 +67,10 @@ SIGNATURES = {
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
     'iiseg_confusion_masked_f32': (C.c_int, [_vp] * 6 + [_i32] * 3),
     'iiseg_confusion_masked_f64': (C.c_int, [_vp] * 6 + [_i32] * 3),
-    'iiseg_bn_stats_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp]),
+    'iiseg_bn_stats_workspace_elems': (_i64, [_i32]),
+    'iiseg_bn_stats_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     'iiseg_bn_relu_f32': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
-    'iiseg_bn_stats_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _vp]),
+    'iiseg_bn_stats_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _f64, _vp, _vp, _vp]),
     'iiseg_bn_relu_f64': (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32] + [_vp] * 5),
     'iiseg_sqerr_softmax_bwd_f32': (C.c_int, [_vp] * 4 + [_i32] * 8),
     'iiseg_sqerr_softmax_bwd_f64': (C.c_int, [_vp] * 4 + [_i32] * 8),

@@ -2,27 +2,34 @@
 // Replaces lasagne BatchNormLayer with batch_norm_use_averages=False (reference
 // iterative_inference.py:187; SURVEY P10: batch mean, biased variance over (B,H,W), eps 1e-4) and
 // the rectify that follows it in BN_ReLU_Conv (FC_DenseNet.layers, models/FCDenseNet.py:12).
-// stats: one workgroup per channel, fp64 accumulation, fixed reduction order (deterministic);
+// stats: 64 workgroups per channel + a finalize pass, fp64 accumulation, fixed reduction order
+// (deterministic);
 // apply: HBM-bound element-wise kernel.  A channel's statistics never change once the channel is
 // in the stack, so the host computes them once per produced tensor, not once per consumer.
 #include "common.h"
 
 namespace {
 
+// stats, stage 1: block (chunk, channel) reduces its slice of the B*HW elements of one channel to
+// (sum, sum of squares) in fp64; stage 2: one thread per channel adds the NCHUNK partials in a
+// fixed order (deterministic, no atomics) and writes mean / inv_std.  (A single workgroup per
+// channel left 240 of the 256 CUs idle for the 16-channel tensors of FC-DenseNet.)
+constexpr int BN_NCHUNK = 64;
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t bstride,
-                                                       int B, int HW, double eps,
-                                                       T* __restrict__ mean, T* __restrict__ inv_std) {
+                                                       int B, int HW, double* __restrict__ partial) {
     __shared__ double red[2][4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.y, chunk = blockIdx.x;
+    const size_t n = (size_t)B * HW;
+    const size_t per = (n + BN_NCHUNK - 1) / BN_NCHUNK;
+    const size_t lo = (size_t)chunk * per, hi = lo + per < n ? lo + per : n;
     double s = 0.0, ss = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const T* xp = x + (size_t)b * bstride + (size_t)c * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            const double v = (double)xp[i];
-            s += v;
-            ss += v * v;
-        }
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const size_t b = i / HW, r = i - b * HW;
+        const double v = (double)x[b * bstride + (size_t)c * HW + r];
+        s += v;
+        ss += v * v;
     }
     s = wave_sum(s);
     ss = wave_sum(ss);
@@ -32,13 +39,26 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double n = (double)B * HW;
-        const double m = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
-        double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[c] = (T)m;
-        inv_std[c] = (T)(1.0 / sqrt(var + eps));
+        partial[((size_t)c * BN_NCHUNK + chunk) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[((size_t)c * BN_NCHUNK + chunk) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
+}
+
+template <typename T>
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int C, double n,
+                                         double eps, T* __restrict__ mean, T* __restrict__ inv_std) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < BN_NCHUNK; ++k) {
+        s += partial[((size_t)c * BN_NCHUNK + k) * 2 + 0];
+        ss += partial[((size_t)c * BN_NCHUNK + k) * 2 + 1];
+    }
+    const double m = s / n;
+    double var = ss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (T)m;
+    inv_std[c] = (T)(1.0 / sqrt(var + eps));
 }
 
 template <typename T>
@@ -97,11 +117,14 @@ int bn_affine_window(void* stream, T* x, int32_t B, int32_t C, int32_t H, int32_
 
 template <typename T>
 int bn_stats(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, int32_t HW, double eps,
-             T* mean, T* inv_std) {
-    if (!x || !mean || !inv_std) return IISEG_ERR_NULL;
+             T* mean, T* inv_std, double* workspace) {
+    if (!x || !mean || !inv_std || !workspace) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || HW <= 0 || bstride < (int64_t)C * HW) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, bstride, B,
-                       HW, eps, mean, inv_std);
+    if (C > 65535) return IISEG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(BN_NCHUNK, C), dim3(256), 0, (hipStream_t)stream, x,
+                       bstride, B, HW, workspace);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel<T>, dim3((C + 63) / 64), dim3(64), 0,
+                       (hipStream_t)stream, workspace, C, (double)B * HW, eps, mean, inv_std);
     return iiseg_check_launch();
 }
 
@@ -120,13 +143,16 @@ int bn_relu(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, int
 
 }  // namespace
 
+extern "C" int64_t iiseg_bn_stats_workspace_elems(int32_t C) { return (int64_t)C * BN_NCHUNK * 2; }
 extern "C" int iiseg_bn_stats_f32(void* stream, const float* x, int64_t bstride, int32_t B,
-                                  int32_t C, int32_t HW, float eps, float* mean, float* inv_std) {
-    return bn_stats<float>(stream, x, bstride, B, C, HW, (double)eps, mean, inv_std);
+                                  int32_t C, int32_t HW, float eps, float* mean, float* inv_std,
+                                  double* workspace) {
+    return bn_stats<float>(stream, x, bstride, B, C, HW, (double)eps, mean, inv_std, workspace);
 }
 extern "C" int iiseg_bn_stats_f64(void* stream, const double* x, int64_t bstride, int32_t B,
-                                  int32_t C, int32_t HW, double eps, double* mean, double* inv_std) {
-    return bn_stats<double>(stream, x, bstride, B, C, HW, eps, mean, inv_std);
+                                  int32_t C, int32_t HW, double eps, double* mean, double* inv_std,
+                                  double* workspace) {
+    return bn_stats<double>(stream, x, bstride, B, C, HW, eps, mean, inv_std, workspace);
 }
 extern "C" int iiseg_bn_relu_f32(void* stream, const float* x, int64_t bstride, int32_t B, int32_t C,
                                  int32_t HW, const float* beta, const float* gamma,

@@ -494,6 +494,9 @@ def confusion_accumulate(y, t, cm, sums, active=None):
                                _ptr(sums, torch.float64), B, Cc, H * W), 'iiseg_confusion')
 
 
+_bn_ws = {}   # device -> partial-sum workspace (stream-ordered reuse)
+
+
 def bn_stats(buf, c0, n, mean, inv_std, eps=1e-4):
     """Batch statistics (P10) of channels [c0, c0+n) of `buf` (B, Ctot, H, W) into
     mean[c0:c0+n], inv_std[c0:c0+n] (1-D tensors of length >= c0+n)."""
@@ -502,9 +505,14 @@ def bn_stats(buf, c0, n, mean, inv_std, eps=1e-4):
     item = buf.element_size()
     _ptr(buf, dt), _ptr(mean, dt), _ptr(inv_std, dt)
     xp = C.c_void_p(buf.data_ptr() + c0 * H * W * item)
+    ws = _bn_ws.get(buf.device)
+    need = _lib.load().iiseg_bn_stats_workspace_elems(n)
+    if ws is None or ws.numel() < need:
+        ws = _bn_ws[buf.device] = torch.empty(int(need), dtype=torch.float64, device=buf.device)
     check(_fn('bn_stats', dt)(_stream(), xp, Ctot * H * W, B, n, H * W, float(eps),
                               C.c_void_p(mean.data_ptr() + c0 * item),
-                              C.c_void_p(inv_std.data_ptr() + c0 * item)), 'iiseg_bn_stats')
+                              C.c_void_p(inv_std.data_ptr() + c0 * item),
+                              _ptr(ws, torch.float64)), 'iiseg_bn_stats')
 
 
 def bn_relu(buf, n, beta, gamma, mean, inv_std, out=None):
