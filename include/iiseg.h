@@ -106,6 +106,17 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
                    const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
                    const float* bias, const float* add, float* out);
 
+/* iiseg_conv_f32 that also writes the 2x2/2 max-pool (ignore_border) of its output: the
+ * Pool2DLayer that follows the conv (models/fcn_down.py:122, models/fcn8.py:38-45) fused into the
+ * epilogue of the halo-tile kernel, saving the pool kernel's read of the full-resolution map.
+ * pool_out is the FULL pooled tensor (B, Cout, fullH/2, fullW/2); the pooled positions of the
+ * computed window are written in place.  Supported (iiseg_conv_pool_supported) for the 3x3 layers
+ * the halo kernel takes (16 < Cout < 256) with an even window origin and whole pooling windows. */
+int iiseg_conv_pool_supported(const iiseg_conv_desc* d);
+int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                        const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
+                        const float* bias, const float* add, float* out, float* pool_out);
+
 /* Winograd F(2x2,3x3) form of the same convolution (same call sites as iiseg_conv_f32 for
  * 3x3, dil 1, stride 1 layers with (C1+C2) % 16 == 0, no TRANSPOSED2; with IISEG_CONV_UNPOOL the
  * DePool2D mask is applied while the input transform loads its 4x4 patches, operands as in

@@ -42,6 +42,8 @@ struct ConvParams {
     int out_ctot, out_c0;  // destination channel slice (out_ctot == Cout, out_c0 == 0: dense)
     int transposed;        // 3x3 stride-2 transposed convolution (conv_taps only)
     int out_H, out_W, out_y0, out_x0;  // destination planes / placement (dense: OH, OW, 0, 0)
+    float* pool;           // fused 2x2 max-pool of the output (conv_halo only), full (fullH/2, fullW/2) planes
+    int pool_H, pool_W;
 };
 
 // Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give

@@ -217,8 +217,44 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
     // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store ---------------------------
     // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh
     const int wx = wx0 + l31;
-    if (wx >= p.OW) return;
     const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    if (p.pool) {
+        // fused 2x2 max-pool: a wave owns the row pairs (2m, 2m+1) of its rows (window origin and
+        // RW are even), the column pair is the neighbouring lane.  No lane leaves early here: the
+        // cross-lane max needs every lane; stores are predicated.
+        static_assert(TN % 2 == 0, "row pairs");
+        const size_t PPL = (size_t)p.pool_H * p.pool_W;
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+            const int wy = wy0 + wn * RW + j;
+            const bool ok0 = wy < p.OH && wx < p.OW, ok1 = wy + 1 < p.OH && wx < p.OW;
+            float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                          (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+            const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
+            const bool okp = ok1 && wx + 1 < p.OW && !(l31 & 1) && py < p.pool_H && px < p.pool_W;
+            float* poolp = p.pool + (size_t)b * p.Cout * PPL + (size_t)py * p.pool_W + px;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float bias = p.bias ? p.bias[min(co, p.Cout - 1)] : 0.f;
+                    float v0 = acc[i][j][r] + bias, v1 = acc[i][j + 1][r] + bias;
+                    if (p.relu) {
+                        v0 = fmaxf(v0, 0.f);
+                        v1 = fmaxf(v1, 0.f);
+                    }
+                    const bool cv = co < p.Cout;
+                    if (cv && ok0) outp[(size_t)co * OPL] = v0;
+                    if (cv && ok1) outp[(size_t)co * OPL + p.out_W] = v1;
+                    float m = fmaxf(v0, v1);
+                    m = fmaxf(m, __shfl_xor(m, 1));
+                    if (cv && okp) poolp[(size_t)co * PPL] = m;
+                }
+        }
+        return;
+    }
+    if (wx >= p.OW) return;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int wy = wy0 + wn * RW + j;

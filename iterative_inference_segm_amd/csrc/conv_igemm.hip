@@ -410,7 +410,30 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
                               const float* x2, const float* pre, const float* pooled,
                               const float* wp, const int32_t* ktab, const float* bias,
                               const float* add, float* out) {
+    return iiseg_conv_pool_f32(stream, d, x1, x2, pre, pooled, wp, ktab, bias, add, out, nullptr);
+}
+
+extern "C" int iiseg_conv_pool_supported(const iiseg_conv_desc* d) {
+    if (!d || check_desc(d)) return 0;
+    static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
+    if (!halo || d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2) ||
+        d->Cout >= 256 || d->Cout <= 16 || d->Kpad % 36 || (d->C2 > 0 && d->C1 % 4))
+        return 0;
+    // pooling windows must be whole inside the computed window: even origin, and an even extent
+    // unless the window ends at the map's last (unpaired) row / column
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if ((d->oy0 | d->ox0) & 1) return 0;
+    if ((d->OH & 1) && d->oy0 + d->OH != fullH) return 0;
+    if ((d->OW & 1) && d->ox0 + d->OW != fullW) return 0;
+    return 1;
+}
+
+extern "C" int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
+                                   const float* x2, const float* pre, const float* pooled,
+                                   const float* wp, const int32_t* ktab, const float* bias,
+                                   const float* add, float* out, float* pool_out) {
     int st = check_desc(d);
+    if (pool_out && !iiseg_conv_pool_supported(d)) return IISEG_ERR_UNSUPPORTED;
     if (st) return st;
     if (!x1 || !wp || !ktab || !out) return IISEG_ERR_NULL;
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
@@ -432,6 +455,9 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     p.Kpad = d->Kpad; p.Mpad = d->Mpad;
     p.pad = d->pad; p.dil = d->dil;
     p.debug_nogather = 0;
+    p.pool = pool_out;
+    p.pool_H = (d->H + 2 * d->pad - d->dil * (d->KH - 1)) / 2;
+    p.pool_W = (d->W + 2 * d->pad - d->dil * (d->KW - 1)) / 2;
     p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
     p.out_c0 = d->out_ctot ? d->out_c0 : 0;
     p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
@@ -446,8 +472,9 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     hipStream_t s = (hipStream_t)stream;
     // IISEG_CONV_HALO: 0 = never, 1 = 3x3 layers with Cout < 256 (default), 2 = every 3x3 layer
     static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
-    if (halo && (halo > 1 || d->Cout < 256) && iiseg_conv_halo_ok(p, d->KH, d->KW))
-        return iiseg_launch_conv_halo(s, p, pick_bm(d->Cout), unpool);
+    const bool use_halo = halo && (halo > 1 || d->Cout < 256) && iiseg_conv_halo_ok(p, d->KH, d->KW);
+    if (pool_out && (!use_halo || add || d->Cout <= 16)) return IISEG_ERR_UNSUPPORTED;
+    if (use_halo) return iiseg_launch_conv_halo(s, p, pick_bm(d->Cout), unpool);
     if (iiseg_taps_cpt(d->KH, d->KW) > 0)
         return iiseg_launch_conv_taps(s, p, d->KH, d->KW, pick_bm(d->Cout), unpool);
     switch (pick_bm(d->Cout)) {

@@ -204,6 +204,7 @@ class StandardDAE:
             return lo, max(hi - lo, 0)
 
         for p in range(self.total):                      # fcn_down.py:77-136
+            fused_pool = None
             for i in range(1, self.conv_before_pool + 1):
                 name = 'conv%d_%d' % (p + 1, i)
                 conv = self.enc[name]
@@ -248,6 +249,22 @@ class StandardDAE:
                     t = conv(pending_h, x2=t, **kw)
                     pending_h = None
                 else:
+                    # last conv of the level on the halo kernel: its epilogue also writes pool_p
+                    # (the window is widened to whole pooling windows; the extra row / column is
+                    # recomputed to the values it already has)
+                    pw_ = None
+                    if i == self.conv_before_pool and not self.bn:
+                        pw_ = conv.pool_window(t.shape[2], t.shape[3], dep if primed else None)
+                    if pw_ is not None:
+                        fh, fw = conv.out_hw(t.shape[2], t.shape[3])
+                        if primed:
+                            pooled_t = session['pool%d' % (p + 1)]
+                            kw.update(window=pw_, place=(pw_[0], pw_[1]))
+                        else:
+                            pooled_t = torch.empty((t.shape[0], conv.Cout, fh // 2, fw // 2),
+                                                   dtype=t.dtype, device=t.device)
+                        fused_pool = pooled_t
+                        kw['pool_out'] = pooled_t
                     t = conv(t, **kw)
                 if self.bn:
                     ops.bn_affine(t, self.enc_bn[name], window=dep if primed else None)
@@ -263,9 +280,9 @@ class StandardDAE:
                 qy0, qh = clip(dep[0] // 2, (dep[0] + dep[2] + 1) // 2, buf.shape[2])
                 qx0, qw = clip(dep[1] // 2, (dep[1] + dep[3] + 1) // 2, buf.shape[3])
                 dep = (qy0, qx0, qh, qw)
-                t = ops.maxpool2x2(t, out=buf, window=dep)
+                t = buf if fused_pool is not None else ops.maxpool2x2(t, out=buf, window=dep)
             else:
-                t = ops.maxpool2x2(t)                    # :122
+                t = fused_pool if fused_pool is not None else ops.maxpool2x2(t)   # :122
                 if session is not None:
                     session['pool%d' % (p + 1)] = t
             pool[p + 1] = t

@@ -108,6 +108,7 @@ class FCN8:
         deps = {}
         pending = hs.get('input')
         for bi, names in enumerate(_BLOCKS):
+            fused_pool = None
             for name in names:
                 conv = self.convs[name]
                 fh, fw = conv.out_hw(t.shape[2], t.shape[3])
@@ -116,6 +117,17 @@ class FCN8:
                 kw = dict(anchor=(dep[0], dep[1]))
                 if primed:
                     kw.update(window=dep, out=session[name], place=(dep[0], dep[1]))
+                if name == names[-1] and pending is None:
+                    # last conv of the block on the halo kernel: the pool rides in its epilogue
+                    pw_ = conv.pool_window(t.shape[2], t.shape[3], dep if primed else None)
+                    if pw_ is not None:
+                        if primed:
+                            fused_pool = session['pool%d' % (bi + 1)]
+                            kw.update(window=pw_, place=(pw_[0], pw_[1]))
+                        else:
+                            fused_pool = torch.empty((t.shape[0], conv.Cout, fh // 2, fw // 2),
+                                                     dtype=t.dtype, device=t.device)
+                        kw['pool_out'] = fused_pool
                 if pending is not None:
                     t = self._conv(name, pending, x2=t, **kw)
                     pending = None
@@ -125,7 +137,11 @@ class FCN8:
                     session[name] = t
             pname = 'pool%d' % (bi + 1)
             dep = _pool_region(dep, t.shape[2] // 2, t.shape[3] // 2)
-            if primed:
+            if fused_pool is not None:
+                t = fused_pool
+                if session is not None and not primed:
+                    session[pname] = t
+            elif primed:
                 t = ops.maxpool2x2(t, out=session[pname], window=dep)   # :38,45,54,63,72
             else:
                 t = ops.maxpool2x2(t)

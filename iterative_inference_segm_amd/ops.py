@@ -28,6 +28,8 @@ WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
 # transform (products stay in registers, no M round trip through HBM); deeper layers are
 # MFMA-bound and run faster on the plain 256x128 GEMM + separate output transform.  0: never.
 WINO_FUSED_MAX_CIN = int(os.environ.get('IISEG_WINO_FUSED_MAX_CIN', '256'))
+# fuse the 2x2 max-pool behind a halo-kernel conv into that conv's epilogue
+POOL_FUSE = os.environ.get('IISEG_POOL_FUSE', '1') != '0'
 # 'valid' KxK layers without a static-tap variant (7x7 fc6) as im2col + split-K GEMM
 CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
@@ -171,7 +173,7 @@ class Conv:
         return plan
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
-                 window=None, out=None, out_c0=None, place=None, anchor=(0, 0)):
+                 window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
@@ -180,7 +182,9 @@ class Conv:
         `place` = (y0, x0) the (OH, OW) result is written at that offset of the larger planes of
         `out` (everything else in `out` is left untouched).  `anchor` = parity of the output
         row / column where the Winograd 2x2 tiles start (a per-layer constant for the caller:
-        launches of one layer agree bit for bit only under the same anchor)."""
+        launches of one layer agree bit for bit only under the same anchor).  `pool_out`: the FULL
+        pooled tensor (B, Cout, fullH//2, fullW//2) of this layer; the 2x2 max-pool of the computed
+        window is written into it by the conv's epilogue (see `pool_window`)."""
         dt = self.dtype
         unpool = pre is not None
         B, C1 = x1.shape[0], x1.shape[1]
@@ -232,9 +236,22 @@ class Conv:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
+        if pool_out is None and self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof,
                                    ev0 if prof is not None else None)
+        if pool_out is not None:
+            fh, fw = self.out_hw(H, W)
+            if dt != torch.float32 or tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2) or \
+                    not self.lib.iiseg_conv_pool_supported(C.byref(d)):
+                raise RuntimeError('conv + pool fusion is not available for this launch')
+            check(self.lib.iiseg_conv_pool_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
+                                               _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
+                                               _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out)),
+                  'iiseg_conv_pool_f32')
+            if prof is not None:
+                ev1.record()
+                prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
+            return out
         gemm_shape = self.kernel == 'conv_igemm_f32_kernel' or (
             # deep 1x1 layers on few pixels (fc7): the same split-K GEMM beats the 1x1 tap kernel
             dt == torch.float32 and (self.KH, self.KW) == (1, 1) and self.Cin >= 1024 and
@@ -271,6 +288,25 @@ class Conv:
             prof.append((kern, self.flops(B, d.OH, d.OW), ev0, ev1))
         return out
 
+
+    def pool_window(self, H, W, region=None):
+        """If the 2x2 max-pool that follows this layer can be fused into its epilogue: the conv
+        window (y0, x0, h, w) to launch so that every pooling window touching `region` (of the
+        conv output; None = the whole map) is whole -- even origin, even extent unless it ends at
+        the map's last row / column.  None if the layer does not run on the halo kernel."""
+        if not POOL_FUSE or self.dtype != torch.float32 or self.wino or \
+                self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256:
+            return None
+        fh, fw = self.out_hw(H, W)
+        if region is None:
+            return (0, 0, fh, fw)
+        y0, x0 = region[0] & ~1, region[1] & ~1
+        y1, x1 = min((region[0] + region[2] + 1) & ~1, fh), min((region[1] + region[3] + 1) & ~1, fw)
+        if region[0] + region[2] == fh:
+            y1 = fh
+        if region[1] + region[3] == fw:
+            x1 = fw
+        return (y0, x0, y1 - y0, x1 - x0)
 
     def _call_wino(self, d, x1, x2, pre, pooled, add, out, prof, ev0):
         """Winograd F(2x2,3x3) form of the layer (include/iiseg.h, iiseg_conv_wino_f32)."""

@@ -214,6 +214,38 @@ def test_conv_winograd_fused_unpool(ops, shape, cout, fused_max, monkeypatch):
             assert np.array_equal(win, full[:, :, y0:y0 + h, x0:x0 + w]), (anchor, y0, x0)
 
 
+@pytest.mark.parametrize('case', [(2, 5, 21, 19, 40, 3), (1, 12, 16, 70, 100, 1), (2, 8, 9, 9, 64, 5)])
+def test_conv_with_fused_pool_is_bit_exact(ops, case):
+    """The 2x2 max-pool fused into the halo kernel's epilogue (iiseg_conv_pool_f32) == the pool
+    kernel applied to the conv output, bit for bit, for the full map and for windows widened to
+    whole pooling windows (`Conv.pool_window`); odd map sizes leave the last row / column unpooled."""
+    B, Cin, H, W, Cout, pad = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x, w, b = rnd(rng, B, Cin, H, W), rnd(rng, Cout, Cin, 3, 3) * 0.3, rnd(rng, Cout)
+    conv = ops.Conv(w, b, pad=pad, relu=True)
+    full = conv(dev(x))
+    ref_pool = host(ops.maxpool2x2(full))
+    fh, fw = full.shape[2], full.shape[3]
+    assert conv.pool_window(H, W) == (0, 0, fh, fw)
+    pooled = torch.full((B, Cout, fh // 2, fw // 2), -3.0, device='cuda')
+    out = conv(dev(x), pool_out=pooled)
+    assert np.array_equal(host(out), host(full)) and np.array_equal(host(pooled), ref_pool)
+    for region in [(3, 5, 4, 6), (0, 1, fh, 3), (fh - 3, fw - 4, 3, 4), (2, 2, 1, 1)]:
+        win = conv.pool_window(H, W, region)
+        y0, x0, h, ww = win
+        assert y0 % 2 == 0 and x0 % 2 == 0 and y0 <= region[0] and y0 + h >= region[0] + region[2]
+        buf = torch.full_like(full, -5.0)
+        pooled = torch.full((B, Cout, fh // 2, fw // 2), -3.0, device='cuda')
+        conv(dev(x), window=win, out=buf, place=(y0, x0), pool_out=pooled)
+        bh, ph = host(buf), host(pooled)
+        assert np.array_equal(bh[:, :, y0:y0 + h, x0:x0 + ww], host(full)[:, :, y0:y0 + h, x0:x0 + ww])
+        py0, px0 = y0 // 2, x0 // 2
+        py1, px1 = min((y0 + h) // 2, fh // 2), min((x0 + ww) // 2, fw // 2)
+        assert np.array_equal(ph[:, :, py0:py1, px0:px1], ref_pool[:, :, py0:py1, px0:px1])
+        ph[:, :, py0:py1, px0:px1] = -3.0
+        assert (ph == -3.0).all(), 'pooled values written outside the window'
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 9, 7), (3, 2, 211, 13), (1, 1, 2, 2)])
 def test_maxpool_bit_exact(ops, shape):
     rng = np.random.default_rng(11)
