@@ -12,8 +12,9 @@ otherwise); inside the 10-step loop only the y-dependent part of the DAE encoder
 (the pad-100 border and the h-only contributions are loop-invariant); and the pad-100 border of the
 FCN-8 encoder maps, a function of the weights alone, is folded once per input geometry (the
 first, untimed batch) -- every timed step runs on a DIFFERENT image batch.  All are tested to give
-BIT-IDENTICAL refined maps (tests/test_gpu_e2e.py).  `full_recompute` in the JSON is the same run
-with all of them switched off (every layer recomputed in full every step, 872 GFLOP/image).
+BIT-IDENTICAL refined maps (tests/test_gpu_e2e.py).  The JSON also carries the same run with the
+cross-batch border stores off (`per_batch_only`) and with every elimination off (`full_recompute`:
+every layer recomputed in full every step, 872 nominal GFLOP/image).
 
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
@@ -201,30 +202,37 @@ def main():
         line['roofline'] = rl
         line['executed_gflop_per_image'] = round(rl['all_conv_gflop_per_step'] / B, 1)
     if not args.no_full_recompute:
-        # same timing protocol with the exact work eliminations switched off
-        ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = False
-        one_step(ii, X, T, args.num_iter, args.step_size)
-        torch.cuda.synchronize()
-        iidist.barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            one_step(ii, Xs[i % n_distinct], Ts[i % n_distinct], args.num_iter, args.step_size)
-        torch.cuda.synchronize()
-        iidist.barrier()
-        dt_full = time.perf_counter() - t1
-        if world > 1:
-            tmax = torch.tensor([dt_full], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            dt_full = float(tmax.item())
+        # same timing protocol with the exact work eliminations switched off, in two stages:
+        #   per_batch_only : nothing is kept from one batch to the next (no weights-only border
+        #                    stores); decoder DCE / in-loop invariants / h-half stay on
+        #   full_recompute : every layer of every step and batch recomputed in full
+        def timed_leg():
+            one_step(ii, X, T, args.num_iter, args.step_size)
+            torch.cuda.synchronize()
+            iidist.barrier()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(ii, Xs[i % n_distinct], Ts[i % n_distinct], args.num_iter, args.step_size)
+            torch.cuda.synchronize()
+            iidist.barrier()
+            d = time.perf_counter() - t1
+            if world > 1:
+                tmax = torch.tensor([d], dtype=torch.float64, device=device)
+                torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+                d = float(tmax.item())
+            v = world * B * args.steps / d
+            return {'value': round(v, 3), 'unit': 'images/s',
+                    'ms_per_step': round(d / args.steps * 1e3, 2),
+                    'nominal_tflops': round(v * GFLOP_PER_IMAGE / 1e3, 2)}
+        ii.fcn.fold_border = ii.dae.fold_border = False
+        line['per_batch_only'] = dict(timed_leg(), note='IISEG_FCN_BORDER_FOLD=0 '
+                                      'IISEG_DAE_BORDER_FOLD=0: no state carried between batches')
+        ii.dae.dce = ii.dae.licm = False
+        line['full_recompute'] = dict(
+            timed_leg(), note='IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
+                              'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in '
+                              'full every step and batch (same kernels)')
         ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
-        v_full = world * B * args.steps / dt_full
-        line['full_recompute'] = {
-            'value': round(v_full, 3), 'unit': 'images/s',
-            'ms_per_step': round(dt_full / args.steps * 1e3, 2),
-            'nominal_tflops': round(v_full * GFLOP_PER_IMAGE / 1e3, 2),
-            'note': 'IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
-                    'IISEG_DAE_BORDER_FOLD=0: all 872.3 '
-                    'nominal GFLOP/image recomputed in full every step and batch (same kernels)'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(fp, dp, args.num_iter, args.step_size, concat_h)
