@@ -997,10 +997,13 @@ int gemm_conv_geom(const iiseg_conv_desc* d, GemmConvGeom& g) {
     g.T = (int)T;
     g.Tpad = (int)Tpad;
     // split-K: the divisor S of Kpad/16 (<= 16) minimising  GEMM time (rounds of 256 CUs at the
-    // measured 131 TFLOP/s) + the traffic of writing and re-reading the S partial products (5 TB/s)
-    const int tiles = (g.Tpad / 128) * (g.Mpad / g.bm), units = g.Kpad / 16;
+    // measured 131 TFLOP/s) + the traffic of writing and re-reading the S partial products (5 TB/s).
+    // S fixes the association of the K sum, so it must NOT depend on the batch: it is chosen for a
+    // nominal 3200 output pixels (64 images x 7x7, the fc6 / fc7 case) whatever the real T is,
+    // which keeps an image's result independent of the images it is batched with.
+    const int tiles = 25 * (g.Mpad / g.bm), units = g.Kpad / 16;
     const double tile_s = 2.0 * g.Kpad * g.bm * 128 / (131e12 / 256);
-    const double red_s = 8.0 * g.Mpad * g.Tpad / 5e12;
+    const double red_s = 8.0 * g.Mpad * 3200 / 5e12;
     double best = 1e30;
     g.S = 1;
     for (int S = 1; S <= 16; ++S) {

@@ -168,6 +168,48 @@ def test_full_size_single_image(built_lib):
     assert agree >= 0.99 and e.mean() <= 1e-3
 
 
+def test_full_config_batch_properties(built_lib):
+    """BASELINE configs[1] at its FULL size (real FCN-8 + 64-filter DAE, 224x224, batch 64, 10
+    steps), where the oracle is too slow to run: size-independent properties instead.
+      * images are independent: an image refined inside the batch of 64 and the same
+        image refined in a batch of 3 give BIT-IDENTICAL maps (other tile partitions, other
+        Winograd tile counts, other windows of the border stores: same fixed-order sums);
+      * the maps stay probability maps: in [0, 1], FCN output sums to 1 per pixel;
+      * step = 0 leaves y untouched; a huge eps stops every image after one step;
+      * the confusion counts of val_fn add up to the number of non-void pixels."""
+    concat_h = ['pool4']
+    fp, dp = S.make_fcn8_params(), S.make_dae_params()
+    ii = build(built_lib, fp, dp, concat_h, 64)
+    B = 64
+    X = S.make_images(B, 224, 224, seed=321)
+    T = S.make_labels(B, 224, 224, seed=322)
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    Yh = host(Y)
+    assert Yh.min() >= 0 and Yh.max() <= 1 and np.abs(Yh.sum(1) - 1).max() <= 1e-5
+    Yii, iters, norms = ii.refine(H, Y, 0.1, 10, early_stop=False)
+    Yiih = host(Yii)
+    assert list(host(iters)) == [10] * B
+    assert Yiih.min() >= 0 and Yiih.max() <= 1 and np.isfinite(host(norms)).all()
+    # the same images in another batch composition (also another session / store geometry)
+    sub = [5, 17, 63]
+    jj = build(built_lib, fp, dp, concat_h, 64)
+    o2 = jj.pred_fcn_fn(X[sub])
+    assert np.array_equal(host(o2[-1]), Yh[sub]) and np.array_equal(host(o2[0]), host(H[0])[sub])
+    Y2, it2, n2 = jj.refine(o2[:-1], o2[-1], 0.1, 10, early_stop=False)
+    assert np.array_equal(host(Y2), Yiih[sub])
+    assert np.array_equal(host(n2), host(norms)[sub])
+    # step 0: nothing moves; eps huge: one step each
+    Y0, _, _ = ii.refine(H, Y, 0.0, 3, early_stop=False)
+    assert np.array_equal(host(Y0), Yh)
+    _, it1, _ = ii.refine(H, Y, 0.1, 10, eps=1e9)
+    assert list(host(it1)) == [1] * B
+    # metrics: every non-void pixel is counted exactly once
+    m = ii.val_device(Yii, T)
+    cm = m.cm.cpu().numpy().reshape(11, 12)[:, :11]
+    assert int(cm.sum()) == int((T[:, :11].sum(1) > 0.5).sum())
+
+
 def test_contextmod_dae_refine(built_lib):
     """dae kind 'contextmod' (models/contextmod_dae.py): h = the image, pad-32 + dilated convs
     (DilatedConv2DLayer layout), 5 refinement steps at 40x36, batch 2.  No pooling masks here, so
