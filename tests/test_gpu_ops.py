@@ -342,3 +342,32 @@ def test_abi_rejects_bad_arguments(ops):
         conv(dev(rnd(rng, 1, 3, 8, 8)), window=(0, 0, 9, 9))      # window outside the output
     with pytest.raises(RuntimeError, match='device tensors'):
         conv(torch.zeros(1, 3, 8, 8))
+    # the newer entry points through the raw C ABI: sizing queries answer 0 / "unsupported" for
+    # requests their kernels do not take, calls return negative statuses instead of launching
+    import ctypes as C
+    from iterative_inference_segm_amd import _lib
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.B, d.C1, d.C2, d.H, d.W, d.Cout, d.KH, d.KW, d.pad, d.dil = 1, 20, 0, 8, 8, 32, 3, 3, 1, 1
+    d.OH, d.OW = 8, 8
+    assert lib.iiseg_conv_plan(C.byref(d)) == 0
+    assert lib.iiseg_conv_wino_supported(C.byref(d)) == 0          # 20 channels: not a multiple of 16
+    assert lib.iiseg_conv_wino_weight_elems(C.byref(d)) == 0
+    assert lib.iiseg_conv_wino_f32(None, C.byref(d), None, None, None, None, None, None, None, None,
+                                   None, 7) == -5                    # IISEG_ERR_UNSUPPORTED
+    d.C1 = 32
+    assert lib.iiseg_conv_plan(C.byref(d)) == 0 and lib.iiseg_conv_wino_supported(C.byref(d)) == 1
+    assert lib.iiseg_conv_wino_f32(None, C.byref(d), None, None, None, None, None, None, None, None,
+                                   None, 7) == -1                    # IISEG_ERR_NULL
+    d.tile_y0 = 2
+    assert lib.iiseg_conv_wino_supported(C.byref(d)) == 0          # anchor parity must be 0 / 1
+    d.tile_y0 = 0
+    assert lib.iiseg_conv_gemm_supported(C.byref(d)) == 0          # padded conv: not the GEMM form
+    d.oy0, d.OH = 1, 7
+    assert lib.iiseg_conv_pool_supported(C.byref(d)) == 0          # odd window origin
+    d.oy0, d.OH = 0, 8
+    assert lib.iiseg_conv_pool_supported(C.byref(d)) == 1
+    assert lib.iiseg_strerror(-5).decode().startswith('no kernel variant')
+    assert lib.iiseg_bn_stats_workspace_elems(16) == 16 * 64 * 2
+    assert lib.iiseg_depool_bwd_f32(None, None, None, None, None, 1, 4, 4) == -1
+    assert lib.iiseg_add_noise_f32(None, None, None, 0.1, None, 10) == -1
