@@ -132,6 +132,11 @@ class IterativeInference:
             ops.refine_finalize(st, eps_eff)
             if per_iter is not None:
                 ops.confusion_accumulate(y, T, per_iter[it], scratch, active=st.active)
+            # every image has met the stop test: the remaining iterations would not change anything
+            # (the reference breaks out of its per-image loop, iterative_inference.py:276-277).
+            # One small device->host read per iteration, only when early stopping is on.
+            if early_stop and it + 1 < int(num_iter) and not bool(st.active.any()):
+                break
         if per_iter is not None:
             return y, st.iters, st.last_norm, per_iter
         return y, st.iters, st.last_norm
