@@ -117,8 +117,8 @@ def conv_roofline(ii, X, T, num_iter, step_size):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     ap.add_argument('--num_iter', type=int, default=10)
     ap.add_argument('--step_size', type=float, default=0.1)
