@@ -313,6 +313,9 @@ int pick_bm(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
 // channel padding of the packed weights: wide 3x3 layers are padded to 256 so that the
 // 256-channel tile of conv_taps applies (128-channel kernels read the same layout)
 int mpad_for(const iiseg_conv_desc* d) {
+    // deep 1x1 layers (score_fr: 4096 -> 11): padded to the 128-channel tile of the split-K GEMM
+    // path (iiseg_conv_gemm_f32); a handful of workgroups walking K = 4096 alone is latency-bound
+    if (d->KH == 1 && d->KW == 1 && d->C1 + d->C2 >= 1024 && d->Cout < 128) return 128;
     const int bm = (d->KH == 3 && d->KW == 3 && d->Cout >= 256) ? 256 : pick_bm(d->Cout);
     return (d->Cout + bm - 1) / bm * bm;
 }

@@ -253,9 +253,9 @@ class Conv:
                 prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
             return out
         gemm_shape = self.kernel == 'conv_igemm_f32_kernel' or (
-            # deep 1x1 layers on few pixels (fc7): the same split-K GEMM beats the 1x1 tap kernel
-            dt == torch.float32 and (self.KH, self.KW) == (1, 1) and self.Cin >= 1024 and
-            self.Cout >= 128)
+            # deep 1x1 layers on few pixels (fc7, score_fr): the same split-K GEMM beats the 1x1 tap
+            # kernel
+            dt == torch.float32 and (self.KH, self.KW) == (1, 1) and self.Cin >= 1024)
         if gemm_shape and CONV_GEMM and x2 is None and not unpool and \
                 add is None and self.lib.iiseg_conv_gemm_supported(C.byref(d)):
             ws = _wino_workspace(self.lib.iiseg_conv_gemm_workspace_elems(C.byref(d)), x1.device)
