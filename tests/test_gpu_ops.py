@@ -246,6 +246,60 @@ def test_conv_with_fused_pool_is_bit_exact(ops, case):
         assert (ph == -3.0).all(), 'pooled values written outside the window'
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_conv3x3_randomised_against_oracle(ops, seed):
+    """Seeded random 3x3 layers through whatever kernel the dispatch picks (halo 32-/16-row,
+    Winograd GEMM / fused, static taps): random channel counts, pad, batch, optional two-source
+    concat, DePool2D input, skip-add, ReLU, output window, placement into a larger tensor, tile
+    anchor -- always against the float64 oracle of the same computation."""
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 4))
+    Cin = int(rng.choice([3, 8, 11, 16, 32, 48, 64, 130]))
+    Cout = int(rng.choice([5, 11, 16, 24, 64, 96, 130, 260]))
+    H, W = int(rng.integers(6, 23)), int(rng.integers(6, 23))
+    pad = int(rng.choice([0, 1, 1, 2, 7]))
+    relu = bool(rng.integers(0, 2))
+    unpool = bool(rng.integers(0, 3) == 0)
+    two = (not unpool) and Cin >= 8 and bool(rng.integers(0, 3) == 0)
+    w, b = rnd(rng, Cout, Cin, 3, 3) / np.sqrt(9 * Cin), rnd(rng, Cout)
+    conv = ops.Conv(w, b, pad=pad, relu=relu)
+    conv.wino = Cin % 16 == 0 and bool(rng.integers(0, 2))        # force either family
+    kw = {}
+    if unpool:
+        pre = np.maximum(rnd(rng, B, Cin, H, W), 0)
+        pooled = onn.maxpool2(pre)
+        up = rnd(rng, *pooled.shape)
+        x_ref = onn.depool_eqmask(up.astype(np.float64), pre.astype(np.float64),
+                                  pooled.astype(np.float64))
+        x_arg, kw = dev(up), dict(pre=dev(pre), pooled=dev(pooled))
+    elif two:
+        c1 = int(rng.choice([4, Cin // 2])) if Cin // 2 >= 4 else 4
+        xa, xb = rnd(rng, B, c1, H, W), rnd(rng, B, Cin - c1, H, W)
+        x_ref = np.concatenate([xa, xb], 1).astype(np.float64)
+        x_arg, kw = dev(xa), dict(x2=dev(xb))
+    else:
+        x = rnd(rng, B, Cin, H, W)
+        x_ref, x_arg = x.astype(np.float64), dev(x)
+    ref = onn.conv2d(x_ref, w.astype(np.float64), b.astype(np.float64), pad=pad)
+    OH, OW = ref.shape[2], ref.shape[3]
+    y0, x0 = int(rng.integers(0, OH)), int(rng.integers(0, OW))
+    h, ww = int(rng.integers(1, OH - y0 + 1)), int(rng.integers(1, OW - x0 + 1))
+    if rng.integers(0, 2):
+        add = rnd(rng, B, Cout, OH + 2, OW + 1)
+        ref = ref + add[:, :, 1:1 + OH, 1:1 + OW]
+        kw.update(add=dev(add), add_off=(1 + y0, 1 + x0))
+    if relu:
+        ref = np.maximum(ref, 0)
+    big = torch.full((B, Cout + 1, OH + 3, OW + 2), -9.0, device='cuda')
+    conv(x_arg, window=(y0, x0, h, ww), out=big, out_c0=1, place=(y0 + 2, x0 + 1),
+         anchor=(int(rng.integers(0, 2)), int(rng.integers(0, 2))), **kw)
+    got = host(big)
+    sel = got[:, 1:, y0 + 2:y0 + 2 + h, x0 + 1:x0 + 1 + ww]
+    assert np.abs(sel - ref[:, :, y0:y0 + h, x0:x0 + ww]).max() <= 4 * conv_tol(ref, 9 * Cin)
+    got[:, 1:, y0 + 2:y0 + 2 + h, x0 + 1:x0 + 1 + ww] = -9.0
+    assert (got == -9.0).all(), 'wrote outside the placement window'
+
+
 @pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 5, 9, 7), (3, 2, 211, 13), (1, 1, 2, 2)])
 def test_maxpool_bit_exact(ops, shape):
     rng = np.random.default_rng(11)
