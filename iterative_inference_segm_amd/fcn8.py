@@ -5,6 +5,7 @@ sense without Theano: there is no symbolic `input_var`; the returned object is c
 the image batch and returns `[net[el] for el in layer]` (models/fcn8.py:200), i.e. it plays
 the role of the compiled `pred_fcn_fn` (iterative_inference.py:187-188).
 """
+import itertools
 import os
 
 import numpy as np
@@ -20,6 +21,9 @@ PARAM_ORDER = ['conv1_1', 'conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2',
 
 _BLOCKS = [('conv1_1', 'conv1_2'), ('conv2_1', 'conv2_2'), ('conv3_1', 'conv3_2', 'conv3_3'),
            ('conv4_1', 'conv4_2', 'conv4_3'), ('conv5_1', 'conv5_2', 'conv5_3')]
+
+
+_UID = itertools.count(1)   # identity of a net in the provenance tags (never reused, unlike id())
 
 
 def _center(big, small):
@@ -76,6 +80,7 @@ class FCN8:
         # fold the weights-only pad-100 border of the encoder maps once per input geometry
         self.fold_border = os.environ.get('IISEG_FCN_BORDER_FOLD', '1') != '0'
         self._border = {}
+        self._uid = next(_UID)
 
     def conv_layers(self):
         return self.convs
@@ -172,13 +177,14 @@ class FCN8:
         # maps owned by the internal border store are overwritten by the next call: hand out
         # copies, tagged with their provenance -- outside `deps[el]` such a map is a function of
         # this net's weights and the geometry alone, which lets a consumer (the DAE's encoder)
-        # keep ITS weights-only border across batches as well
+        # keep ITS weights-only border across batches as well.  (The tag vouches for the values as
+        # returned: a caller that edits such a tensor in place must drop `_iiseg_border`.)
         res = []
         for el in self.layer:
             t = net[el]
             if own and el.startswith('pool'):
                 t = t.clone()
-                t._iiseg_border = ((id(self), session['key']), deps[el])
+                t._iiseg_border = ((self._uid, session['key']), deps[el])
             res.append(t)
         return res
 
