@@ -115,6 +115,7 @@ class Conv:
                      0 < WINO_MIN_CIN <= self.Cin and self.Cout >= WINO_MIN_COUT)
         self._U = None
         self._plans = {}
+        self._packs = {}
 
     def out_hw(self, H, W):
         if self.transposed:
@@ -155,19 +156,28 @@ class Conv:
             d.C1, d.C2, d.H, d.W = C1 * self.KH * self.KW, 0, fullH, fullW
             d.KH = d.KW = 1
             so, sc = self.Cin * self.KH * self.KW, 1
+        # the packed weights (and the gather table of the table-driven kernel) depend on the input
+        # geometry only: one copy per (C1, C2, H, W), shared by every window / placement variant
+        pkey = (d.C1, d.C2, d.H, d.W)
+        packed = self._packs.get(pkey)
         if self.dtype == torch.float64:
             check(self.lib.iiseg_conv_plan_f64(C.byref(d)), 'iiseg_conv_plan_f64')
-            wp = torch.empty(d.Kpad * d.Mpad, dtype=self.dtype, device=self.W.device)
-            ktab = None
-            check(self.lib.iiseg_conv_pack_f64(_stream(), C.byref(d), _ptr(self.W, self.dtype), so,
-                                               sc, _ptr(wp, self.dtype)), 'iiseg_conv_pack_f64')
+            if packed is None:
+                wp = torch.empty(d.Kpad * d.Mpad, dtype=self.dtype, device=self.W.device)
+                check(self.lib.iiseg_conv_pack_f64(_stream(), C.byref(d), _ptr(self.W, self.dtype),
+                                                   so, sc, _ptr(wp, self.dtype)),
+                      'iiseg_conv_pack_f64')
+                packed = self._packs[pkey] = (wp, None)
         else:
             check(self.lib.iiseg_conv_plan(C.byref(d)), 'iiseg_conv_plan')
-            wp = torch.empty(d.Kpad * d.Mpad, dtype=self.dtype, device=self.W.device)
-            ktab = torch.empty(d.Kpad * 4, dtype=torch.int32, device=self.W.device)
-            check(self.lib.iiseg_conv_pack_f32(_stream(), C.byref(d), _ptr(self.W), so, sc,
-                                               _ptr(wp), _ptr(ktab, torch.int32)),
-                  'iiseg_conv_pack_f32')
+            if packed is None:
+                wp = torch.empty(d.Kpad * d.Mpad, dtype=self.dtype, device=self.W.device)
+                ktab = torch.empty(d.Kpad * 4, dtype=torch.int32, device=self.W.device)
+                check(self.lib.iiseg_conv_pack_f32(_stream(), C.byref(d), _ptr(self.W), so, sc,
+                                                   _ptr(wp), _ptr(ktab, torch.int32)),
+                      'iiseg_conv_pack_f32')
+                packed = self._packs[pkey] = (wp, ktab)
+        wp, ktab = packed
         plan = (d, wp, ktab)
         self._plans[key] = plan
         return plan
