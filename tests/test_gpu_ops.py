@@ -226,6 +226,8 @@ def test_conv_with_fused_pool_is_bit_exact(ops, case):
     full = conv(dev(x))
     ref_pool = host(ops.maxpool2x2(full))
     fh, fw = full.shape[2], full.shape[3]
+    if conv.pool_window(H, W) is None:
+        pytest.skip('pool fusion switched off (IISEG_POOL_FUSE=0 / IISEG_CONV_HALO=0)')
     assert conv.pool_window(H, W) == (0, 0, fh, fw)
     pooled = torch.full((B, Cout, fh // 2, fw // 2), -3.0, device='cuda')
     out = conv(dev(x), pool_out=pooled)
@@ -420,7 +422,9 @@ def test_abi_rejects_bad_arguments(ops):
     d.oy0, d.OH = 1, 7
     assert lib.iiseg_conv_pool_supported(C.byref(d)) == 0          # odd window origin
     d.oy0, d.OH = 0, 8
-    assert lib.iiseg_conv_pool_supported(C.byref(d)) == 1
+    import os
+    if os.environ.get('IISEG_CONV_HALO', '1') != '0':
+        assert lib.iiseg_conv_pool_supported(C.byref(d)) == 1
     assert lib.iiseg_strerror(-5).decode().startswith('no kernel variant')
     assert lib.iiseg_bn_stats_workspace_elems(16) == 16 * 64 * 2
     assert lib.iiseg_depool_bwd_f32(None, None, None, None, None, 1, 4, 4) == -1
