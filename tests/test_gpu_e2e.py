@@ -372,6 +372,8 @@ def test_border_fold_across_batches_is_bit_identical(built_lib, size, div, nf, d
         fcn.fold_border = dae.fold_border = fold
         return IterativeInference(fcn, dae, 11, [11], dtype=dtype)
     ii_fold, ii_full = make(True), make(False)
+    ii_fold.prepare(B, size[0], size[1])       # borders folded at load, from an all-zero image
+    assert ii_fold.fcn._border.get('primed') and ii_fold.dae._store['primed']
     for i in range(3):
         X = S.make_images(B, size[0], size[1], seed=90 + i)
         res = []
