@@ -43,8 +43,8 @@ GFLOP_PER_IMAGE = 872.3          # 119.24 (FCN-8) + 10 x 75.31 (DAE)
 PEAK_TFLOPS_F32_MFMA = 157.3     # MI355X_MICROARCH.md, fp32 matrix peak
 # HBM GB per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
 # MI355X_MICROARCH.md HBM section), profiles/r01_pmc_hbm_traffic.md; None = not measured
-TRAFFIC_GB_PER_LAUNCH = {'wino_gemm_kernel': 1.033, 'wino_fused_kernel': 1.430,
-                         'conv_halo_f32_kernel': 1.476, 'conv_taps_f32_kernel': 0.293}
+TRAFFIC_GB_PER_LAUNCH = {'wino_gemm_kernel': 1.048, 'wino_fused_kernel': 1.430,
+                         'conv_halo_f32_kernel': 1.456, 'conv_taps_f32_kernel': 0.293}
 
 
 def build_model(device, concat_h):
