@@ -248,6 +248,38 @@ def test_conv_with_fused_pool_is_bit_exact(ops, case):
         assert (ph == -3.0).all(), 'pooled values written outside the window'
 
 
+FULL_LAYERS = [
+    # name, Cin, Cout, H, k, pad, window   -- real configs[1] layer shapes (batch 4)
+    ('dae.conv2_1 halo', 64, 128, 211, 3, 1, (48, 48, 116, 116)),
+    ('dae.up_conv1 halo16', 64, 11, 422, 3, 1, (99, 99, 224, 224)),
+    ('dae.conv4_1 wino fused', 256, 512, 52, 3, 1, (10, 10, 33, 33)),
+    ('dae.conv6_1 wino gemm', 1024, 2048, 13, 3, 1, (1, 1, 12, 12)),
+    ('fcn.fc6 split-K gemm', 512, 4096, 13, 7, 0, None),
+    ('fcn.score_pool4 1x1 taps', 512, 11, 26, 1, 0, None),
+]
+
+
+@pytest.mark.parametrize('case', FULL_LAYERS, ids=[c[0] for c in FULL_LAYERS])
+def test_full_size_layers_are_exactly_homogeneous(ops, case):
+    """Size-independent exactness at the real layer sizes (where the oracle takes minutes): a
+    bias-free convolution is linear, and scaling by a power of two is exact in binary floating
+    point, so conv(4 x) == 4 conv(x) and conv(x) with weights / 2 == conv(x) / 2 BIT FOR BIT, for
+    every kernel family (direct, Winograd transforms included, split-K sums); and zero maps to
+    zero."""
+    name, Cin, Cout, H, k, pad, win = case
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(4, Cin, H, H, device='cuda', generator=g)
+    w = torch.randn(Cout, Cin, k, k, device='cuda', generator=g) / (Cin * k * k) ** 0.5
+    kw = dict(window=win) if win else {}
+    conv = ops.Conv(w, None, pad=pad, relu=False)
+    y = conv(x, **kw)
+    assert torch.isfinite(y).all() and float(y.abs().max()) > 0
+    assert torch.equal(conv(4.0 * x, **kw), 4.0 * y)
+    half = ops.Conv(0.5 * w, None, pad=pad, relu=False)
+    assert torch.equal(half(x, **kw), 0.5 * y)
+    assert not conv(torch.zeros_like(x), **kw).any()
+
+
 @pytest.mark.parametrize('seed', range(24))
 def test_conv3x3_randomised_against_oracle(ops, seed):
     """Seeded random 3x3 layers through whatever kernel the dispatch picks (halo 32-/16-row,
