@@ -280,6 +280,30 @@ def test_full_size_layers_are_exactly_homogeneous(ops, case):
     assert not conv(torch.zeros_like(x), **kw).any()
 
 
+def test_pool_unpool_round_trip_full_size(ops):
+    """Round trip at the largest map of configs[1] (64 ch, 422x422): for a rectified map
+    maxpool(DePool2D(up = pooled, pre, pooled)) == pooled exactly, the unpooled map equals `pre` on
+    the mask and 0 elsewhere, and the window forms write exactly their window."""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    pre = torch.relu(torch.randn(8, 64, 422, 422, device='cuda', generator=g))
+    pooled = ops.maxpool2x2(pre)
+    un = ops.unpool_eqmask(pooled, pre, pooled)
+    assert torch.equal(ops.maxpool2x2(un), pooled)
+    assert torch.equal(un, torch.where(un != 0, pre, torch.zeros_like(pre)))
+    assert int((un != 0).sum()) >= int((pooled != 0).sum())          # >= : ties mark several
+    win = (99, 98, 226, 227)
+    out = torch.full_like(pre, -1.0)
+    ops.unpool_eqmask(pooled, pre, pooled, out=out, window=win)
+    y0, x0, h, w = win
+    assert torch.equal(out[:, :, y0:y0 + h, x0:x0 + w], un[:, :, y0:y0 + h, x0:x0 + w])
+    out[:, :, y0:y0 + h, x0:x0 + w] = -1.0
+    assert bool((out == -1.0).all())
+    pw = (49, 49, 113, 114)
+    pout = torch.full_like(pooled, -1.0)
+    ops.maxpool2x2(pre, out=pout, window=pw)
+    assert torch.equal(pout[:, :, 49:49 + 113, 49:49 + 114], pooled[:, :, 49:49 + 113, 49:49 + 114])
+
+
 @pytest.mark.parametrize('seed', range(24))
 def test_conv3x3_randomised_against_oracle(ops, seed):
     """Seeded random 3x3 layers through whatever kernel the dispatch picks (halo 32-/16-row,
