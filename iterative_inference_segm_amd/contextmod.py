@@ -1,8 +1,9 @@
 """Context-module DAE on the HIP kernels (mirror of reference models/contextmod_dae.py:19-138):
 conv3x3(+ReLU) on [h=image, y] -> pad 32 -> six dilated 3x3 convs (dilation 1,2,4,8,16,1, ReLU)
 -> 1x1 linear -> softmax, 11 channels throughout.  The PadLayer is the `pad` of the first dilated
-conv; the concat is the two-source gather; everything runs on `conv_taps` (3x3 with dilation,
-DilatedConv2DLayer weight layout W[in,out,k,k], P11).  HBM/latency-bound (11 channels)."""
+conv; the 3x3 layers (dilation 1..16) run on the 16-channel halo kernel (`conv_halo16`, 16x16x4
+MFMA; DilatedConv2DLayer weight layout W[in,out,k,k], P11); inside a refinement loop the concat is
+a buffer whose y channels are refreshed per step, outside it the two-source gather."""
 import os
 
 import torch
@@ -39,10 +40,26 @@ class ContextModDAE:
         d.update({'dilconv%d' % (i + 1): c for i, c in enumerate(self.dil)})
         return d
 
-    def scores(self, h_list, y, mask_override=None):
+    def new_session(self, h_list=None, y=None):
+        """State of one refinement loop (h fixed, y evolving): the ConcatLayer((h, y)) buffer of
+        contextmod_dae.py:55-59 with h copied in once; each step only refreshes the y channels
+        (plain device copies), so conv1 runs single-source on the 16-channel halo kernel."""
+        if not h_list or y is None or len(h_list) != 1:
+            return None
+        h = h_list[0]
+        cat = torch.empty((y.shape[0], h.shape[1] + y.shape[1], y.shape[2], y.shape[3]),
+                          dtype=y.dtype, device=y.device)
+        cat[:, :h.shape[1]].copy_(h)
+        return {'cat': cat, 'ch': h.shape[1]}
+
+    def scores(self, h_list, y, mask_override=None, session=None):
         if len(h_list) != 1:
             raise ValueError('expected 1 h tensor, got %d' % len(h_list))
-        t = self.conv1(h_list[0], x2=y)                              # h first (P13)
+        if session is not None:
+            session['cat'][:, session['ch']:].copy_(y)
+            t = self.conv1(session['cat'])
+        else:
+            t = self.conv1(h_list[0], x2=y)                          # h first (P13)
         for conv in self.dil:
             t = conv(t)
         return self.last(t)

@@ -313,12 +313,17 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
 // is still sequential in k (4 at a time), results agree with the 32-row kernels to fp32 rounding.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int TH, bool UNPOOL>
+template <int TH, bool UNPOOL, int DIL>
 __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParams p, const int tiles_y,
                                                                  const int tiles_x) {
     constexpr int BM = 16, CPT = 4, BK = 9 * CPT, NS = BK / 4;
-    constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    // dilation DIL (DilatedConv2DLayer of the context module, models/contextmod_dae.py:78-101): the
+    // taps sit DIL apart, so the patch has a DIL-wide halo; when DIL > TH the three row bands a
+    // tile reads (one per ky) do not overlap and only those 3*TH rows are staged
+    constexpr bool COMPACT = DIL > TH;
+    constexpr int TW = 32, PH = COMPACT ? 3 * TH : TH + 2 * DIL, PW = TW + 2 * DIL, PP = PH * PW;
     constexpr int PE = CPT * PP, NE = (PE + 255) / 256;
+    static_assert(!(UNPOOL && DIL != 1), "DePool2D input only for undilated layers");
     constexpr int RW = TH / 4, TN = 2 * RW;     // 16-pixel column tiles per wave
     constexpr int WVEC = BK * BM / 4;           // 144 float4 per weight tile
     static_assert(TH % 4 == 0 && WVEC <= 256, "tile config");
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
         const int e = i * 256 + tid;
         const int c = e / PP, rr = e - c * PP;
         const int py = rr / PW, px = rr - py * PW;
-        const int iy = iy0 + py, ix = ix0 + px;
+        const int iy = iy0 + (COMPACT ? (py / TH) * DIL + py % TH : py), ix = ix0 + px;
         bool ok = e < PE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         cl[i] = c;
         voff[i] = ok ? 4u * (unsigned)(c * HW + iy * p.W + ix) : OOB;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
     for (int s = 0; s < NS; ++s) {
         const int k = 4 * s + kq;
         const int c = k / 9, tap = k - 9 * c;
-        koff[s] = c * PP + (tap / 3) * PW + tap % 3;
+        koff[s] = c * PP + (tap / 3) * (COMPACT ? TH : DIL) * PW + (tap % 3) * DIL;
     }
     const int lbase = wave * RW * PW + n;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -495,13 +500,18 @@ int launch_halo16(hipStream_t s, const ConvParams& cp, bool unpool) {
     const int tiles_y = (p.OH + TH - 1) / TH, tiles_x = (p.OW + 31) / 32;
     p.n_ptiles = p.B * tiles_y * tiles_x;
     p.n_mtiles = (p.Cout + 15) / 16;
-    const int grid = p.n_ptiles * p.n_mtiles;
-    if (unpool)
-        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, true>), dim3(grid), dim3(256), 0, s, p, tiles_y,
-                           tiles_x);
-    else
-        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, false>), dim3(grid), dim3(256), 0, s, p,
-                           tiles_y, tiles_x);
+    const dim3 grid(p.n_ptiles * p.n_mtiles), block(256);
+#define H16(U, D) hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, U, D>), grid, block, 0, s, p, tiles_y, tiles_x)
+    if (unpool) H16(true, 1);
+    else switch (p.dil) {
+        case 1: H16(false, 1); break;
+        case 2: H16(false, 2); break;
+        case 4: H16(false, 4); break;
+        case 8: H16(false, 8); break;
+        case 16: H16(false, 16); break;
+        default: return IISEG_ERR_UNSUPPORTED;
+    }
+#undef H16
     return iiseg_check_launch();
 }
 
@@ -509,7 +519,10 @@ int launch_halo16(hipStream_t s, const ConvParams& cp, bool unpool) {
 
 // 1 if the halo kernel can run this (already validated) 3x3 request
 bool iiseg_conv_halo_ok(const ConvParams& p, int KH, int KW) {
-    if (KH != 3 || KW != 3 || p.dil != 1 || p.transposed) return false;
+    if (KH != 3 || KW != 3 || p.transposed) return false;
+    // dilated layers only on the 16-channel variant (context module: 11 -> 11 channels)
+    if (p.dil != 1 && !(p.Cout <= 16 && (p.dil == 2 || p.dil == 4 || p.dil == 8 || p.dil == 16)))
+        return false;
     if (p.Kpad % 36) return false;
     if (p.C2 > 0 && p.C1 % 4) return false;  // a k-tile (4 channels) must not straddle the sources
     const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;

@@ -106,8 +106,11 @@ class Conv:
             self.kernel = 'conv_taps_f32_kernel' if taps else 'conv_igemm_f32_kernel'
             # direct 3x3 layers below 256 output channels run on the halo-tile kernel (the C side
             # dispatches: conv_igemm.hip, IISEG_CONV_HALO)
-            if (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed and \
-                    self.Cout < 256 and os.environ.get('IISEG_CONV_HALO', '1') != '0':
+            # (dilated 3x3 layers with at most 16 output channels -- the context module -- too)
+            if (self.KH, self.KW) == (3, 3) and not self.transposed and \
+                    os.environ.get('IISEG_CONV_HALO', '1') != '0' and \
+                    ((self.dil == 1 and self.Cout < 256) or
+                     (self.dil in (2, 4, 8, 16) and self.Cout <= 16)):
                 self.kernel = 'conv_halo_f32_kernel'
             self.via_im2col = False
         self.wino = (dtype == torch.float32 and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
