@@ -117,6 +117,18 @@ int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
                         const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
                         const float* bias, const float* add, float* out, float* pool_out);
 
+/* 3x3 convolution with at most 16 output channels whose INPUT is normalised and rectified while it
+ * is staged: x <- max((x - mean[c]) * (gamma[c] * inv_std[c]) + beta[c], 0) per input channel --
+ * BN_ReLU_Conv of FC-DenseNet (models/FCDenseNet.py:12,90,109,123) as one kernel instead of
+ * iiseg_bn_relu_f32 + iiseg_conv_f32 (the normalised copy of the growing feature stack is never
+ * written).  x is (B, >= C1, H, W) with x_bstride elements between images (the first C1 channels of
+ * a stack).  Same arithmetic as iiseg_bn_relu_f32; zero padding pads the normalised map. */
+int iiseg_conv_bnrelu_supported(const iiseg_conv_desc* d);
+int iiseg_conv_bnrelu_f32(void* stream, const iiseg_conv_desc* d, const float* x, int64_t x_bstride,
+                          const float* beta, const float* gamma, const float* mean,
+                          const float* inv_std, const float* wp, const int32_t* ktab,
+                          const float* bias, float* out);
+
 /* Winograd F(2x2,3x3) form of the same convolution (same call sites as iiseg_conv_f32 for
  * 3x3, dil 1, stride 1 layers with (C1+C2) % 16 == 0, no TRANSPOSED2; with IISEG_CONV_UNPOOL the
  * DePool2D mask is applied while the input transform loads its 4x4 patches, operands as in

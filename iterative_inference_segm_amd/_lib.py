@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     'iiseg_conv_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_conv_pool_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pool_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 10),
+    'iiseg_conv_bnrelu_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_bnrelu_f32': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64] + [_vp] * 8),
     'iiseg_conv_wino_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_wino_weight_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_wino_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),

@@ -44,6 +44,10 @@ struct ConvParams {
     int out_H, out_W, out_y0, out_x0;  // destination planes / placement (dense: OH, OW, 0, 0)
     float* pool;           // fused 2x2 max-pool of the output (conv_halo only), full (fullH/2, fullW/2) planes
     int pool_H, pool_W;
+    // fused input BatchNorm + ReLU (conv_halo16 only): x <- max((x - mean[c]) * (gamma[c] * inv_std[c])
+    // + beta[c], 0) while the patch is staged; in_bstride = elements between images of x1 (0: dense)
+    const float *bn_beta, *bn_gamma, *bn_mean, *bn_inv_std;
+    long long in_bstride;
 };
 
 // Tile order: the XCD that gets block b is b % 8 (round-robin dispatch, speed only), so give

@@ -313,7 +313,7 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
 // is still sequential in k (4 at a time), results agree with the 32-row kernels to fp32 rounding.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int TH, bool UNPOOL, int DIL>
+template <int TH, bool UNPOOL, int DIL, bool BNRELU = false>
 __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParams p, const int tiles_y,
                                                                  const int tiles_x) {
     constexpr int BM = 16, CPT = 4, BK = 9 * CPT, NS = BK / 4;
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
     constexpr int TW = 32, PH = COMPACT ? 3 * TH : TH + 2 * DIL, PW = TW + 2 * DIL, PP = PH * PW;
     constexpr int PE = CPT * PP, NE = (PE + 255) / 256;
     static_assert(!(UNPOOL && DIL != 1), "DePool2D input only for undilated layers");
+    static_assert(!(UNPOOL && BNRELU), "one input fusion at a time");
     constexpr int RW = TH / 4, TN = 2 * RW;     // 16-pixel column tiles per wave
     constexpr int WVEC = BK * BM / 4;           // 144 float4 per weight tile
     static_assert(TH % 4 == 0 && WVEC <= 256, "tile config");
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
             voff2[i] = ok ? 4u * (unsigned)(c * hw2 + (iy >> 1) * p.w2 + (ix >> 1)) : OOB;
         }
     }
-    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW
+                                : p.x1 + (size_t)b * (p.in_bstride ? (size_t)p.in_bstride : (size_t)C1 * HW);
     const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
     const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
     const float* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
 
-    float xv[UNPOOL ? NE : 1], xq[UNPOOL ? NE : 1], xu[UNPOOL ? NE : 1];
+    float xv[(UNPOOL || BNRELU) ? NE : 1], xq[UNPOOL ? NE : 1], xu[UNPOOL ? NE : 1];
+    int cbn[BNRELU ? NE : 1];   // BNRELU: channel of the staged element, -1 where it is padding
     const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, p.Kpad * p.Mpad * 4);
     const int wrow = tid / 4, wc4 = tid % 4;
 
@@ -392,6 +395,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
                 xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
                 xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
             });                                                                                    \
+        } else if constexpr (BNRELU) {                                                             \
+            const int crem = C1 - c0;                                                              \
+            static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const bool ok = cl[i] < crem && voff[i] != OOB;                                    \
+                xv[i] = buf_ld(mk_rsrc(base1, n1), ok ? voff[i] : OOB, (unsigned)(c0 * HW) * 4u);  \
+                cbn[i] = ok ? c0 + cl[i] : -1;                                                     \
+            });                                                                                    \
         } else {                                                                                   \
             const bool s1 = c0 < C1;                                                               \
             const int crem = (s1 ? C1 : Ctot) - c0;                                                \
@@ -407,6 +418,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
         }                                                                                          \
     }
 #define H16_STORE_X(BUF)                                                                           \
+    if constexpr (BNRELU) {                                                                        \
+        /* same arithmetic as bn_relu_kernel: (x - mean) * (gamma * inv_std) + beta, rectified;   */ \
+        /* zero padding stays zero (it pads the NORMALISED map)                                    */ \
+        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            const int c = cbn[i] < 0 ? 0 : cbn[i];                                                 \
+            const float g = p.bn_gamma[c] * p.bn_inv_std[c];                                       \
+            const float v = (xv[i] - p.bn_mean[c]) * g + p.bn_beta[c];                             \
+            Ps[BUF][i * 256 + tid] = (cbn[i] >= 0 && v > 0.f) ? v : 0.f;                           \
+        });                                                                                        \
+    }                                                                                              \
     if constexpr (UNPOOL) {                                                                        \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
@@ -502,7 +524,11 @@ int launch_halo16(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_mtiles = (p.Cout + 15) / 16;
     const dim3 grid(p.n_ptiles * p.n_mtiles), block(256);
 #define H16(U, D) hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, U, D>), grid, block, 0, s, p, tiles_y, tiles_x)
-    if (unpool) H16(true, 1);
+    if (p.bn_mean) {
+        if (unpool || p.dil != 1 || p.C2 != 0) return IISEG_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, false, 1, true>), grid, block, 0, s, p, tiles_y,
+                           tiles_x);
+    } else if (unpool) H16(true, 1);
     else switch (p.dil) {
         case 1: H16(false, 1); break;
         case 2: H16(false, 2); break;

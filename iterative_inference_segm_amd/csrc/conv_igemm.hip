@@ -431,10 +431,44 @@ extern "C" int iiseg_conv_pool_supported(const iiseg_conv_desc* d) {
     return 1;
 }
 
+struct BnIn {   // fused input BatchNorm + ReLU (conv_halo16 only)
+    const float *beta, *gamma, *mean, *inv_std;
+    int64_t bstride;
+};
+static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                    const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
+                    const float* bias, const float* add, float* out, float* pool_out,
+                    const BnIn* bn);
+
 extern "C" int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
                                    const float* x2, const float* pre, const float* pooled,
                                    const float* wp, const int32_t* ktab, const float* bias,
                                    const float* add, float* out, float* pool_out) {
+    return conv_run(stream, d, x1, x2, pre, pooled, wp, ktab, bias, add, out, pool_out, nullptr);
+}
+
+extern "C" int iiseg_conv_bnrelu_supported(const iiseg_conv_desc* d) {
+    if (!d || check_desc(d)) return 0;
+    static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
+    return halo && d->KH == 3 && d->KW == 3 && d->dil == 1 && d->Cout <= 16 && d->C2 == 0 &&
+           !(d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2)) && d->Kpad % 36 == 0;
+}
+
+extern "C" int iiseg_conv_bnrelu_f32(void* stream, const iiseg_conv_desc* d, const float* x,
+                                     int64_t x_bstride, const float* beta, const float* gamma,
+                                     const float* mean, const float* inv_std, const float* wp,
+                                     const int32_t* ktab, const float* bias, float* out) {
+    if (!beta || !gamma || !mean || !inv_std) return IISEG_ERR_NULL;
+    if (!iiseg_conv_bnrelu_supported(d)) return IISEG_ERR_UNSUPPORTED;
+    if (x_bstride < (int64_t)d->C1 * d->H * d->W) return IISEG_ERR_SHAPE;
+    const BnIn bn = {beta, gamma, mean, inv_std, x_bstride};
+    return conv_run(stream, d, x, nullptr, nullptr, nullptr, wp, ktab, bias, nullptr, out, nullptr, &bn);
+}
+
+static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                    const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
+                    const float* bias, const float* add, float* out, float* pool_out,
+                    const BnIn* bn) {
     int st = check_desc(d);
     if (pool_out && !iiseg_conv_pool_supported(d)) return IISEG_ERR_UNSUPPORTED;
     if (st) return st;
@@ -459,6 +493,11 @@ extern "C" int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const
     p.pad = d->pad; p.dil = d->dil;
     p.debug_nogather = 0;
     p.pool = pool_out;
+    p.bn_beta = bn ? bn->beta : nullptr;
+    p.bn_gamma = bn ? bn->gamma : nullptr;
+    p.bn_mean = bn ? bn->mean : nullptr;
+    p.bn_inv_std = bn ? bn->inv_std : nullptr;
+    p.in_bstride = bn ? bn->bstride : 0;
     p.pool_H = (d->H + 2 * d->pad - d->dil * (d->KH - 1)) / 2;
     p.pool_W = (d->W + 2 * d->pad - d->dil * (d->KW - 1)) / 2;
     p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
@@ -477,6 +516,7 @@ extern "C" int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const
     static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
     const bool use_halo = halo && (halo > 1 || d->Cout < 256) && iiseg_conv_halo_ok(p, d->KH, d->KW);
     if (pool_out && (!use_halo || add || d->Cout <= 16)) return IISEG_ERR_UNSUPPORTED;
+    if (bn && !use_halo) return IISEG_ERR_UNSUPPORTED;
     if (use_halo) return iiseg_launch_conv_halo(s, p, pick_bm(d->Cout), unpool);
     if (iiseg_taps_cpt(d->KH, d->KW) > 0)
         return iiseg_launch_conv_taps(s, p, d->KH, d->KW, pick_bm(d->Cout), unpool);

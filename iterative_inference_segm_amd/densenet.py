@@ -103,6 +103,13 @@ class FCDenseNet:
 
     def _brc(self, it, stack, out=None, out_c0=None):
         e = next(it)
+        if out is not None and out_c0 is not None:
+            # dense-block layer (3x3, 16 filters): BatchNorm + ReLU applied while the conv stages
+            # its input -- the normalised copy of the whole stack is never written
+            r = e['conv'].bnrelu_conv(stack.buf, stack.n,
+                                      (e['beta'], e['gamma'], stack.mean, stack.inv_std), out, out_c0)
+            if r is not None:
+                return r
         t = ops.bn_relu(stack.buf, stack.n, e['beta'], e['gamma'], stack.mean, stack.inv_std)
         return e['conv'](t, out=out, out_c0=out_c0)
 

@@ -30,6 +30,10 @@ WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
 WINO_FUSED_MAX_CIN = int(os.environ.get('IISEG_WINO_FUSED_MAX_CIN', '256'))
 # fuse the 2x2 max-pool behind a halo-kernel conv into that conv's epilogue
 POOL_FUSE = os.environ.get('IISEG_POOL_FUSE', '1') != '0'
+# BN_ReLU_Conv of FC-DenseNet's dense blocks as one kernel.  Off by default: measured 6 % SLOWER
+# end to end on config 3 (361 vs 383 images/s) -- the per-element parameter loads in the conv's
+# staging cost more than the separate HBM-bound normalisation pass saves.
+BNRELU_FUSE = os.environ.get('IISEG_BNRELU_FUSE', '0') != '0'
 # 'valid' KxK layers without a static-tap variant (7x7 fc6) as im2col + split-K GEMM
 CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
@@ -301,6 +305,36 @@ class Conv:
             prof.append((kern, self.flops(B, d.OH, d.OW), ev0, ev1))
         return out
 
+
+    def bnrelu_conv(self, stack, n, bn, out, out_c0):
+        """BN_ReLU_Conv as one kernel (iiseg_conv_bnrelu_f32): the conv reads the first `n`
+        channels of `stack` (B, cap, H, W) and normalises + rectifies them while staging
+        (bn = (beta, gamma, mean, inv_std), batch statistics); the result goes to channels
+        [out_c0, out_c0 + Cout) of `out`.  Returns None when the layer has no such kernel (the
+        caller then runs bn_relu + the plain conv)."""
+        if self.dtype != torch.float32 or not BNRELU_FUSE or (self.KH, self.KW) != (3, 3) or \
+                self.Cout > 16 or self.dil != 1 or self.transposed:
+            return None
+        B, cap, H, W = stack.shape
+        pl = None
+        out_slice = (out.shape[1], int(out_c0))
+        d, wp, ktab = self._plan(B, n, 0, H, W, None, None, False, out_slice, pl)
+        if not self.lib.iiseg_conv_bnrelu_supported(C.byref(d)) or \
+                tuple(out.shape[2:]) != (d.OH, d.OW) or out_c0 + self.Cout > out.shape[1]:
+            return None
+        prof = CONV_PROFILE
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        beta, gamma, mean, inv_std = bn
+        check(self.lib.iiseg_conv_bnrelu_f32(_stream(), C.byref(d), _ptr(stack), cap * H * W,
+                                             _ptr(beta), _ptr(gamma), _ptr(mean), _ptr(inv_std),
+                                             _ptr(wp), _ptr(ktab, torch.int32), _ptr(self.b),
+                                             _ptr(out)), 'iiseg_conv_bnrelu_f32')
+        if prof is not None:
+            ev1.record()
+            prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
+        return out
 
     def pool_window(self, H, W, region=None):
         """If the 2x2 max-pool that follows this layer can be fused into its epilogue: the conv

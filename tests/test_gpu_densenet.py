@@ -96,3 +96,26 @@ def test_densenet_host_with_standard_dae_f64(built_lib):
     Yii, iters, _ = ii.refine(H, Y, 0.2, 3)
     assert list(host(iters)) == list(it_ref)
     assert np.abs(host(Yii) - yii_ref).max() <= 1e-9
+
+
+def test_fused_bnrelu_conv_equals_two_kernels(built_lib, monkeypatch):
+    """The opt-in BN_ReLU_Conv kernel (iiseg_conv_bnrelu_f32, IISEG_BNRELU_FUSE=1) gives bit for bit
+    the result of iiseg_bn_relu_f32 followed by the conv: same arithmetic, zero padding applied to
+    the normalised map, input = the first n channels of a wider stack, output = a channel slice."""
+    from iterative_inference_segm_amd import ops
+    monkeypatch.setattr(ops, 'BNRELU_FUSE', True)
+    rng = np.random.default_rng(5)
+    B, cap, n, H, W, Cout = 3, 40, 22, 19, 37, 16
+    stack = torch.from_numpy(rng.standard_normal((B, cap, H, W)).astype(np.float32)).cuda()
+    mean = torch.zeros(cap, device='cuda'); inv = torch.zeros(cap, device='cuda')
+    ops.bn_stats(stack, 0, n, mean, inv)
+    beta = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32)).cuda()
+    w = rng.standard_normal((Cout, n, 3, 3)).astype(np.float32) / np.sqrt(9 * n)
+    conv = ops.Conv(w, rng.standard_normal(Cout).astype(np.float32), pad=1, relu=False)
+    out_f = torch.full((B, cap, H, W), -2.0, device='cuda')
+    assert conv.bnrelu_conv(stack, n, (beta, gamma, mean, inv), out_f, 20) is not None
+    out_r = torch.full((B, cap, H, W), -2.0, device='cuda')
+    conv(ops.bn_relu(stack, n, beta, gamma, mean, inv), out=out_r, out_c0=20)
+    assert torch.equal(out_f, out_r)
+    assert bool((out_f[:, :20] == -2.0).all()) and bool((out_f[:, 36:] == -2.0).all())
