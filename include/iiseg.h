@@ -203,7 +203,7 @@ int iiseg_unpool_eqmask_window_f32(void* stream, const float* up, const float* p
  * models/fcn_up.py:41-45.  w is the reference layout W[Cin][Cout][K][K]; the kernel applies
  * the spatial flip of Lasagne's filter_flip=True gradient form.
  * Only the window [oy0,oy0+OH) x [ox0,ox0+OW) of the (H-1)*s+K output is produced.
- * Optional: out += add[b, c, ay0+oy, ax0+ox] (add is (B,Cout,AH,AW)); Cout <= 16.
+ * Optional: out += add[b, c, ay0+oy, ax0+ox] (add is (B,Cout,AH,AW)); Cout <= 32.
  * ------------------------------------------------------------------------------------- */
 typedef struct iiseg_deconv_desc {
     int32_t B, Cin, H, W, Cout, K, stride;

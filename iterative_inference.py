@@ -164,6 +164,7 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     # Prepare load/save directories (:84-104)
     name_kw = dict(dae_dict)
     name_kw.update(training_dict)
+    name_kw.pop('emulate_noise', None)   # extra key of this build, not part of the reference's name
     exp_name = build_experiment_name(segm_net, data_aug=data_augmentation, ae_h=ae_h, **name_kw)
     if savepath is None:
         raise ValueError('A saving directory must be specified')

@@ -10,6 +10,8 @@ batched device loop that keeps the reference's per-image semantics (per-image ea
 update applied before the test).  Arguments and results are device tensors
 (C-contiguous NCHW float32): no host round trip per call.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -61,6 +63,27 @@ class IterativeInference:
         if self.void_labels and self.void_labels != [n_classes]:
             raise NotImplementedError('void_labels must be [] or [n_classes]')
         self.device = device
+        # provenance records of the h maps handed out by pred_fcn_fn (fcn8.FCN8.last_provenance),
+        # keyed by tensor identity: id -> (weakref, torch version counter, record)
+        self._prov = {}
+
+    def _remember(self, outs):
+        prov = getattr(self.fcn, 'last_provenance', None)
+        self._prov = {}
+        if prov is not None:
+            for t, tag in zip(outs, prov):
+                if tag is not None:
+                    self._prov[id(t)] = (weakref.ref(t), t._version, tag)
+        return outs
+
+    def provenance_of(self, h):
+        """The record pred_fcn_fn kept for this very tensor object, or None: a clone / slice /
+        host copy is another object, and an in-place edit bumps torch's version counter -- both
+        fall back (loudly visible through this method) to the full first step."""
+        ent = self._prov.get(id(h))
+        if ent is None or ent[0]() is not h or h._version != ent[1]:
+            return None
+        return ent[2]
 
     def prepare(self, batch, height, width, channels=3):
         """Load-time constant folding for one input geometry: with pad 100 most of every encoder
@@ -73,17 +96,17 @@ class IterativeInference:
             return
         x0 = torch.zeros((int(batch), int(channels), int(height), int(width)), dtype=self.dtype,
                          device=self.device)
-        out = self.fcn(x0)
+        out = self._remember(self.fcn(x0))
         if not isinstance(out, (list, tuple)) or len(out) < 2 or not hasattr(self.dae, 'new_session'):
             return
         H, Y = list(out[:-1]), out[-1]
-        sess = self.dae.new_session(H, Y)
+        sess = self.dae.new_session(H, Y, tags=[self.provenance_of(h) for h in H])
         if sess is not None:
             self.dae.scores(H, Y, session=sess)
 
     # ---- reference function level -------------------------------------------------------
     def pred_fcn_fn(self, X):
-        return self.fcn(self._dev(X))
+        return self._remember(self.fcn(self._dev(X)))
 
     def pred_dae_fn(self, *args):
         return self.dae(*[self._dev(a) for a in args])
@@ -103,7 +126,7 @@ class IterativeInference:
 
     # ---- fused loop ---------------------------------------------------------------------
     def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
-               per_iter_target=None, mode='residual'):
+               per_iter_target=None, mode='residual', h_provenance=None):
         """Batched replacement of iterative_inference.py:258-284.
 
         for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
@@ -117,12 +140,21 @@ class IterativeInference:
         with a hand-written backward pass through the DAE (`StandardDAE.backward_y`); the stop
         test uses mean_px ||grad||_2.
 
+        `h_provenance`: explicit provenance records for H (one per h, `provenance_of(h)` of the
+        tensors pred_fcn_fn returned) when the caller hands in copies of them; default: looked up
+        by tensor identity.
+
         `per_iter_target` (one-hot T): also returns a (num_iter, C*(C+1)) int64 tensor of
         per-iteration confusion counts over the images still iterating after that iteration --
         the `valid_mat[:, :, it] += jacc_iter` of iterative_inference_valid.py:231,280-288 (the
         reference calls val_fn only when the loop did not break).
         """
-        H = [self._dev(h) for h in (H if isinstance(H, (list, tuple)) else [H])]
+        H_in = list(H) if isinstance(H, (list, tuple)) else [H]
+        H = [self._dev(h) for h in H_in]
+        # where each h came from: explicit records, else what pred_fcn_fn remembered for these
+        # very tensor objects (None -> no cross-batch reuse for this call)
+        tags = list(h_provenance) if h_provenance is not None else \
+            [self.provenance_of(a) if isinstance(a, torch.Tensor) else None for a in H_in]
         y = self._dev(Y)
         if not inplace:
             y = y.clone()
@@ -136,7 +168,7 @@ class IterativeInference:
             per_iter = torch.zeros((int(num_iter), nb), dtype=torch.int64, device=y.device)
             scratch = torch.zeros(2, dtype=torch.float64, device=y.device)
         # h is fixed and only y evolves: the DAE may keep loop-invariant parts of its maps
-        sess = self.dae.new_session(H, y) if hasattr(self.dae, 'new_session') else None
+        sess = self.dae.new_session(H, y, tags=tags) if hasattr(self.dae, 'new_session') else None
         for it in range(int(num_iter)):
             score = self.dae.scores(H, y, session=sess) if sess is not None \
                 else self.dae.scores(H, y)

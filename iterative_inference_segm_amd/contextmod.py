@@ -40,7 +40,7 @@ class ContextModDAE:
         d.update({'dilconv%d' % (i + 1): c for i, c in enumerate(self.dil)})
         return d
 
-    def new_session(self, h_list=None, y=None):
+    def new_session(self, h_list=None, y=None, tags=None):
         """State of one refinement loop (h fixed, y evolving): the ConcatLayer((h, y)) buffer of
         contextmod_dae.py:55-59 with h copied in once; each step only refreshes the y channels
         (plain device copies), so conv1 runs single-source on the 16-channel halo kernel."""

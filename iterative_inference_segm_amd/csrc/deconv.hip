@@ -1,5 +1,5 @@
 // Small-channel transposed convolution in gather form (each thread owns one output pixel and
-// all <=16 output channels).  The three FCN-8 upsamplers are 11->11 channels (k4 s2, k4 s2,
+// all output channels: <=16, or <=32 for the reference's 21-class default of models/fcn8.py:17).  The three FCN-8 upsamplers are 11->11 channels (k4 s2, k4 s2,
 // k16 s8): a few MFLOP per image, latency/HBM-bound, so no matrix cores here.
 // Replaces Deconv2DLayer = Theano CorrMM_gradInputs (reference models/fcn8.py:90,100,109;
 // models/fcn_up.py:41-45), with Lasagne's filter_flip=True spatial flip:
@@ -9,7 +9,7 @@
 
 namespace {
 
-constexpr int MAXC = 16;
+constexpr int MAXC_LIMIT = 32;
 
 template <typename T>
 struct DeconvParams {
@@ -23,7 +23,7 @@ struct DeconvParams {
     int AH, AW, ay0, ax0;
 };
 
-template <typename T>
+template <typename T, int MAXC>
 __global__ __launch_bounds__(256) void deconv_gather_kernel(const DeconvParams<T> p) {
     const int OHW = p.OH * p.OW;
     const size_t n = (size_t)p.B * OHW;
@@ -78,7 +78,7 @@ int deconv(void* stream, const iiseg_deconv_desc* d, const T* x, const T* w, con
     if (d->B <= 0 || d->Cin <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->K <= 0 ||
         d->stride <= 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
         return IISEG_ERR_SHAPE;
-    if (d->Cout > MAXC) return IISEG_ERR_UNSUPPORTED;
+    if (d->Cout > MAXC_LIMIT) return IISEG_ERR_UNSUPPORTED;
     const int fullH = (d->H - 1) * d->stride + d->K, fullW = (d->W - 1) * d->stride + d->K;
     if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
     if (add && (d->ay0 < 0 || d->ax0 < 0 || d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW))
@@ -91,7 +91,12 @@ int deconv(void* stream, const iiseg_deconv_desc* d, const T* x, const T* w, con
     const size_t n = (size_t)d->B * d->OH * d->OW;
     size_t g = (n + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(deconv_gather_kernel<T>, dim3((int)g), dim3(256), 0, (hipStream_t)stream, p);
+    if (d->Cout <= 16)
+        hipLaunchKernelGGL((deconv_gather_kernel<T, 16>), dim3((int)g), dim3(256), 0,
+                           (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((deconv_gather_kernel<T, 32>), dim3((int)g), dim3(256), 0,
+                           (hipStream_t)stream, p);
     return iiseg_check_launch();
 }
 

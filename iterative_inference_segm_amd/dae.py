@@ -63,9 +63,12 @@ class StandardDAE:
                                       "only")
         self.bn = bool(bn)
         self.enc_bn = {}
-        # noise>0 mask emulation (optional): DePool2D's masks from a hidden down-path
-        # re-forward with GaussianNoiseLayer / DropoutLayer active, one fresh sample per level.
-        # Off by default: the deterministic masks are the build's reference semantics.
+        # stochastic-mask emulation (optional): DePool2D's masks from a hidden down-path
+        # re-forward with GaussianNoiseLayer / DropoutLayer active, one fresh sample per level
+        # (whenever noise > 0 OR dropout > 0: layers/mylayers.py:91-93 drops `deterministic` for
+        # every stochastic layer).  Off by default: the deterministic masks are the build's
+        # reference semantics -- a documented deviation from the reference whenever noise or
+        # dropout is non-zero.
         self.noise, self.dropout = float(noise), float(dropout)
         self.emulate_noise = bool(emulate_noise)
         self.random_source = None     # callable(kind, level, name, shape) -> tensor, or None: torch RNG
@@ -148,15 +151,17 @@ class StandardDAE:
         self._store = None
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
 
-    def new_session(self, h_list=None, y=None):
+    def new_session(self, h_list=None, y=None, tags=None):
         """State of one refinement loop (h fixed, y evolving): see `scores`.
 
-        When every h carries the provenance tag of a border-folding FCN-8 (fcn8.py: outside the
-        tagged region the map depends on that net's weights and the geometry only), the encoder
-        maps of this DAE have a batch-independent border too: the session of the previous batch
-        of the same geometry is handed out again and the first step recomputes only the region
-        that y or the image-dependent part of h can reach."""
-        tags = [getattr(h, '_iiseg_border', None) for h in (h_list or [])]
+        `tags`: one provenance record per h (FCN8.last_provenance: ((store id, geometry),
+        image-dependent region)) or None.  When EVERY h comes with the record of a border-folding
+        FCN-8 (outside the recorded region the map depends on that net's weights and the geometry
+        only), the encoder maps of this DAE have a batch-independent border too: the session of
+        the previous batch of the same geometry is handed out again and the first step recomputes
+        only the region that y or the image-dependent part of h can reach.  No records (the
+        default): a fresh session, every map computed in full on the first step."""
+        tags = list(tags) if tags is not None else [None] * len(h_list or [])
         if self.licm and self.fold_border and y is not None and tags and \
                 all(t is not None for t in tags):
             key = (tuple(t[0] for t in tags), tuple(y.shape), y.dtype)
@@ -295,8 +300,11 @@ class StandardDAE:
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')
-        if self.emulate_noise and self.noise > 0 and self.unpool_type == 'trackind' and \
-                mask_override is None:
+        # the hidden re-forward is stochastic whenever ANY stochastic layer is live: Gaussian noise
+        # (noise > 0) or the DropoutLayers (dropout > 0, even at noise == 0 -- the configuration of
+        # the reference's golden experiment name, plots.ipynb:84: dropout 0.5, z0)
+        if self.emulate_noise and (self.noise > 0 or self.dropout > 0) and \
+                self.unpool_type == 'trackind' and mask_override is None:
             mask_override = self.hidden_masks(h_list, y)
         if self.unpool_type == 'standard':
             # fcn_up.py:37-63: up_p = Deconv2DLayer(prev, n_cl, 4, stride=2, crop='valid', linear),
@@ -466,7 +474,8 @@ class StandardDAE:
         return (u >= self.dropout).to(like.dtype)     # keep mask
 
     def hidden_masks(self, h_list, y):
-        """{level: (pre, pooled)} as DePool2D sees them when dae_dict['noise'] > 0: every DePool2D
+        """{level: (pre, pooled)} as DePool2D sees them when dae_dict['noise'] > 0 or
+        dae_dict['dropout'] > 0: every DePool2D
         calls lasagne.layers.get_output([pool_in, pool]) WITHOUT deterministic=True
         (layers/mylayers.py:91-93), i.e. a fresh forward of the down path up to its level with
         GaussianNoiseLayer (fcn_down.py:60-63) and the DropoutLayers (:108-111) active.  The
@@ -476,7 +485,9 @@ class StandardDAE:
                                       'forward) is not supported')
         masks = {}
         for p in range(self.total, 0, -1):
-            t = ops.add_noise(y, self._rand('noise', p, None, y.shape, y), self.noise)
+            # GaussianNoiseLayer(sigma=0) adds nothing (and draws nothing worth emulating)
+            t = ops.add_noise(y, self._rand('noise', p, None, y.shape, y), self.noise) \
+                if self.noise > 0 else y
             pos, pending = 0, None
             if self.concat_h[0] == 'input':
                 pending, pos = h_list[0], 1

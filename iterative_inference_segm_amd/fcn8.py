@@ -81,6 +81,7 @@ class FCN8:
         self.fold_border = os.environ.get('IISEG_FCN_BORDER_FOLD', '1') != '0'
         self._border = {}
         self._uid = next(_UID)
+        self.last_provenance = None   # per output of the latest forward: (store id, region) or None
 
     def conv_layers(self):
         return self.convs
@@ -175,17 +176,22 @@ class FCN8:
         net['score'] = score
         net['probs_dimshuffle'] = ops.crop_softmax(score, oh, ow, off=(0, 0))  # :122-130,187-191
         # maps owned by the internal border store are overwritten by the next call: hand out
-        # copies, tagged with their provenance -- outside `deps[el]` such a map is a function of
+        # copies.  Their PROVENANCE is reported next to the result, never stuck onto the tensor:
+        # `last_provenance[i]` describes output i -- outside `region` such a map is a function of
         # this net's weights and the geometry alone, which lets a consumer (the DAE's encoder)
-        # keep ITS weights-only border across batches as well.  (The tag vouches for the values as
-        # returned: a caller that edits such a tensor in place must drop `_iiseg_border`.)
-        res = []
+        # keep ITS weights-only border across batches as well.  api.IterativeInference carries
+        # the records from pred_fcn_fn to refine (validated by object identity + torch's in-place
+        # version counter), or a caller passes them explicitly (`refine(..., h_provenance=)`).
+        res, prov = [], []
         for el in self.layer:
             t = net[el]
+            tag = None
             if own and el.startswith('pool'):
                 t = t.clone()
-                t._iiseg_border = ((self._uid, session['key']), deps[el])
+                tag = ((self._uid, session['key']), deps[el])
             res.append(t)
+            prov.append(tag)
+        self.last_provenance = prov
         return res
 
     def new_session(self):
@@ -227,7 +233,7 @@ class FCN8DAE:
     def conv_layers(self):
         return self.net.convs
 
-    def new_session(self, h_list=None, y=None):
+    def new_session(self, h_list=None, y=None, tags=None):
         """State of one refinement loop (h fixed, y evolving)."""
         return self.net.new_session() if self.licm else None
 

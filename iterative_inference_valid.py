@@ -37,6 +37,7 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     dae_dict.update(dae_dict_updates)
     name_kw = dict(dae_dict)
     name_kw.update(training_dict)
+    name_kw.pop('emulate_noise', None)   # extra key of this build, not part of the reference's name
     exp_name = build_experiment_name(segm_net, data_aug=data_augmentation, ae_h=ae_h, **name_kw)
     exp_name += '_ftsmall' if full_im_ft else ''                         # :86
     if savepath is None:

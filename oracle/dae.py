@@ -49,8 +49,12 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
                 dropout=0.0, hidden_rand=None):
     """pred_dae_fn(h..., y) -> r  (iterative_inference.py:189-190) for dae kind 'standard'.
 
-    Deterministic: GaussianNoiseLayer and DropoutLayer are identities (P8, P9) and the
-    DePool2D masks come from the same deterministic encoder pass (noise == 0).
+    Deterministic main path: GaussianNoiseLayer and DropoutLayer are identities (P8, P9).  The
+    DePool2D masks come from the same deterministic encoder pass unless `hidden_rand` is given
+    and noise > 0 or dropout > 0: then they come from the reference's stochastic hidden
+    re-forward (layers/mylayers.py:91-93) with the caller's samples.  Without
+    `hidden_rand` the oracle states the DETERMINISTIC-mask semantics, which deviates from the
+    reference whenever noise or dropout is non-zero (the reference is then itself random).
     """
     concat_h = list(concat_h)
     h_list = list(h_list)
@@ -89,15 +93,17 @@ def dae_forward(params, h_list, y, concat_h=('pool4',), padding=100, n_filters=6
         net['pool%d' % (p + 1)] = t = nn.maxpool2(t)         # :122
         if p < n_pool:
             t, pos = maybe_concat('pool%d' % (p + 1), t, pos)  # :131-134
-    # noise > 0: every DePool2D re-evaluates the down path up to its pool WITHOUT
+    # noise > 0 or dropout > 0: every DePool2D re-evaluates the down path up to its pool WITHOUT
     # deterministic=True (layers/mylayers.py:91-93): GaussianNoiseLayer on y (fcn_down.py:60-63)
     # and the DropoutLayers after the convs (:108-111, rescale 1/(1-p)) are active, one fresh
     # sample per DePool2D.  hidden_rand(kind, level, name, shape) supplies the samples.
     hidden = {}
-    if noise > 0 and hidden_rand is not None and unpool_type == 'trackind':
+    # The gate is "any stochastic layer live": dropout > 0 alone (noise == 0, the configuration of
+    # the golden experiment name of plots.ipynb:84) already makes the reference's masks random.
+    if (noise > 0 or dropout > 0) and hidden_rand is not None and unpool_type == 'trackind':
         assert not bn
         for p in range(total, 0, -1):
-            u = y + noise * hidden_rand('noise', p, None, y.shape)
+            u = y + noise * hidden_rand('noise', p, None, y.shape) if noise > 0 else y
             hpos = 0
             u, hpos = maybe_concat('input', u, hpos)
             for q in range(p):

@@ -45,6 +45,19 @@ def test_error_behaviour_without_gpu(tmp_path):
         ii.inference('imagenet', 'fcn8', **kw)
 
 
+def test_extra_dae_dict_key_does_not_reach_the_name_builder(tmp_path):
+    """`dae_dict['emulate_noise']` (an extra key of this build) must not be forwarded to
+    build_experiment_name, which mirrors the reference's keyword list (helpers.py:118-169): the
+    call has to get past the name to the dataset check, in both drivers."""
+    import iterative_inference as ii
+    import iterative_inference_valid as iv
+    kw = dict(savepath=str(tmp_path / 's'), loadpath=str(tmp_path / 'l'), synthetic=True,
+              verbose=False, n_images=2, dae_dict_updates={'emulate_noise': True, 'kind': 'standard'})
+    for mod in (ii, iv):
+        with pytest.raises(ValueError, match='Unknown dataset'):
+            mod.inference('imagenet', 'fcn8', **kw)
+
+
 @pytest.mark.gpu
 def test_synthetic_evaluation_end_to_end(built_lib, tmp_path):
     """2 batches of 2 images (64x48), reduced DAE width, 3 steps: summary numbers agree with the

@@ -385,12 +385,22 @@ def test_border_fold_across_batches_is_bit_identical(built_lib, size, div, nf, d
             assert np.array_equal(a, b), 'batch %d differs' % i
     assert ii_fold.dae._store is not None and ii_fold.dae._store['primed']
     assert ii_full.dae._store is None
-    # an untagged h (e.g. numpy from disk) must not touch the store
+    # provenance is explicit: pred_fcn_fn remembers the record of the tensor OBJECTS it returned
     out = ii_fold.pred_fcn_fn(X)
+    rec = ii_fold.provenance_of(out[0])
+    assert rec is not None and ii_fold.provenance_of(out[0].clone()) is None
+    assert ii_full.provenance_of(ii_full.pred_fcn_fn(X)[0]) is None     # no border store: no record
+    # a copy without a record (e.g. numpy from disk) must not touch the store ...
     h_np = host(out[0])
     y1, _, _ = ii_fold.refine([h_np], out[-1], 0.3, 2)
     y2, _, _ = ii_full.refine([h_np], out[-1], 0.3, 2)
     assert np.array_equal(host(y1), host(y2))
+    # ... the same copy WITH the record handed over explicitly may, with identical results ...
+    y3, _, _ = ii_fold.refine([out[0].clone()], out[-1], 0.3, 2, h_provenance=[rec])
+    assert np.array_equal(host(y3), host(y2))
+    # ... and an in-place edit of the original invalidates its record (torch version counter)
+    out[0].mul_(1.0)
+    assert ii_fold.provenance_of(out[0]) is None
 
 
 def test_fcn8_kind_dae_session_is_bit_identical(built_lib):
@@ -492,6 +502,15 @@ def test_noise_mask_emulation(built_lib, dtype, tol):
     assert np.abs(ref - det).max() > 1e-3          # the noisy masks do change the output
     dae.emulate_noise = False
     assert np.abs(host(dae(ht, yt)) - det).max() <= tol
+    # dropout alone (noise == 0, the golden-name configuration): the hidden re-forward is live too
+    def keep_only(kind, level, name, shape):
+        assert kind == 'dropout'
+        return samples(kind, level, name, shape)
+    dz = StandardDAE(dp, 11, dtype=dtype, noise=0.0, dropout=0.3, emulate_noise=True, **kw)
+    dz.random_source = keep_only
+    ref_z = odae.dae_forward(to64(dp), [h], y, noise=0.0, dropout=0.3, hidden_rand=keep_only, **kw)
+    assert np.abs(host(dz(ht, yt)) - ref_z).max() <= tol
+    assert np.abs(ref_z - det).max() > 1e-3
     # default RNG path: runs, is reproducible per seed, and differs from the deterministic masks
     a = StandardDAE(dp, 11, dtype=dtype, noise=0.5, dropout=0.3, emulate_noise=True, seed=5, **kw)
     b = StandardDAE(dp, 11, dtype=dtype, noise=0.5, dropout=0.3, emulate_noise=True, seed=5, **kw)

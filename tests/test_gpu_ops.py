@@ -385,6 +385,20 @@ def test_deconv_flip_and_crop_add(ops, k, s, H, W):
     assert np.abs(got2 - ref2).max() <= 1e-5 * (1 + np.abs(ref2).max())
 
 
+def test_deconv_21_classes(ops):
+    """The reference's default n_classes=21 (models/fcn8.py:17): the gather-form transposed conv
+    takes up to 32 channels (the 32-channel instantiation), k16 s8 and k4 s2."""
+    rng = np.random.default_rng(21)
+    for k, s, H, W in [(4, 2, 6, 5), (16, 8, 3, 4)]:
+        x, Wt, b = rnd(rng, 2, 21, H, W), rnd(rng, 21, 21, k, k), rnd(rng, 21)
+        ref = onn.deconv2d(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), stride=s)
+        got = host(ops.Deconv(Wt, b, s)(dev(x)))
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-5 * (1 + np.abs(ref).max())
+    with pytest.raises(RuntimeError, match='no kernel variant'):
+        ops.Deconv(rnd(rng, 4, 33, 4, 4), rnd(rng, 33), 2)(dev(rnd(rng, 1, 4, 3, 3)))
+
+
 def test_crop_softmax_and_residual(ops):
     rng = np.random.default_rng(3)
     score = 5 * rnd(rng, 2, 11, 30, 28)

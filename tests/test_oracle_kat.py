@@ -179,3 +179,34 @@ def test_metrics_orientation_void_and_mse():
     assert mse == pytest.approx((2 / 3) / 3)
     loss, a, j = ometrics.summarize(mse * 2, acc * 2, jacc * 2, 2)
     assert (loss, a) == (pytest.approx(mse), pytest.approx(acc)) and j == pytest.approx((0.5 + 0 + 1) / 3)
+
+
+def test_hidden_reforward_is_live_with_dropout_alone():
+    """layers/mylayers.py:91-93 calls get_output without deterministic=True, so the DropoutLayers
+    of models/fcn_down.py:108-111 are live in DePool2D's hidden re-forward even at noise == 0 (the
+    configuration of the golden experiment name, plots.ipynb:84: dropout 0.5, z0).  With injected
+    keep-masks the oracle must (a) differ from the deterministic masks, (b) fall back to them when
+    every unit is kept at p -> 0, (c) draw no Gaussian sample at `noise == 0`."""
+    from oracle import dae as odae
+    from iterative_inference_segm_amd import synthetic as S
+    rng = np.random.default_rng(5)
+    concat_h, nf = ['pool2'], 4
+    dp = S.make_dae_params(h_channels=(3,), concat_h=concat_h, n_filters=nf, additional_pool=1, seed=6)
+    dp = {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in dp.items()}
+    y = rng.random((1, 11, 16, 20)); y /= y.sum(1, keepdims=True)
+    h = rng.random((1, 3, (16 + 198) // 4, (20 + 198) // 4))
+    kw = dict(concat_h=concat_h, n_filters=nf, additional_pool=1)
+    det = odae.dae_forward(dp, [h], y, **kw)
+
+    def keep(kind, level, name, shape):
+        assert kind == 'dropout'                   # noise == 0: no Gaussian sample is drawn
+        g = np.random.default_rng(abs(hash((level, name))) % (2 ** 32))
+        return (g.random(shape) >= 0.5).astype(np.float64)
+    got = odae.dae_forward(dp, [h], y, noise=0.0, dropout=0.5, hidden_rand=keep, **kw)
+    assert np.abs(got - det).max() > 1e-3
+    # p -> 0 with every unit kept: the hidden forward IS the deterministic one
+    all_kept = odae.dae_forward(dp, [h], y, noise=0.0, dropout=1e-300,
+                                hidden_rand=lambda k, l, n, shp: np.ones(shp), **kw)
+    assert np.abs(all_kept - det).max() <= 1e-12
+    # no sample source: the documented deterministic-mask semantics
+    assert np.array_equal(odae.dae_forward(dp, [h], y, noise=0.0, dropout=0.5, **kw), det)
