@@ -4,28 +4,40 @@
 Workload (BASELINE.json configs[1]): FCN-8 + standard DAE (n_filters=64, additional_pool=2,
 concat_h=['pool4'], trackind unpool, skip), 11 classes, synthetic random 224x224x3 images,
 batch 64 per GPU, 10 refinement steps (step 0.1, early stop disabled so the work is fixed),
-fp32 HIP kernels.  One "step" = one batch through pred_fcn_fn -> refine x10 -> val_fn.
-
-Work accounting.  `value` is measured with the exact work eliminations on (DESIGN.md 3.3):
-decoder levels are computed only on the window that reaches the final center crop (dead code
-otherwise); inside the 10-step loop only the y-dependent part of the DAE encoder maps is recomputed
-(the pad-100 border and the h-only contributions are loop-invariant); and the pad-100 border of the
-FCN-8 / DAE encoder maps, a function of the weights alone, is folded once per input geometry at
-load time (`ii.prepare`, from an all-zero image) -- every timed step runs on a DIFFERENT image batch.  All are tested to give
-BIT-IDENTICAL refined maps (tests/test_gpu_e2e.py).  The JSON also carries the same run with the
-cross-batch border stores off (`per_batch_only`) and with every elimination off (`full_recompute`:
-every layer recomputed in full every step, 872 nominal GFLOP/image).
+fp32 HIP kernels.  One "step" = one batch through the per-batch path of reference
+iterative_inference.py:226-294: pred_fcn_fn -> val_fn (FCN metrics, :242) -> pred_dae_fn + val_fn
+(one-shot DAE metrics, :250-251; the same DAE forward as the loop's first step, shared) ->
+refine x10 (:258-284) -> val_fn (:287).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     : the implicit-GEMM conv kernel, HIP-event timed per launch in an extra pass
-  cpu_baseline : the numpy/BLAS float32 restatement (oracle, "port") on the host cores, N=1 only
+N > 1 without a torch.distributed environment: this process only LAUNCHES
+`python -m torch.distributed.run --nproc-per-node N ... bench.py ...` as a child (before anything
+here touches the GPU), forwards rank 0's JSON line and exits with the child's code.  Under
+torch.distributed.run (the driver's own launch line) every rank runs `worker()`.
+
+Work accounting.  `value` is measured with the exact work eliminations on (DESIGN.md 3.3):
+decoder levels computed only on the window that reaches the final center crop; inside the 10-step
+loop only the y-dependent part of the DAE encoder maps recomputed; the weights-only pad-100 borders
+folded once per input geometry at load time (`ii.prepare`, from an all-zero image) -- every timed
+step runs on a DIFFERENT image batch.  All are tested to give BIT-IDENTICAL refined maps.  The JSON
+also carries the run with the cross-batch border stores off (`per_batch_only`) and with every
+elimination off (`full_recompute`, all 872.3 nominal GFLOP/image executed).
+
+Extra objects on the ONE JSON line rank 0 prints:
+  roofline     the dominant kernel from HIP events around every conv launch (extra, untimed pass
+               behind a queued-up stream so that no bracket contains host launch gaps), plus
+               `whole_path` = executed conv FLOPs / ms_per_step
+  strict_f64   the float64 path (the reference's CPU numerics) on the same config: the number
+               that carries the 1e-4 parity claim end to end
+  cpu_baseline float32 torch-CPU restatement of the same loop on the host cores (oracle/, "port"),
+               reference-faithful per-image schedule and a batched one; rank 0, N = 1 only
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,77 +53,214 @@ from iterative_inference_segm_amd import synthetic as S  # noqa: E402
 N_CLASSES = 11
 GFLOP_PER_IMAGE = 872.3          # 119.24 (FCN-8) + 10 x 75.31 (DAE), nominal
 PEAK_TFLOPS_F32_MFMA = 157.3     # MI355X_MICROARCH.md, fp32 matrix peak
-# HBM GB per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
-# MI355X_MICROARCH.md HBM section), profiles/r01_pmc_hbm_traffic.md; None = not measured
-TRAFFIC_GB_PER_LAUNCH = {'wino_gemm_kernel': 1.048, 'wino_fused_kernel': 1.430,
-                         'conv_halo_f32_kernel': 1.456, 'conv_taps_f32_kernel': 0.293}
+PEAK_TFLOPS_F64_MFMA = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate
 
 
-def build_model(device, concat_h):
+def build_model(device, concat_h, dtype=torch.float32):
     from iterative_inference_segm_amd.api import IterativeInference
     from iterative_inference_segm_amd.dae import StandardDAE
     from iterative_inference_segm_amd.fcn8 import FCN8
     fp = S.make_fcn8_params(seed=1234)      # same seed on every rank: replicated weights
     dp = S.make_dae_params(seed=4321)
-    fcn = FCN8(fp, N_CLASSES, layer=concat_h + ['probs_dimshuffle'], device=device)
+    fcn = FCN8(fp, N_CLASSES, layer=concat_h + ['probs_dimshuffle'], device=device, dtype=dtype)
     dae = StandardDAE(dp, N_CLASSES, concat_h=concat_h, padding=100, n_filters=64,
-                      additional_pool=2, skip=True, unpool_type='trackind', device=device)
-    return IterativeInference(fcn, dae, N_CLASSES, [N_CLASSES], device=device), fp, dp
+                      additional_pool=2, skip=True, unpool_type='trackind', device=device,
+                      dtype=dtype)
+    return IterativeInference(fcn, dae, N_CLASSES, [N_CLASSES], device=device, dtype=dtype), fp, dp
 
 
 def one_step(ii, X, T, num_iter, step_size):
-    """One batch of the hot path; returns the device-side metric accumulators."""
-    out = ii.pred_fcn_fn(X)
+    """One batch of the per-batch path (iterative_inference.py:237-287); returns the device-side
+    metric accumulators (refined, FCN, one-shot DAE)."""
+    out = ii.pred_fcn_fn(X)                                            # :237-239
     H, Y = out[:-1], out[-1]
-    Yii, _, _ = ii.refine(H, Y, step_size, num_iter, early_stop=False)
-    return ii.val_device(Yii, T), ii.val_device(Y, T)
+    m_fcn = ii.val_device(Y, T)                                        # :242
+    Yii, _, _, R0 = ii.refine(H, Y, step_size, num_iter, early_stop=False,
+                              first_reconstruction=True)               # :258-284
+    m_dae = ii.val_device(R0, T)                                       # :250-251 (shared forward)
+    return ii.val_device(Yii, T), m_fcn, m_dae                         # :287
 
 
-def cpu_baseline(fp, dp, num_iter, step_size, concat_h):
-    """Times the oracle's float32 numpy/BLAS restatement (same loop, one image) on the host."""
-    from oracle import dae as odae, fcn8 as ofcn8, refine as orefine
-    x = S.make_images(1, 224, 224, seed=777)
-    to32 = lambda p: {k: tuple(np.asarray(a, np.float32) for a in v) for k, v in p.items()}
-    fp32, dp32 = to32(fp), to32(dp)
-    t0 = time.time()
-    h, y = ofcn8.fcn8_forward(fp32, x, layer=concat_h + ['probs_dimshuffle'])
-    orefine.refine_batch(lambda hh, yy: odae.dae_forward(dp32, hh, yy), [h], y, step_size,
-                         num_iter, eps=-1.0)
-    dt = time.time() - t0
-    return {'value': round(1.0 / dt, 5), 'unit': 'images/s', 'cores': os.cpu_count(),
-            'kind': 'port',
-            'sample': '1 image 224x224, FCN-8 + %d DAE steps, numpy/BLAS float32 restatement '
-                      '(oracle), %.1f s' % (num_iter, dt)}
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
-def conv_roofline(ii, X, T, num_iter, step_size):
-    """Extra (untimed) pass with HIP events around every conv launch on the launch stream."""
+def cpu_baseline(fp, dp, num_iter, step_size, budget_s=12.0):
+    """SURVEY 8(d) / BASELINE.md section 4: the float32 torch-CPU restatement of the identical loop
+    (oracle/torch_cpu.py) on all host cores, 1 warm-up batch, then timed batches of 10 images -- 3 of
+    them when that fits `budget_s` per schedule, fewer / smaller otherwise (the sample is stated).
+    `value` is the reference-faithful per-image (B = 1) schedule of iterative_inference.py:258-284;
+    `batched` runs the DAE on the whole batch per step."""
+    from oracle import torch_cpu as tcpu
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    torch.set_num_threads(max(1, cores))
+    Pf, Pd = tcpu.prepare_params(fp), tcpu.prepare_params(dp)
+    res = {}
+    for name, per_image in (('per_image', True), ('batched', False)):
+        t0 = time.perf_counter()
+        tcpu.run_batch(Pf, Pd, S.make_images(2, 224, 224, seed=700), step_size, num_iter, per_image)
+        t_img = (time.perf_counter() - t0) / 2            # warm-up batch (2 images), not reported
+        n_img = int(max(2, min(30, budget_s / max(t_img, 1e-3))))
+        sizes = [10, 10, 10] if n_img >= 30 else ([n_img // 2, n_img - n_img // 2] if n_img >= 4
+                                                   else [n_img])
+        t0 = time.perf_counter()
+        for i, b in enumerate(sizes):
+            tcpu.run_batch(Pf, Pd, S.make_images(b, 224, 224, seed=701 + i), step_size, num_iter,
+                           per_image)
+        dt = time.perf_counter() - t0
+        res[name] = {'value': round(sum(sizes) / dt, 4), 'images': sum(sizes), 'batches': sizes,
+                     'seconds': round(dt, 2)}
+    v = res['per_image']['value']
+    return {'value': v, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'cpu_model': _cpu_model(), 'torch_threads': torch.get_num_threads(),
+            'gflops_nominal': round(v * GFLOP_PER_IMAGE, 1),
+            'batched': res['batched'], 'per_image': res['per_image'],
+            'sample': 'float32 torch-CPU restatement (oracle/torch_cpu.py; CPU restatement, baseline '
+                      'only) of FCN-8 + %d DAE steps at 224x224: 1 warm-up batch of 2 images, then '
+                      'batches of %s images (reference-faithful per-image B=1 schedule, %.1f s) and '
+                      '%s images (batched schedule, %.1f s)'
+                      % (num_iter, res['per_image']['batches'], res['per_image']['seconds'],
+                         res['batched']['batches'], res['batched']['seconds'])}
+
+
+def _traffic(kernel):
+    """HBM GB per launch of `kernel` from the committed rocprofv3 PMC artefact (two --pmc passes,
+    FETCH_SIZE x2 correction + WRITE_SIZE; scripts/make_profiles.py pmc), with its provenance; None
+    when the artefact has no row for this kernel."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic_latest.json')
+    try:
+        art = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    gb = art.get('gb_per_launch', {}).get(kernel)
+    return gb, {'file': 'profiles/hbm_traffic_latest.json', 'commit': art.get('commit'),
+                'source': art.get('source')}
+
+
+def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
+    """Extra (untimed) pass with HIP events immediately around every conv launch, on the launch
+    stream.  The stream is first blocked by a spin kernel (torch.cuda._sleep) long enough for the
+    host to enqueue the whole step behind it, so the GPU then runs launch after launch and a
+    bracket never contains a host-side launch gap: all_conv_ms_per_step <= ms_per_step on any host."""
     from iterative_inference_segm_amd import ops
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(6e8))          # ~0.25-0.3 s of GPU time: the host runs ahead meanwhile
     ops.CONV_PROFILE = prof = []
     one_step(ii, X, T, num_iter, step_size)
     torch.cuda.synchronize()
     ops.CONV_PROFILE = None
-    # dominant kernel = the one with the largest total time: the Winograd GEMM (wide 3x3 layers)
-    # or the static-tap direct conv (everything else; fc6 7x7 runs on conv_igemm)
     per = {}
     for k, f, s, e in prof:
         ent = per.setdefault(k, [0.0, 0.0, 0])
         ent[0] += f; ent[1] += s.elapsed_time(e); ent[2] += 1
-    kern = max(per, key=lambda k: per[k][1])
+    # dominant kernel = largest total time among the matrix-core kernels
+    kern = max((k for k in per if per[k][0] > 0), key=lambda k: per[k][1])
     flops, ms, n = per[kern]
     all_ms = sum(v[1] for v in per.values())
+    all_gflop = sum(f for _, f, _, _ in prof) / 1e9
     achieved = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': kern, 'achieved': round(achieved, 2),
-            'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_TFLOPS_F32_MFMA, 4),
-            'traffic': TRAFFIC_GB_PER_LAUNCH.get(kern),
-            'traffic_unit': 'GB of HBM traffic per launch (rocprofv3 PMC, profiles/)',
+    gb, prov = _traffic(kern)
+    whole = all_gflop / ms_per_step          # GFLOP / ms = TFLOP/s
+    return {'bound': 'mfma', 'kernel': kern, 'achieved': round(achieved, 2), 'peak': peak,
+            'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': gb,
+            'traffic_unit': 'GB of HBM traffic per launch (rocprofv3 PMC passes)',
+            'traffic_provenance': prov,
             'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
             'gflop_per_launch': round(flops / n / 1e9, 3), 'kernel_ms_per_step': round(ms, 2),
             'per_kernel_ms_per_step': {k: round(v[1], 2) for k, v in per.items()},
             'per_kernel_tflops': {k: round(v[0] / v[1] / 1e9, 1) for k, v in per.items() if v[0]},
             'all_conv_ms_per_step': round(all_ms, 2),
-            'all_conv_gflop_per_step': round(sum(f for _, f, _, _ in prof) / 1e9, 1)}
+            'all_conv_gflop_per_step': round(all_gflop, 1),
+            'whole_path': {'executed_tflops': round(whole, 2), 'frac': round(whole / peak, 4),
+                           'note': 'FLOPs the conv kernels actually issue per step (Winograd layers '
+                                   'count their 4/9) / ms_per_step of the timed run / MFMA peak'}}
+
+
+def timed_steps(ii, Xs, Ts, steps, warmup, num_iter, step_size, world, device, start=0):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks.
+    Returns (seconds, per-step metric accumulators)."""
+    it, n = start, len(Xs)
+    for _ in range(warmup):
+        one_step(ii, Xs[it % n], Ts[it % n], num_iter, step_size)
+        it += 1
+    torch.cuda.synchronize()
+    iidist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    results = []
+    for _ in range(steps):
+        results.append(one_step(ii, Xs[it % n], Ts[it % n], num_iter, step_size))
+        it += 1
+    return t0, results
+
+
+def launch_workers(args, argv):
+    """Parent of an N-GPU run: never touches the GPU, starts torch.distributed.run as a CHILD
+    process (one rank per GPU), forwards its output and exits with its code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this pool (RCCL)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for out in proc.stdout:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.lstrip().startswith('{"metric"'):
+            line = out
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write('bench.py: workers exited without a result line\n')
+        rc = 1
+    return rc
+
+
+def dry_run(args):
+    """CPU rehearsal of the multi-rank protocol (no HIP work): rendezvous, barrier-bracketed
+    timing with max over ranks, the metric all-reduce, rank 0's JSON line.  `value` is null."""
+    rank, world, device = iidist.init_from_env('cpu')
+    if world != args.gpus:
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    iidist.barrier()
+    t0 = time.perf_counter()
+    acc = iidist.EvalAccumulator(N_CLASSES)
+    for i in range(args.steps):
+        cm = np.zeros((N_CLASSES, N_CLASSES + 1))
+        cm[rank % N_CLASSES, rank % N_CLASSES] = 1 + i
+        acc.add_batch(cm, 1.0, 0.0)
+    acc.all_reduce(device)
+    iidist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'refined images/s (dry run: protocol only, no GPU work)',
+                          'value': None, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'f32', 'data': 'none', 'dry_run': True,
+                          'batches_reduced': acc.results()[4],
+                          'config': {'workload': 'dry run', 'parallelism': 'dp%d' % world}}),
+              flush=True)
+    iidist.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 def main():
@@ -124,18 +273,30 @@ def main():
     ap.add_argument('--step_size', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-full-recompute', action='store_true',
-                    help='skip the extra timed run with DCE/LICM off')
+                    help='skip the extra timed runs with the work eliminations off')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-strict-f64', action='store_true',
+                    help='skip the float64 (strict parity) leg')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU rehearsal of the launch / reduction protocol, no GPU work')
     args = ap.parse_args()
 
+    # N > 1 outside a torch.distributed environment: fan out FIRST, before any GPU call
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_workers(args, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
+    worker(args)
+
+
+def worker(args):
     rank, world, device = iidist.init_from_env('cuda')
     if world != args.gpus:
-        raise SystemExit('WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run '
-                         '--nproc-per-node %d' % (world, args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     concat_h = ['pool4']
     ii, fp, dp = build_model(device, concat_h)
     B = args.batch
-    # weak scaling: every rank refines its own shard of `B` synthetic images per step
+    # weak scaling: every rank refines its own shard of `B` synthetic images per step;
     # distinct image batches per step (up to 4, then rotating): nothing image-dependent can be
     # carried from one step to the next
     n_distinct = max(1, min(args.steps + args.warmup, 4))
@@ -143,33 +304,19 @@ def main():
           for i in range(n_distinct)]
     Ts = [torch.from_numpy(S.make_labels(B, 224, 224, seed=99 + rank + 1000 * i)).to(device)
           for i in range(n_distinct)]
-    X, T = Xs[0], Ts[0]
-    it = 0
     # load-time constant folding of the weights-only borders for this geometry (from a zero image)
     ii.prepare(B, 224, 224)
 
-    for _ in range(args.warmup):
-        one_step(ii, Xs[it % n_distinct], Ts[it % n_distinct], args.num_iter, args.step_size)
-        it += 1
-    torch.cuda.synchronize()
-    iidist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    results = []
-    for _ in range(args.steps):
-        results.append(one_step(ii, Xs[it % n_distinct], Ts[it % n_distinct], args.num_iter,
-                                args.step_size))
-        it += 1
+    t0, results = timed_steps(ii, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
+                              world, device)
     # the path's only collective: one all-reduce of the metric accumulator (RCCL over xGMI)
-    acc_ii = iidist.EvalAccumulator(N_CLASSES)
-    acc_fcn = iidist.EvalAccumulator(N_CLASSES)
-    for m_ii, m_fcn in results:
-        a, j, mse = m_ii.result()
-        acc_ii.add_batch(m_ii.cm.cpu().numpy(), a, mse)
-        a, j, mse = m_fcn.result()
-        acc_fcn.add_batch(m_fcn.cm.cpu().numpy(), a, mse)
-    acc_ii.all_reduce(device)
-    acc_fcn.all_reduce(device)
+    accs = [iidist.EvalAccumulator(N_CLASSES) for _ in range(3)]
+    for ms in results:
+        for acc, m in zip(accs, ms):
+            a, j, mse = m.result()
+            acc.add_batch(m.cm.cpu().numpy(), a, mse)
+    for acc in accs:
+        acc.all_reduce(device)
     torch.cuda.synchronize()
     iidist.barrier()
     torch.cuda.synchronize()
@@ -181,63 +328,89 @@ def main():
 
     images = world * B * args.steps
     value = images / dt
+    ms_per_step = dt / args.steps * 1e3
     line = {
         'metric': 'refined images/s (FCN-8 + standard DAE, 10-step iterative inference, 224x224, '
                   '11 classes)',
         'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic (seeded uniform images, blob labels, He-uniform random weights)',
         'config': {'workload': 'BASELINE configs[1]: FCN-8 + standard DAE (f64c1p2, pool4, '
                                'trackind, skip), 224x224x3, batch %d/GPU, %d steps, step %.2g, '
-                               'early stop off' % (B, args.num_iter, args.step_size),
+                               'early stop off; per batch: pred_fcn_fn, val_fn, pred_dae_fn+val_fn, '
+                               'refine, val_fn' % (B, args.num_iter, args.step_size),
                    'global_batch': world * B, 'parallelism': 'dp%d' % world},
-        'nominal_tflops': round(value * GFLOP_PER_IMAGE / 1e3, 2),
+        'nominal_equivalent_tflops': {
+            'value': round(value * GFLOP_PER_IMAGE / 1e3, 2),
+            'note': 'images/s x 872.3 nominal GFLOP/image (SURVEY 6.2).  NOT a hardware rate: the '
+                    'exact work eliminations and Winograd issue far fewer FLOPs; the hardware rate '
+                    'is roofline.whole_path'},
+        'parity': {'fp32_value': 'teacher-forced-mask 1e-4 + statistical free-running criterion '
+                                 '(DePool2D equality masks are a discontinuity; DESIGN.md section 4)',
+                   'strict_1e-4_end_to_end': 'strict_f64 leg (float64 = the reference CPU numerics)'},
     }
-    loss, acc, miou, _, nb = acc_ii.results()
-    _, acc_f, miou_f, _, _ = acc_fcn.results()
+    _, acc, miou, _, nb = accs[0].results()
+    _, acc_f, miou_f, _, _ = accs[1].results()
+    _, acc_d, miou_d, _, _ = accs[2].results()
     line['miou'] = {'iterative_inference': round(miou, 5), 'fcn': round(miou_f, 5),
-                    'acc_ii': round(acc, 5), 'acc_fcn': round(acc_f, 5), 'batches': nb,
+                    'dae_one_shot': round(miou_d, 5), 'acc_ii': round(acc, 5),
+                    'acc_fcn': round(acc_f, 5), 'acc_dae': round(acc_d, 5), 'batches': nb,
                     'note': 'consistency metric (random weights), reduced over ranks'}
+    X, T = Xs[0], Ts[0]
     if not args.no_roofline:
-        rl = conv_roofline(ii, X, T, args.num_iter, args.step_size)
+        rl = conv_roofline(ii, X, T, args.num_iter, args.step_size, ms_per_step,
+                           PEAK_TFLOPS_F32_MFMA)
         line['roofline'] = rl
         line['executed_gflop_per_image'] = round(rl['all_conv_gflop_per_step'] / B, 1)
+
+    def leg(model, xs, ts, steps, warmup):
+        t1, _ = timed_steps(model, xs, ts, steps, warmup, args.num_iter, args.step_size, world, device)
+        torch.cuda.synchronize()
+        iidist.barrier()
+        d = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([d], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            d = float(tmax.item())
+        v = world * xs[0].shape[0] * steps / d
+        return {'value': round(v, 3), 'unit': 'images/s', 'ms_per_step': round(d / steps * 1e3, 2)}
+
     if not args.no_full_recompute:
         # same timing protocol with the exact work eliminations switched off, in two stages:
         #   per_batch_only : nothing is kept from one batch to the next (no weights-only border
         #                    stores); decoder DCE / in-loop invariants / h-half stay on
         #   full_recompute : every layer of every step and batch recomputed in full
-        def timed_leg():
-            one_step(ii, X, T, args.num_iter, args.step_size)
-            torch.cuda.synchronize()
-            iidist.barrier()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                one_step(ii, Xs[i % n_distinct], Ts[i % n_distinct], args.num_iter, args.step_size)
-            torch.cuda.synchronize()
-            iidist.barrier()
-            d = time.perf_counter() - t1
-            if world > 1:
-                tmax = torch.tensor([d], dtype=torch.float64, device=device)
-                torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-                d = float(tmax.item())
-            v = world * B * args.steps / d
-            return {'value': round(v, 3), 'unit': 'images/s',
-                    'ms_per_step': round(d / args.steps * 1e3, 2),
-                    'nominal_tflops': round(v * GFLOP_PER_IMAGE / 1e3, 2)}
         ii.fcn.fold_border = ii.dae.fold_border = False
-        line['per_batch_only'] = dict(timed_leg(), note='IISEG_FCN_BORDER_FOLD=0 '
+        line['per_batch_only'] = dict(leg(ii, Xs, Ts, args.steps, 1), note='IISEG_FCN_BORDER_FOLD=0 '
                                       'IISEG_DAE_BORDER_FOLD=0: no state carried between batches')
         ii.dae.dce = ii.dae.licm = False
         line['full_recompute'] = dict(
-            timed_leg(), note='IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
-                              'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in '
-                              'full every step and batch (same kernels)')
+            leg(ii, Xs, Ts, args.steps, 1),
+            note='IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
+                 'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in full every '
+                 'step and batch (same kernels)')
         ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
+    if not args.no_strict_f64:
+        # the float64 path (reference CPU numerics): same config at batch 16, the leg
+        # that carries the end-to-end 1e-4 parity claim (tests/test_gpu_f64.py)
+        del ii
+        torch.cuda.empty_cache()
+        b64 = min(B, 16)
+        ii64, _, _ = build_model(device, concat_h, dtype=torch.float64)
+        ii64.prepare(b64, 224, 224)
+        X64 = [x[:b64].to(torch.float64) for x in Xs[:2]]
+        T64 = [t[:b64].to(torch.float64) for t in Ts[:2]]
+        f64 = leg(ii64, X64, T64, 3, 1)
+        f64.update(dtype='f64', batch=b64,
+                   note='float64 HIP kernels (v_mfma_f64_16x16x4_f64), identical loop and work '
+                        'eliminations; refined map within 1e-4 of the float64 oracle end to end '
+                        '(measured ~1e-11, tests/test_gpu_f64.py)')
+        line['strict_f64'] = f64
+        del ii64
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(fp, dp, args.num_iter, args.step_size, concat_h)
+            line['cpu_baseline'] = cpu_baseline(fp, dp, args.num_iter, args.step_size)
         print(json.dumps(line), flush=True)
     iidist.barrier()
     if torch.distributed.is_initialized():

@@ -126,7 +126,8 @@ class IterativeInference:
 
     # ---- fused loop ---------------------------------------------------------------------
     def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
-               per_iter_target=None, mode='residual', h_provenance=None):
+               per_iter_target=None, mode='residual', h_provenance=None,
+               first_reconstruction=False):
         """Batched replacement of iterative_inference.py:258-284.
 
         for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
@@ -139,6 +140,10 @@ class IterativeInference:
             y = clip(y - step * (J_r^T 2(r - y) - 2(r - y)), 0, 1),
         with a hand-written backward pass through the DAE (`StandardDAE.backward_y`); the stop
         test uses mean_px ||grad||_2.
+
+        `first_reconstruction`: also return r(y_0 | h) = softmax of the first step's score map, i.e.
+        the `pred_dae_fn(H, Y)` of iterative_inference.py:250 without a second DAE forward (it is
+        the same forward as the loop's first `de_fn` call); appended to the returned tuple.
 
         `h_provenance`: explicit provenance records for H (one per h, `provenance_of(h)` of the
         tensors pred_fcn_fn returned) when the caller hands in copies of them; default: looked up
@@ -161,7 +166,7 @@ class IterativeInference:
         B, _, Hh, Ww = y.shape
         st = ops.RefineState(B, Hh, Ww, y.device)
         eps_eff = eps if early_stop else -1.0
-        per_iter = None
+        per_iter, r0 = None, None
         if per_iter_target is not None:
             T = self._dev(per_iter_target)
             nb = self.n_classes * (self.n_classes + 1)
@@ -172,6 +177,8 @@ class IterativeInference:
         for it in range(int(num_iter)):
             score = self.dae.scores(H, y, session=sess) if sess is not None \
                 else self.dae.scores(H, y)
+            if it == 0 and first_reconstruction:
+                r0 = ops.crop_softmax(score, Hh, Ww, off=(0, 0))
             if mode == 'gradient':
                 g_score = ops.sqerr_softmax_bwd(score, y, off=(0, 0))
                 ops.grad_update(score, self.dae.backward_y(g_score, y.shape), y, st, step,
@@ -188,9 +195,12 @@ class IterativeInference:
             # One small device->host read per iteration, only when early stopping is on.
             if early_stop and it + 1 < int(num_iter) and not bool(st.active.any()):
                 break
+        res = (y, st.iters, st.last_norm)
         if per_iter is not None:
-            return y, st.iters, st.last_norm, per_iter
-        return y, st.iters, st.last_norm
+            res = res + (per_iter,)
+        if first_reconstruction:
+            res = res + (r0,)
+        return res
 
     def _dev(self, a):
         if isinstance(a, torch.Tensor):

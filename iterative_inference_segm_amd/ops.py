@@ -47,6 +47,13 @@ def _wino_workspace(n, device):
     return ws
 
 
+def _ev():
+    """A HIP event recorded on the launch stream right now (bench.py's roofline leg)."""
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
 def _stream():
     if not torch.cuda.is_available():
         raise RuntimeError('iiseg ops need device tensors on a HIP GPU; none is available and '
@@ -249,25 +256,23 @@ class Conv:
             out = torch.empty((B, self.Cout, d.OH, d.OW), dtype=dt, device=x1.device)
         elif tuple(out.shape) != (B, self.Cout, d.OH, d.OW) or out.dtype != dt:
             raise RuntimeError('out shape %s != %s' % (tuple(out.shape), (B, self.Cout, d.OH, d.OW)))
+        # profiling: every launch is bracketed by events recorded IMMEDIATELY around the ctypes
+        # call (after all planning / workspace work), so a bracket holds the kernel and nothing else
         prof = CONV_PROFILE
-        if prof is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         if pool_out is None and self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
-            return self._call_wino(d, x1, x2, pre, pooled, add, out, prof,
-                                   ev0 if prof is not None else None)
+            return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
         if pool_out is not None:
             fh, fw = self.out_hw(H, W)
             if dt != torch.float32 or tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2) or \
                     not self.lib.iiseg_conv_pool_supported(C.byref(d)):
                 raise RuntimeError('conv + pool fusion is not available for this launch')
+            ev0 = _ev() if prof is not None else None
             check(self.lib.iiseg_conv_pool_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
                                                _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
                                                _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out)),
                   'iiseg_conv_pool_f32')
             if prof is not None:
-                ev1.record()
-                prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
+                prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
             return out
         gemm_shape = self.kernel == 'conv_igemm_f32_kernel' or (
             # deep 1x1 layers on few pixels (fc7, score_fr): the same split-K GEMM beats the 1x1 tap
@@ -281,13 +286,14 @@ class Conv:
                 check(self.lib.iiseg_conv_gemm_f32(_stream(), *args, 7), 'iiseg_conv_gemm_f32')
                 return out
             names = ('gemm_im2col_kernel', 'wino_gemm_kernel', 'gemm_output_kernel')
+            ev0 = _ev()
             for i, stage in enumerate((1, 2, 4)):        # the three kernels separately
                 check(self.lib.iiseg_conv_gemm_f32(_stream(), *args, stage), 'iiseg_conv_gemm_f32')
-                ev1 = torch.cuda.Event(enable_timing=True)
-                ev1.record()
+                ev1 = _ev()
                 prof.append((names[i], self.flops(B, d.OH, d.OW) if i == 1 else 0.0, ev0, ev1))
                 ev0 = ev1
             return out
+        ev0 = _ev() if prof is not None else None
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
                                           _ptr(pre, dt), _ptr(pooled, dt), _ptr(wp, dt),
@@ -298,7 +304,7 @@ class Conv:
                                           _ptr(pooled), _ptr(wp), _ptr(ktab, torch.int32),
                                           _ptr(self.b), _ptr(add), _ptr(out)), 'iiseg_conv_f32')
         if prof is not None:
-            ev1.record()
+            ev1 = _ev()
             kern = self.kernel
             if kern == 'conv_halo_f32_kernel' and C2 > 0 and C1 % 4:
                 kern = 'conv_taps_f32_kernel'      # a k-tile would straddle the two sources
@@ -323,17 +329,14 @@ class Conv:
                 tuple(out.shape[2:]) != (d.OH, d.OW) or out_c0 + self.Cout > out.shape[1]:
             return None
         prof = CONV_PROFILE
-        if prof is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         beta, gamma, mean, inv_std = bn
+        ev0 = _ev() if prof is not None else None
         check(self.lib.iiseg_conv_bnrelu_f32(_stream(), C.byref(d), _ptr(stack), cap * H * W,
                                              _ptr(beta), _ptr(gamma), _ptr(mean), _ptr(inv_std),
                                              _ptr(wp), _ptr(ktab, torch.int32), _ptr(self.b),
                                              _ptr(out)), 'iiseg_conv_bnrelu_f32')
         if prof is not None:
-            ev1.record()
-            prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, ev1))
+            prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
         return out
 
     def pool_window(self, H, W, region=None):
@@ -355,7 +358,7 @@ class Conv:
             x1 = fw
         return (y0, x0, y1 - y0, x1 - x0)
 
-    def _call_wino(self, d, x1, x2, pre, pooled, add, out, prof, ev0):
+    def _call_wino(self, d, x1, x2, pre, pooled, add, out, prof):
         """Winograd F(2x2,3x3) form of the layer (include/iiseg.h, iiseg_conv_wino_f32)."""
         lib = self.lib
         if self._U is None:
@@ -379,10 +382,10 @@ class Conv:
         r0, c0 = d.oy0 - ((d.oy0 - d.tile_y0) & 1), d.ox0 - ((d.ox0 - d.tile_x0) & 1)
         T = d.B * ((d.oy0 + d.OH - r0 + 1) // 2) * ((d.ox0 + d.OW - c0 + 1) // 2)
         gemm_flops = 16 * 2.0 * self.Cin * self.Cout * T      # multiplies actually issued
+        ev0 = _ev()
         for i, stage in enumerate(stages):
             check(lib.iiseg_conv_wino_f32(_stream(), *args, stage), 'iiseg_conv_wino_f32')
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record()
+            ev1 = _ev()
             prof.append((names[i], gemm_flops if i == 1 else 0.0, ev0, ev1))
             ev0 = ev1
         return out

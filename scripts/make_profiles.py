@@ -2,7 +2,8 @@
 
   python scripts/make_profiles.py stats <dir with *kernel_trace.csv> <out.csv>
   python scripts/make_profiles.py steady <dir with *kernel_trace.csv> <out.csv>   (first batch dropped)
-  python scripts/make_profiles.py pmc <fetch dir> <write dir> <out.md>
+  python scripts/make_profiles.py pmc <fetch dir> <write dir> <out.md> [<commit>]
+      (also rewrites profiles/hbm_traffic_latest.json, which bench.py reads for roofline.traffic)
 
 PMC units follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE count KiB; on gfx950
 FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled; WRITE_SIZE is exact."""
@@ -57,7 +58,7 @@ def stats(d, out, steady=False):
     print(open(out).read())
 
 
-def pmc(fd, wd, out):
+def pmc(fd, wd, out, commit=None):
     def load(d, counter):
         per = collections.OrderedDict()
         seen = collections.defaultdict(set)
@@ -85,6 +86,15 @@ def pmc(fd, wd, out):
         for k, n, fs, rd, ws, wg in rows:
             f.write('| %s | %d | %.4g | %.3f | %.4g | %.3f | %.3f |\n' % (k, n, fs, rd, ws, wg, rd + wg))
     print(open(out).read())
+    import json
+    import os
+    latest = os.path.join(os.path.dirname(os.path.abspath(out)), 'hbm_traffic_latest.json')
+    json.dump({'commit': commit, 'source': os.path.basename(out),
+               'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; '
+                         'reads doubled (gfx950 tallies 128-B requests at 64 B), KiB units',
+               'gb_per_launch': {re.sub(r'<.*', '', k): round(rd + wg, 4)
+                                 for k, n, fs, rd, ws, wg in rows}},
+              open(latest, 'w'), indent=1)
 
 
 if __name__ == '__main__':
@@ -93,4 +103,4 @@ if __name__ == '__main__':
     elif sys.argv[1] == 'steady':
         stats(sys.argv[2], sys.argv[3], steady=True)
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)

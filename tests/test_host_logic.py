@@ -143,3 +143,28 @@ def test_synthetic_data_contract():
     assert np.array_equal(S.make_images(2, 8, 8, seed=5), S.make_images(2, 8, 8, seed=5))
     k = S.bilinear_kernel(4)
     assert np.allclose(k, k.T) and np.allclose(k[0], [0.0625, 0.1875, 0.1875, 0.0625])
+
+
+def test_bench_self_launches_two_ranks_dry_run():
+    """`python bench.py --gpus 2` outside a torch.distributed environment must fan out to two
+    workers by itself (the parent never touches the GPU), reduce over both ranks and print ONE
+    JSON line from rank 0.  --dry-run swaps the HIP work for the protocol alone (gloo on CPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run',
+                        '--steps', '3', '--warmup', '1'], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['dry_run'] is True
+    assert out['batches_reduced'] == 6 and out['scaling'] == 'weak'
+    # a failing worker makes the launcher fail (WORLD_SIZE mismatch inside the workers)
+    bad = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                          '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port',
+                          '29677', os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--dry-run'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
