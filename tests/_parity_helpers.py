@@ -1,0 +1,70 @@
+"""Shared pieces of the full-size GPU parity tests (fp32 HIP path vs the float64 oracle where the
+DePool2D equality masks make strict free-running parity a float64-only property)."""
+import numpy as np
+import torch
+
+from oracle import dae as odae
+
+TOL = 1e-4   # BASELINE.json north_star: within 1e-4 on the refined softmax map
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def to64(p):
+    return {k: tuple(np.asarray(a, dtype=np.float64) for a in v) for k, v in p.items()}
+
+
+def eq_masks(pre, pool):
+    h2, w2 = pool.shape[2] * 2, pool.shape[3] * 2
+    return pre[:, :, :h2, :w2] == np.repeat(np.repeat(pool, 2, 2), 2, 3)
+
+
+def teacher_forced_mask_check(ii, H, Y, dp64, levels, dae_kw=None, max_flip_frac=1e-5):
+    """One DAE forward from the SAME (GPU) h, y on both sides (fp32 HIP vs float64 oracle):
+      1. every mask disagreement is a near-tie (the oracle window's top-2 gap is below twice the
+         measured fp32 error of that tensor) and they are < `max_flip_frac` of all mask bits;
+      2. with the oracle's masks injected r(y|h) is within 1e-4 everywhere (arithmetic parity).
+    Returns (mask bits, flips, teacher-forced max-abs error)."""
+    from iterative_inference_segm_amd import ops
+    dae_kw = dae_kw or {}
+    h64 = [host(h).astype(np.float64) for h in H]
+    y64 = host(Y).astype(np.float64)
+    r_ref, net = odae.dae_forward(dp64, h64, y64, return_net=True, **dae_kw)
+    ii.dae.trace = {}
+    ii.dae.scores(H, Y)
+    tr = {k: host(v) for k, v in ii.dae.trace.items() if isinstance(v, torch.Tensor)}
+    ii.dae.trace = None
+    total_bits, flips, override = 0, 0, {}
+    for p in range(1, levels + 1):
+        mg = eq_masks(tr['pre%d' % p], tr['pool%d' % p])
+        mo = eq_masks(net['pre%d' % p], net['pool%d' % p])
+        total_bits += mo.size
+        pre_err = np.abs(tr['pre%d' % p] - net['pre%d' % p]).max()
+        assert pre_err <= 1e-4 * (1 + np.abs(net['pre%d' % p]).max())
+        for (b, c, yy, xx) in np.argwhere(mg != mo):
+            win = np.sort(net['pre%d' % p][b, c, yy // 2 * 2:yy // 2 * 2 + 2,
+                                           xx // 2 * 2:xx // 2 * 2 + 2].ravel())
+            assert win[-1] - win[-2] <= 2 * pre_err, \
+                'mask disagreement that is not a near-tie at level %d: %s (fp32 err %g)' \
+                % (p, win, pre_err)
+            flips += 1
+        full = np.zeros(net['pre%d' % p].shape, dtype=np.float32)
+        full[:, :, :mo.shape[2], :mo.shape[3]] = mo
+        override[p] = (torch.from_numpy(full).cuda(),
+                       torch.ones(net['pool%d' % p].shape, dtype=torch.float32, device='cuda'))
+    assert flips <= max_flip_frac * total_bits
+    score = ii.dae.scores(H, Y, mask_override=override)
+    r_forced = host(ops.crop_softmax(score, Y.shape[2], Y.shape[3], off=(0, 0)))
+    err = float(np.abs(r_forced - r_ref).max())
+    assert err <= TOL, 'teacher-forced-mask r(y|h) max-abs err %.3e' % err
+    return total_bits, flips, err
+
+
+def agreement(a, b):
+    """(argmax agreement, mean |err|, max |err|, fraction of pixels within 1e-4) of two maps."""
+    e = np.abs(a - b)
+    return (float((a.argmax(1) == b.argmax(1)).mean()), float(e.mean()), float(e.max()),
+            float((e.max(axis=1) <= TOL).mean()))

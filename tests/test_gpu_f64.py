@@ -98,8 +98,10 @@ def test_tail_deconv_metrics_f64(ops):
 
 
 def test_full_size_end_to_end_strict(built_lib):
-    """BASELINE config-1/2 network, one 224x224 image, 3 refinement steps, float64 on the GPU vs
-    the float64 oracle: identical masks, refined map within 1e-4 (north_star) -- in fact ~1e-11."""
+    """BASELINE config-1/2 network, one 224x224 image, ALL 10 refinement steps of the bench
+    workload, float64 on the GPU vs the float64 oracle, free-running: identical mask decisions,
+    refined map within 1e-4 (north_star) -- in fact ~1e-11.  This is the path (and bench.py's
+    `strict_f64` leg the number) that carries the end-to-end 1e-4 claim."""
     from iterative_inference_segm_amd.api import IterativeInference
     from iterative_inference_segm_amd.dae import StandardDAE
     from iterative_inference_segm_amd.fcn8 import FCN8
@@ -113,12 +115,42 @@ def test_full_size_end_to_end_strict(built_lib):
     assert np.abs(host(Y) - y_ref).max() <= 1e-10
     dp64 = to64(dp)
     dae_fn = lambda hh, yy: odae.dae_forward(dp64, hh, yy)
-    yii_ref, it_ref = orefine.refine_batch(dae_fn, [h_ref], y_ref, 0.1, 3)
-    Yii, iters, _ = ii.refine(H, Y, 0.1, 3)
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, [h_ref], y_ref, 0.1, 10)
+    Yii, iters, _ = ii.refine(H, Y, 0.1, 10)
     err = np.abs(host(Yii) - yii_ref).max()
-    print('float64 end-to-end max-abs err after 3 steps: %.3e' % err)
-    assert list(host(iters)) == list(it_ref)
+    print('float64 end-to-end max-abs err after 10 steps: %.3e' % err)
+    assert list(host(iters)) == list(it_ref) == [10]
     assert err <= 1e-4
+
+
+def test_reference_function_is_discontinuous_at_float32_resolution(built_lib):
+    """Why no float32 implementation can promise 1e-4 free-running through DePool2D: the
+    reference's OWN function (float64 arithmetic throughout, here the oracle-pinned float64 HIP
+    path) is fed the same FCN-8 output once as computed and once rounded to float32 -- a relative
+    perturbation of at most 6e-8, what any float32 API boundary does to y.  Equality-mask
+    decisions at near-tied pooling windows (layers/mylayers.py:111-114) flip and after the 10
+    steps of the bench workload the two refined maps differ by far more than 1e-4 at some pixels,
+    while agreeing statistically.  (Deterministic for this seed; the numbers are printed.)"""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, dp = S.make_fcn8_params(), S.make_dae_params()
+    ii = IterativeInference(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=F64),
+                            StandardDAE(dp, 11, dtype=F64), 11, [11], dtype=F64)
+    X = S.make_images(4, 224, 224, seed=1234)
+    out = ii.pred_fcn_fn(X)
+    H, Y = out[:-1], out[-1]
+    Y_rounded = Y.to(torch.float32).to(F64)
+    assert float((Y - Y_rounded).abs().max()) <= 6e-8
+    a = host(ii.refine(H, Y, 0.1, 10, early_stop=False)[0])
+    b = host(ii.refine(H, Y_rounded, 0.1, 10, early_stop=False)[0])
+    e = np.abs(a - b)
+    agree = float((a.argmax(1) == b.argmax(1)).mean())
+    frac = float((e.max(axis=1) <= 1e-4).mean())
+    print('float64 path, y0 vs float32-rounded y0 after 10 steps: max %.3e mean %.3e, pixels within '
+          '1e-4 %.4f, argmax agreement %.5f' % (e.max(), e.mean(), frac, agree))
+    assert e.max() > 1e-4          # the discontinuity: 6e-8 in, > 1e-4 out
+    assert agree >= 0.99 and e.mean() <= 1e-3
 
 
 def test_config4_geometry_360x480_strict(built_lib):
