@@ -18,7 +18,8 @@ import torch
 
 from oracle import contextmod as octx, dae as odae, densenet as oden, fcn8 as ofcn8, refine as orefine
 from iterative_inference_segm_amd import synthetic as S
-from _parity_helpers import TOL, agreement, host, teacher_forced_mask_check, to64
+from _parity_helpers import (TOL, agreement, assert_within_reference_sensitivity, host,
+                             teacher_forced_mask_check, to64)
 
 pytestmark = pytest.mark.gpu
 F32, F64 = torch.float32, torch.float64
@@ -66,16 +67,14 @@ def test_config3_densenet103_dae_batch32(built_lib):
     # the same 4 images alone give DIFFERENT maps -- a reference batch must stay on one GPU
     y_sub = host(ii32.pred_fcn_fn(X[:4])[1])
     assert np.abs(y_sub - y32[:4]).max() > 1e-3
-    # the refinement loop at full size, both precisions; fp32 vs float64 only statistically
-    # (DePool2D near-tie flips), both stay probability-like maps
+    # the refinement loop at full size (batch 32, 10 steps) stays a probability-like map ...
     r32 = ii32.refine(o32[:-1], o32[-1], 0.1, 10, early_stop=False)
-    r64 = ii64.refine(o64[:-1], o64[-1], 0.1, 10, early_stop=False)
-    a32, a64 = host(r32[0]), host(r64[0])
+    a32 = host(r32[0])
     assert list(host(r32[1])) == [10] * B and a32.min() >= 0 and a32.max() <= 1
-    agree, mean_e, max_e, frac = agreement(a32, a64)
-    print('DenseNet103 + DAE, 10 steps: argmax agreement %.5f mean err %.2e max %.2e within-1e-4 %.4f'
-          % (agree, mean_e, max_e, frac))
-    assert agree >= 0.99 and mean_e <= 1e-3
+    # ... and free-running the fp32 path is as close to the float64 path as that path is to itself
+    # under a float32-level perturbation of y0 (the loop is chaotic with random weights)
+    sub32, sub64 = [t[:4].contiguous() for t in o32], [t[:4].contiguous() for t in o64]
+    assert_within_reference_sensitivity(ii32, ii64, sub32, sub64, (1, 2, 10), label='DenseNet103+DAE')
     # teacher-forced arithmetic parity of the DAE at this geometry (padding 0, 464-channel h)
     bits, flips, err = teacher_forced_mask_check(
         _ii(None, ii32.dae, F32), [o32[0][:2].contiguous()], o32[1][:2].contiguous(), to64(dp), 6,
@@ -130,14 +129,22 @@ def test_config4_360x480_fp32_refine_vs_oracle(built_lib):
     dp64 = to64(dp)
     bits, flips, err = teacher_forced_mask_check(ii, H, Y, dp64, 6)
     print('360x480: mask bits %d, near-tie flips %d, teacher-forced err %.2e' % (bits, flips, err))
+    # 1 free-running step against the oracle (iteration bookkeeping; the few near-tie flips move
+    # skip-sized values by one pixel, so the bound is statistical), then 3 steps against the
+    # float64 HIP path under the reference-sensitivity criterion
     yii_ref, it_ref = orefine.refine_batch(lambda hh, yy: odae.dae_forward(dp64, hh, yy), [h_ref],
-                                           y_ref, 0.1, 3)
-    Yii, iters, _ = ii.refine(H, Y, 0.1, 3)
+                                           y_ref, 0.1, 1)
+    Yii, iters, _ = ii.refine(H, Y, 0.1, 1)
     agree, mean_e, max_e, frac = agreement(host(Yii), yii_ref)
-    print('360x480 free-running 3 steps: argmax agreement %.5f mean err %.2e max %.2e within-1e-4 %.4f'
-          % (agree, mean_e, max_e, frac))
+    print('360x480 free-running 1 step vs oracle: argmax agreement %.5f mean err %.2e max %.2e '
+          'within-1e-4 %.4f' % (agree, mean_e, max_e, frac))
     assert list(host(iters)) == list(it_ref)
-    assert agree >= 0.99 and mean_e <= 1e-3
+    assert agree >= 0.999 and mean_e <= 1e-4
+    ii64 = _ii(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=F64),
+               StandardDAE(dp, 11, dtype=F64), F64)
+    o64 = ii64.pred_fcn_fn(X)
+    assert np.abs(host(o64[-1]) - y_ref).max() <= 1e-10
+    assert_within_reference_sensitivity(ii, ii64, out, o64, (1, 3), label='360x480')
 
 
 def test_config4_360x480_batch32_properties(built_lib):
@@ -238,14 +245,11 @@ def test_config5_multi_concat_standard_dae_50_steps(built_lib):
     o1 = jj.pred_fcn_fn(X[2:3])
     Y1, _, n1 = jj.refine(o1[:-1], o1[-1], 0.1, 50, early_stop=False)
     assert np.array_equal(host(Y1), a32[2:3]) and np.array_equal(host(n1), host(n32)[2:3])
-    # float64 HIP, same batch: statistical agreement after the 50-step chain
+    # float64 HIP: the fp32 path vs the reference's own sensitivity along the 50-step chain
     ii64 = make(F64)
-    o64 = ii64.pred_fcn_fn(X)
-    Y64, _, _ = ii64.refine(o64[:-1], o64[-1], 0.1, 50, early_stop=False)
-    agree, mean_e, max_e, frac = agreement(a32, host(Y64))
-    print('multi-concat DAE 50 steps: fp32 vs float64 argmax agreement %.5f mean err %.2e max %.2e '
-          'within-1e-4 %.4f' % (agree, mean_e, max_e, frac))
-    assert agree >= 0.98 and mean_e <= 2e-3
+    o64 = ii64.pred_fcn_fn(X[:2])
+    assert_within_reference_sensitivity(make(F32), ii64, [t[:2].contiguous() for t in o32], o64,
+                                        (1, 2, 10, 50), label='multi-concat DAE')
     # oracle on image 0: float64 strict (3 steps), fp32 teacher-forced
     dp64 = to64(dp)
     ref = ofcn8.fcn8_forward(to64(fp), X[:1].astype(np.float64), layer=concat_h + ['probs_dimshuffle'])
