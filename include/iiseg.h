@@ -162,6 +162,29 @@ int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
                         const float* pre, const float* pooled, const float* U, const float* bias,
                         const float* add, float* workspace, float* out, uint32_t stages);
 
+/* ---------------------------------------------------------------------------------------
+ * 16-bit MFMA path (BASELINE north_star "fp16 MFMA peak", configs[2] "bf16 with fp32 accumulate"):
+ * the same Winograd F(2x2,3x3) convolution with bf16 GEMM operands on v_mfma_f32_32x32x16_bf16
+ * and fp32 accumulation.  Tensors at the ABI stay fp32 NCHW; weights are rounded to bf16 when they
+ * are packed, activations when the input transform writes its workspace; the 16 GEMMs, the output
+ * transform and the epilogue (bias, add, ReLU, window, placement, channel slice -- same descriptor
+ * fields as iiseg_conv_wino_f32) run as one kernel.  Statistical parity only (8 significant bits
+ * per operand).  Any (C1 + C2) is accepted (channels are zero-padded to the 64-channel k-tile).
+ *   iiseg_conv_wino_bf16_supported        1 if `d` can run on this path, else 0
+ *   iiseg_conv_wino_bf16_weight_bytes     bytes of the packed bf16 weights U16
+ *   iiseg_conv_wino_bf16_workspace_bytes  bytes of caller-owned workspace (transformed input V16)
+ *   iiseg_conv_wino_bf16_pack             w (layout as in iiseg_conv_pack_f32) -> U16, once per layer
+ *   iiseg_conv_wino_bf16                  stages: IISEG_WINO_INPUT | IISEG_WINO_GEMM (= all)
+ * ------------------------------------------------------------------------------------- */
+int iiseg_conv_wino_bf16_supported(const iiseg_conv_desc* d);
+int64_t iiseg_conv_wino_bf16_weight_bytes(const iiseg_conv_desc* d);
+int64_t iiseg_conv_wino_bf16_workspace_bytes(const iiseg_conv_desc* d);
+int iiseg_conv_wino_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
+                              int64_t stride_o, int64_t stride_c, void* U16);
+int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                         const float* pre, const float* pooled, const void* U16, const float* bias,
+                         const float* add, void* workspace, float* out, uint32_t stages);
+
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,
  * d->Mpad from iiseg_conv_plan), the gather-free MFMA GEMM kernel of the Winograd path, partial

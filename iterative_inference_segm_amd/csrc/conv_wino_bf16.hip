@@ -1,0 +1,550 @@
+// Winograd F(2x2, 3x3) convolution on the bf16 matrix pipe of gfx950 (CDNA4):
+// v_mfma_f32_32x32x16_bf16, bf16 operands, fp32 accumulation -- the 16-bit MFMA path of the hot
+// path's wide 3x3 layers (BASELINE north_star: ">= 1000 images/s at >= 40 % of fp16 MFMA peak";
+// configs[2]: "bf16 with fp32 accumulate").  Activations stay fp32 NCHW in HBM and at the API;
+// only the two GEMM operands are rounded to bf16 (round to nearest even):
+//   U16[xi][c/8][co][8]  = bf16((G g G^T)[xi])      packed once per layer (computed in double)
+//   V16[xi][c/8][t][8]   = bf16((B^T d B)[xi])      input transform, d in fp32 (DePool2D mask and
+//                                                   channel concat applied while loading)
+// Both are "k8-chunk" images: the 8 channels a lane feeds to one MFMA (k = 8*(lane>>5) + j) are 16
+// contiguous bytes, so operand tiles stream global -> LDS with 16-byte LDS-DMA and a fragment is one
+// conflict-free ds_read_b128 (lanes 0..31 read 512 contiguous bytes).
+// One kernel multiplies AND output-transforms: a workgroup walks the 16 transform points of its
+// (channel, tile) block, folds each finished product tile into four fp32 output accumulators
+// (Y_ab += AT[a][i] AT[b][j] M_ij, coefficients 0 / +-1) and applies the epilogue (bias, skip-add
+// with crop, ReLU, window, placement, channel slice): the products M never reach HBM.
+//
+// Numerics: statistical parity only (8 significant bits per operand); the fp32 and float64 paths
+// are the ones with tolerance claims.  Results are deterministic, and equal
+// patches still give bit-equal outputs (same fixed-order sums, same tile anchoring as the fp32
+// Winograd path), so the pad-100 border ties of the equality masks stay ties.
+// Same Lasagne Conv2DLayer(3x3, stride 1) call sites as conv_wino.hip (models/fcn8.py:41-71,
+// models/fcn_down.py:102-104, models/fcn_up.py:83-86).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct WinoBfParams {
+    const float* x1;
+    const float* x2;
+    const float* pre;     // unpool mode: x1 = up, pre, pooled (DePool2D operands)
+    const float* pooled;
+    int h2, w2;
+    const uint4* U;       // U16 chunks
+    const float* bias;
+    const float* add;
+    uint4* V;             // V16 chunks
+    float* out;
+    int B, C1, C2, H, W;
+    int Cout, pad;
+    int oy0, ox0, OH, OW;    // output window in conv-output coordinates
+    int ty0, tx0, nty, ntx;  // first tile's output row / column (absolute), tile counts
+    int T, Tpad;             // B*nty*ntx, padded to the GEMM pixel tile
+    int Kc, Mpad;            // channels padded to the k-tile, output channels padded to the GEMM tile
+    int AH, AW, ay0, ax0;
+    int relu;
+    int out_ctot, out_c0, out_H, out_W, out_y0, out_x0;
+    int n_ttiles, n_mtiles;
+};
+
+constexpr int RSRC_W3 = 0x00027000;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
+}
+
+// two floats -> two bf16 (round to nearest even; a NaN stays a NaN: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// ---- 0. weights: U16[xi][c/8][co][c%8] = bf16((G g G^T)[xi]), g = w[co][c] (cross-correlation) ----
+__global__ void wino_weight_bf16_kernel(const float* __restrict__ w, int64_t so, int64_t sc,
+                                        __bf16* __restrict__ U, int Cin, int Cout, int Kc, int Mpad) {
+    const int64_t n = (int64_t)Kc * Mpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / Mpad), co = (int)(i % Mpad);
+        double g[3][3], t[4][3];
+        const bool real = c < Cin && co < Cout;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = real ? (double)w[co * so + c * sc + a * 3 + b] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {  // G g
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+        const int64_t chunk = ((int64_t)(c >> 3) * Mpad + co) * 8 + (c & 7);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {  // (G g) G^T
+            const double u[4] = {t[a][0], 0.5 * (t[a][0] + t[a][1] + t[a][2]),
+                                 0.5 * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) U[(int64_t)(a * 4 + b) * n + chunk] = (__bf16)(float)u[b];
+        }
+    }
+}
+
+// ---- 1. input transform -> V16 -----------------------------------------------------------------
+// One thread = one tile x 8 channels (one k8 chunk per transform point); lanes run along tiles, so
+// every store instruction writes 64 consecutive 16-byte chunks.  Channels are handled in pairs (two
+// fp32 results pack into one dword of the chunk); all loads of a half-group (4 channels) are issued
+// before any store.  UNPOOL / PY / PX as in conv_wino.hip: the DePool2D equality mask
+// (layers/mylayers.py:88-115) is applied to the fp32 values while the patch is loaded.
+template <bool UNPOOL, int PY, int PX>
+__global__ __launch_bounds__(256) void wino_input_bf16_kernel(const WinoBfParams p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.T) return;
+    const int ntt = p.nty * p.ntx;
+    const int b = t / ntt;
+    const int r = t - b * ntt;
+    const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
+    const int iy0 = p.ty0 + 2 * tyl - p.pad, ix0 = p.tx0 + 2 * txl - p.pad;
+    int rowoff[4];
+    bool rok[4], cok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rok[i] = (unsigned)(iy0 + i) < (unsigned)p.H;
+        cok[i] = (unsigned)(ix0 + i) < (unsigned)p.W;
+        rowoff[i] = (iy0 + i) * p.W + ix0;
+    }
+    constexpr int NQY = UNPOOL ? (PY ? 3 : 2) : 1, NQX = UNPOOL ? (PX ? 3 : 2) : 1;
+    const int qy0 = (iy0 - PY) >> 1, qx0 = (ix0 - PX) >> 1;   // floor(iy0 / 2) for either parity
+    bool qrok[NQY], qcok[NQX];
+    int qoff[NQY];
+    if constexpr (UNPOOL) {
+#pragma unroll
+        for (int i = 0; i < NQY; ++i) {
+            qrok[i] = (unsigned)(qy0 + i) < (unsigned)p.h2;
+            qoff[i] = (qy0 + i) * p.w2 + qx0;
+        }
+#pragma unroll
+        for (int j = 0; j < NQX; ++j) qcok[j] = (unsigned)(qx0 + j) < (unsigned)p.w2;
+    }
+    const size_t HW = (size_t)p.H * p.W, hw2 = (size_t)p.h2 * p.w2;
+    const int Ctot = p.C1 + p.C2;
+    const int kc = blockIdx.y;                 // channel group: channels 8*kc .. 8*kc + 7
+    const size_t xis = (size_t)(p.Kc >> 3) * p.Tpad;       // chunks per transform point
+    uint32_t res[16][4];                       // [xi][channel pair] = the 16 chunks of this thread
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        constexpr int NC_ = 4;
+        float pv[NC_][4][4];
+        float pq[UNPOOL ? NC_ : 1][NQY][NQX], uq[UNPOOL ? NC_ : 1][NQY][NQX];
+        bool creal[NC_];
+#pragma unroll
+        for (int cc = 0; cc < NC_; ++cc) {
+            const int c = kc * 8 + half * NC_ + cc;
+            creal[cc] = c < Ctot;              // channels beyond the layer's: zero (padded k-tile)
+            const int cs = creal[cc] ? c : 0;
+            if constexpr (UNPOOL) {
+                const float* prep = p.pre + ((size_t)b * p.C1 + cs) * HW;
+                const float* poolp = p.pooled + ((size_t)b * p.C1 + cs) * hw2;
+                const float* upp = p.x1 + ((size_t)b * p.C1 + cs) * hw2;
+#pragma unroll
+                for (int i = 0; i < NQY; ++i)
+#pragma unroll
+                    for (int j = 0; j < NQX; ++j) {
+                        const int o = (qrok[i] && qcok[j]) ? qoff[i] + j : 0;
+                        pq[cc][i][j] = poolp[o];
+                        uq[cc][i][j] = upp[o];
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        pv[cc][i][j] = prep[(rok[i] && cok[j]) ? rowoff[i] + j : 0];
+            } else {
+                const float* src = cs < p.C1 ? p.x1 + ((size_t)b * p.C1 + cs) * HW
+                                             : p.x2 + ((size_t)b * p.C2 + (cs - p.C1)) * HW;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        pv[cc][i][j] = src[(rok[i] && cok[j]) ? rowoff[i] + j : 0];
+            }
+        }
+#pragma unroll
+        for (int pr = 0; pr < NC_ / 2; ++pr) {
+            float vv[2][16];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cc = pr * 2 + u;
+                float d[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (UNPOOL) {
+                            const int qi = (PY + i) >> 1, qj = (PX + j) >> 1;
+                            const bool ok = creal[cc] && rok[i] && cok[j] && qrok[qi] && qcok[qj];
+                            d[i][j] = (ok && pv[cc][i][j] == pq[cc][qi][qj]) ? uq[cc][qi][qj] : 0.f;
+                        } else {
+                            d[i][j] = (creal[cc] && rok[i] && cok[j]) ? pv[cc][i][j] : 0.f;
+                        }
+                    }
+                float e[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {  // B^T d
+                    e[0][j] = d[0][j] - d[2][j];
+                    e[1][j] = d[1][j] + d[2][j];
+                    e[2][j] = d[2][j] - d[1][j];
+                    e[3][j] = d[1][j] - d[3][j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // (B^T d) B
+                    vv[u][i * 4 + 0] = e[i][0] - e[i][2];
+                    vv[u][i * 4 + 1] = e[i][1] + e[i][2];
+                    vv[u][i * 4 + 2] = e[i][2] - e[i][1];
+                    vv[u][i * 4 + 3] = e[i][1] - e[i][3];
+                }
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) res[xi][half * 2 + pr] = pack_bf16(vv[0][xi], vv[1][xi]);
+        }
+    }
+    uint4* v = p.V + (size_t)kc * p.Tpad + t;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+        v[(size_t)xi * xis] = make_uint4(res[xi][0], res[xi][1], res[xi][2], res[xi][3]);
+}
+
+// ---- 2+3. the 16 GEMMs + output transform + epilogue in one kernel --------------------------------
+// As / Bs hold k-tiles of BK channels as BK/8 rows of 16-byte chunks.  A wave owns TM x TN blocks of
+// 32 channels x 32 tiles; k-step s of a k-tile reads chunk rows 2s + (lane >> 5).
+template <int BM, int BN, int WM, int WN, int BK, int MINW>
+__global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(const WinoBfParams p) {
+    constexpr int KR = BK / 8, NS = BK / 16;   // chunk rows per k-tile, MFMA k-steps per k-tile
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int AV = KR * BM, BV = KR * BN;  // chunks per operand tile
+    constexpr int APT = AV / NT, BPT = BV / NT;
+    static_assert(AV % NT == 0 && BV % NT == 0 && BK % 16 == 0, "tile config");
+
+    __shared__ __attribute__((aligned(16))) uint4 As[2][KR][BM];
+    __shared__ __attribute__((aligned(16))) uint4 Bs[2][KR][BN];
+
+    int tt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ttiles, p.n_mtiles, tt, mt);
+    const int m0 = mt * BM, t0 = tt * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nkt = p.Kc / BK;
+    const int kcr = p.Kc >> 3;                             // chunk rows per transform point
+    const size_t ustride = (size_t)kcr * p.Mpad, vstride = (size_t)kcr * p.Tpad;
+    const int ubytes = kcr * p.Mpad * 16, vbytes = kcr * p.Tpad * 16;
+
+    // stage k-tile KT of transform point XI into LDS buffer BUF (global -> LDS, 16 B per lane)
+#define WBF_STAGE(XI, KT, BUF)                                                                     \
+    {                                                                                              \
+        const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)(XI) * ustride, ubytes);           \
+        const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)(XI) * vstride, vbytes);           \
+        static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            const int f = j * NT + tid;                                                            \
+            const int row = f / BM, col = f % BM;                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                ar, (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + j * NT + wave * 64), \
+                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
+        });                                                                                        \
+        static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            const int f = j * NT + tid;                                                            \
+            const int row = f / BN, col = f % BN;                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                br, (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + j * NT + wave * 64), \
+                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Tpad + t0 + col)), 0, 0, 0);      \
+        });                                                                                        \
+    }
+
+    f32x16 acc[TM][TN], Y[4][TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                Y[0][i][j][r] = Y[1][i][j][r] = Y[2][i][j][r] = Y[3][i][j][r] = 0.f;
+            }
+
+    WBF_STAGE(0, 0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int xi = 0, kt = 0;              // the k-tile being multiplied
+    const int total = 16 * nkt;
+    for (int s = 0; s < total; ++s) {
+        const int buf = s & 1;
+        int nxi = xi, nkt1 = kt + 1;  // the k-tile being staged
+        if (nkt1 == nkt) { nkt1 = 0; ++nxi; }
+        const bool more = s + 1 < total;
+        uint4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lh][wm * WTM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][lh][wn * WTN + j * 32 + l31];
+        static_for<0, NS>([&](auto ST) __attribute__((always_inline)) {
+            constexpr int st = decltype(ST)::value;
+            if constexpr (st + 1 < NS) {
+                const int kr = (st + 1) * 2 + lh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(st + 1) & 1][i] = As[buf][kr][wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(st + 1) & 1][j] = Bs[buf][kr][wn * WTN + j * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[st & 1][i]), __builtin_bit_cast(bf16x8, b[st & 1][j]),
+                        acc[i][j], 0, 0, 0);
+            if constexpr (st == 0) {
+                if (more) WBF_STAGE(nxi, nkt1, buf ^ 1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (nkt1 == 0) {
+            // M_xi complete: Y_ab += AT[a][xi/4] * AT[b][xi%4] * M_xi,  AT = [1 1 1 0; 0 1 -1 -1]
+            const int wi = xi >> 2, wj = xi & 3;
+            const float r0 = wi < 3 ? 1.f : 0.f, r1 = wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f);
+            const float c0 = wj < 3 ? 1.f : 0.f, c1 = wj == 0 ? 0.f : (wj == 1 ? 1.f : -1.f);
+            const float k00 = r0 * c0, k01 = r0 * c1, k10 = r1 * c0, k11 = r1 * c1;
+#define WBF_FOLD(Q, KQ)                                                                             \
+            if ((KQ) != 0.f) {                                                                      \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r)                                      \
+                    Y[Q][i][j][r] = fmaf((KQ), acc[i][j][r], Y[Q][i][j][r]);                        \
+            }
+            WBF_FOLD(0, k00)
+            WBF_FOLD(1, k01)
+            WBF_FOLD(2, k10)
+            WBF_FOLD(3, k11)
+#undef WBF_FOLD
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        xi = nxi;
+        kt = nkt1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef WBF_STAGE
+
+    // epilogue: rows of the C/D layout are channels, columns (lane & 31) are tiles
+    const int ntt = p.nty * p.ntx;
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int t = t0 + wn * WTN + j * 32 + l31;
+        if (t >= p.T) continue;
+        const int b = t / ntt;
+        const int rr = t - b * ntt;
+        const int tyl = rr / p.ntx, txl = rr - tyl * p.ntx;
+        const int wy = p.ty0 + 2 * tyl - p.oy0, wx = p.tx0 + 2 * txl - p.ox0;
+        const bool ok[4] = {(unsigned)wy < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
+                            (unsigned)wy < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW,
+                            (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
+                            (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW};
+        float* ob = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                    (ptrdiff_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        const float* ab = p.add ? p.add + (size_t)b * p.Cout * APL +
+                                      (ptrdiff_t)(p.ay0 + wy) * p.AW + p.ax0 + wx
+                                : nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // skip-add values first, all loads in flight together (indices clamped instead of
+            // branches), then the stores: `out` and `add` may alias as far as the compiler knows
+            float av[16][4];
+            if (ab) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = min(m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.Cout - 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        av[r][q] = ok[q] ? ab[(size_t)co * APL + (q >> 1) * p.AW + (q & 1)] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!ok[q]) continue;
+                    float v = Y[q][i][j][r] + bias;
+                    if (ab) v += av[r][q];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    ob[(size_t)co * OPL + (size_t)(q >> 1) * p.out_W + (q & 1)] = v;
+                }
+            }
+        }
+    }
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+constexpr int WBF_BK = 64;   // k-tile of the GEMM kernel: channels are padded to it
+
+struct WinoBfGeom {
+    int Kc, Mpad, bm, ty0, tx0, nty, ntx, T, Tpad;
+};
+
+int wino_bf16_geom(const iiseg_conv_desc* d, WinoBfGeom& g) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2))
+        return IISEG_ERR_UNSUPPORTED;
+    if ((d->flags & IISEG_CONV_UNPOOL) && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
+    if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
+        d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
+        return IISEG_ERR_SHAPE;
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
+    g.Kc = round_up(d->C1 + d->C2, WBF_BK);
+    g.bm = d->Cout > 64 ? 128 : 64;
+    g.Mpad = round_up(d->Cout, g.bm);
+    if ((d->tile_y0 | d->tile_x0) & ~1) return IISEG_ERR_SHAPE;
+    g.ty0 = d->oy0 - ((d->oy0 - d->tile_y0) & 1);
+    g.tx0 = d->ox0 - ((d->ox0 - d->tile_x0) & 1);
+    g.nty = (d->oy0 + d->OH - g.ty0 + 1) >> 1;
+    g.ntx = (d->ox0 + d->OW - g.tx0 + 1) >> 1;
+    const int64_t T = (int64_t)d->B * g.nty * g.ntx;
+    const int64_t Tpad = (T + 127) / 128 * 128;
+    // buffer descriptors address one xi-slice of U16 / V16 with 32-bit byte offsets
+    if (Tpad * g.Kc * 2 >= (int64_t)1 << 31 || (int64_t)g.Kc * g.Mpad * 2 >= (int64_t)1 << 31)
+        return IISEG_ERR_UNSUPPORTED;
+    g.T = (int)T;
+    g.Tpad = (int)Tpad;
+    return IISEG_OK;
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_wino_bf16_supported(const iiseg_conv_desc* d) {
+    WinoBfGeom g;
+    return wino_bf16_geom(d, g) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int64_t iiseg_conv_wino_bf16_weight_bytes(const iiseg_conv_desc* d) {
+    WinoBfGeom g;
+    if (wino_bf16_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)16 * g.Kc * g.Mpad * 2;
+}
+
+extern "C" int64_t iiseg_conv_wino_bf16_workspace_bytes(const iiseg_conv_desc* d) {
+    WinoBfGeom g;
+    if (wino_bf16_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)16 * g.Kc * g.Tpad * 2;
+}
+
+extern "C" int iiseg_conv_wino_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
+                                         int64_t stride_o, int64_t stride_c, void* U16) {
+    WinoBfGeom g;
+    const int st = wino_bf16_geom(d, g);
+    if (st) return st;
+    if (!w || !U16) return IISEG_ERR_NULL;
+    if ((uintptr_t)U16 & 15) return IISEG_ERR_ALIGN;
+    const int64_t n = (int64_t)g.Kc * g.Mpad;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino_weight_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                       stride_o, stride_c, (__bf16*)U16, d->C1 + d->C2, d->Cout, g.Kc, g.Mpad);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, const float* x1,
+                                    const float* x2, const float* pre, const float* pooled,
+                                    const void* U16, const float* bias, const float* add,
+                                    void* workspace, float* out, uint32_t stages) {
+    WinoBfGeom g;
+    const int st = wino_bf16_geom(d, g);
+    if (st) return st;
+    if (!x1 || !U16 || !workspace || !out) return IISEG_ERR_NULL;
+    if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if (((uintptr_t)U16 & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
+    WinoBfParams p;
+    p.x1 = x1; p.x2 = x2; p.pre = pre; p.pooled = pooled;
+    p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.U = (const uint4*)U16;
+    p.bias = bias; p.add = add;
+    p.V = (uint4*)workspace;
+    p.out = out;
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.Cout = d->Cout; p.pad = d->pad;
+    p.oy0 = d->oy0; p.ox0 = d->ox0; p.OH = d->OH; p.OW = d->OW;
+    p.ty0 = g.ty0; p.tx0 = g.tx0; p.nty = g.nty; p.ntx = g.ntx;
+    p.T = g.T; p.Tpad = g.Tpad; p.Kc = g.Kc; p.Mpad = g.Mpad;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    if (add && (d->ay0 < 0 || d->ax0 < 0 || d->ay0 + d->OH > d->AH || d->ax0 + d->OW > d->AW))
+        return IISEG_ERR_SHAPE;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot > 0 ? d->out_c0 : 0;
+    if (p.out_c0 < 0 || p.out_c0 + d->Cout > p.out_ctot) return IISEG_ERR_SHAPE;
+    p.out_H = d->out_H > 0 ? d->out_H : d->OH;
+    p.out_W = d->out_H > 0 ? d->out_W : d->OW;
+    p.out_y0 = d->out_H > 0 ? d->out_y0 : 0;
+    p.out_x0 = d->out_H > 0 ? d->out_x0 : 0;
+    if (p.out_y0 < 0 || p.out_x0 < 0 || p.out_y0 + d->OH > p.out_H || p.out_x0 + d->OW > p.out_W)
+        return IISEG_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (stages & IISEG_WINO_INPUT) {
+        const dim3 grid((p.T + 255) / 256, p.Kc / 8), block(256);
+        if (!unpool) {
+            hipLaunchKernelGGL((wino_input_bf16_kernel<false, 0, 0>), grid, block, 0, s, p);
+        } else {
+            const int py = (p.ty0 - p.pad) & 1, px = (p.tx0 - p.pad) & 1;  // patch-origin parity
+            if (py && px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 1>), grid, block, 0, s, p);
+            else if (py) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 0>), grid, block, 0, s, p);
+            else if (px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 1>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 0>), grid, block, 0, s, p);
+        }
+    }
+    if (stages & IISEG_WINO_GEMM) {
+        if (g.bm == 64) {
+            p.n_ttiles = g.Tpad / 128;
+            p.n_mtiles = g.Mpad / 64;
+            hipLaunchKernelGGL((wino_fused_bf16_kernel<64, 128, 1, 4, WBF_BK, 2>),
+                               dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+            return iiseg_check_launch();
+        }
+        p.n_mtiles = g.Mpad / 128;
+        // few tiles: 4-wave workgroups of 128 x 64 fill the CUs better than 8-wave 128 x 128 ones
+        const int w128 = (g.Tpad / 128) * p.n_mtiles;
+        if (w128 < 2 * 256) {
+            p.n_ttiles = g.Tpad / 64;
+            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, WBF_BK, 2>),
+                               dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+        } else {
+            p.n_ttiles = g.Tpad / 128;
+            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, WBF_BK, 2>),
+                               dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
+        }
+    }
+    return iiseg_check_launch();
+}

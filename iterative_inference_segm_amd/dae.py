@@ -50,8 +50,11 @@ class StandardDAE:
     def __init__(self, params, n_classes, concat_h=('pool4',), padding=100, n_filters=64,
                  conv_before_pool=1, additional_pool=2, skip=True, unpool_type='trackind', bn=0,
                  device='cuda', dtype=torch.float32, pad_multi_concat=False, noise=0.0,
-                 dropout=0.0, emulate_noise=False, seed=0):
+                 dropout=0.0, emulate_noise=False, seed=0, mma=None):
+        """mma: matrix-pipe operand precision of the float32 path's convolutions ('f32' default,
+        'bf16' = 16-bit MFMA operands with fp32 accumulation; ops.Conv)."""
         concat_h = list(concat_h)
+        self.mma = mma
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
                    for el in concat_h)                                   # fcn_down.py:39-41
         if concat_h[-1] == 'input' and additional_pool == 0:
@@ -92,7 +95,7 @@ class StandardDAE:
                 name = 'conv%d_%d' % (p + 1, i)
                 self.enc[name] = ops.Conv(params[name][0], params[name][1],
                                           pad=padding if first_pad else 1, relu=True,
-                                          device=device, dtype=dtype)                 # :102-104
+                                          device=device, dtype=dtype, mma=mma)        # :102-104
                 if bn:   # BatchNormLayer on the rectified conv, stored averages (:112-114)
                     self.enc_bn[name] = tuple(
                         torch.as_tensor(np.asarray(a)).to(dtype).contiguous().to(device)
@@ -113,9 +116,9 @@ class StandardDAE:
                 if ch > 0 and at in concat_h:
                     Wt = torch.as_tensor(W)
                     conv_h = ops.Conv(Wt[:, :ch].contiguous(), b, pad=self.enc[name].pad,
-                                      relu=False, device=device, dtype=dtype)
+                                      relu=False, device=device, dtype=dtype, mma=mma)
                     conv_y = ops.Conv(Wt[:, ch:].contiguous(), None, pad=self.enc[name].pad,
-                                      relu=True, device=device, dtype=dtype)
+                                      relu=True, device=device, dtype=dtype, mma=mma)
                     self.hsplit[name] = (conv_h, conv_y)
                 prev = params['conv%d_%d' % (p + 1, conv_before_pool)][0].shape[0]
         for p in range(self.total, 0, -1):
@@ -123,7 +126,7 @@ class StandardDAE:
                 name = 'up%d' % p
                 self.dec[name] = ops.Conv(params[name][0], params[name][1], pad=0, relu=False,
                                           layout='iohw', transposed=True, device=device,
-                                          dtype=dtype)
+                                          dtype=dtype, mma=mma)
                 continue
             name = 'up_conv%d' % p
             W, b = params[name]
@@ -135,7 +138,7 @@ class StandardDAE:
                 W = np.asarray(W, np.float64) * sc[:, None, None, None]
                 b = (np.asarray(b, np.float64) - mean) * sc + beta
             self.dec[name] = ops.Conv(W, b, pad=1, relu=False, device=device,
-                                      dtype=dtype)                                    # fcn_up.py:83-86
+                                      dtype=dtype, mma=mma)                           # fcn_up.py:83-86
         self.conv_log = None
         # DePool2D fused into the conv's input load (halo kernel: 3 loads per PATCH element;
         # Winograd: applied by the input transform) or materialised first.  None (auto): fused in

@@ -78,7 +78,7 @@ class _Stack:
 
 class FCDenseNet:
     def __init__(self, params, n_classes=11, layer=('pool4',), n_layers_per_block=LAYERS_PER_BLOCK,
-                 n_pool=N_POOL, growth=GROWTH, device='cuda', dtype=torch.float32):
+                 n_pool=N_POOL, growth=GROWTH, device='cuda', dtype=torch.float32, mma=None):
         self.layer = list(layer)
         assert all(h in ['input', 'pool1', 'pool2', 'pool3', 'pool4', 'pool5'] for h in self.layer)
         self.nlpb, self.n_pool, self.growth = list(n_layers_per_block), n_pool, growth
@@ -91,11 +91,11 @@ class FCDenseNet:
                 e['beta'], e['gamma'] = dev(p['beta']), dev(p['gamma'])
             if p['kind'] == 'tu':
                 e['conv'] = ops.Conv(p['W'], p['b'], pad=0, relu=False, layout='iohw',
-                                     transposed=True, device=device, dtype=dtype)
+                                     transposed=True, device=device, dtype=dtype, mma=mma)
             else:
                 k = p['W'].shape[2]
                 e['conv'] = ops.Conv(p['W'], p['b'], pad=k // 2, relu=False, device=device,
-                                     dtype=dtype)
+                                     dtype=dtype, mma=mma)
             self.layers.append(e)
 
     def __call__(self, x):

@@ -51,7 +51,9 @@ def _pool_region(dep, ph, pw):
 
 class FCN8:
     def __init__(self, params, n_classes, layer=('probs_dimshuffle',), pad=100, temperature=1.0,
-                 device='cuda', dtype=torch.float32):
+                 device='cuda', dtype=torch.float32, mma=None):
+        """mma: matrix-pipe operand precision of the float32 path's convolutions ('f32' default,
+        'bf16' = 16-bit MFMA operands with fp32 accumulation; ops.Conv)."""
         self.layer = list(layer)
         self.n_classes = n_classes
         self.pad = pad
@@ -59,7 +61,7 @@ class FCN8:
         self.dtype = dtype
         p = params
         c = lambda name, pad_, relu=True: ops.Conv(p[name][0], p[name][1], pad=pad_, relu=relu,
-                                                   device=device, dtype=dtype)
+                                                   device=device, dtype=dtype, mma=mma)
         self.convs = {}
         for bi, names in enumerate(_BLOCKS):
             for ni, name in enumerate(names):
@@ -223,10 +225,11 @@ class FCN8DAE:
     `concat_h`.  Callable like pred_dae_fn(h..., y); `scores` gives the pre-softmax map."""
 
     def __init__(self, params, n_classes, concat_h=('input',), pad=100, device='cuda',
-                 dtype=torch.float32):
+                 dtype=torch.float32, mma=None):
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input'] for el in concat_h)  # :33-34
         self.concat_h = list(concat_h)
-        self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype)
+        self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype,
+                        mma=mma)
         self.net.fold_border = False       # the border depends on h here: sessions only
         self.licm = os.environ.get('IISEG_ENCODER_LICM', '1') != '0'
 

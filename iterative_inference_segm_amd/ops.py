@@ -36,6 +36,13 @@ POOL_FUSE = os.environ.get('IISEG_POOL_FUSE', '1') != '0'
 BNRELU_FUSE = os.environ.get('IISEG_BNRELU_FUSE', '0') != '0'
 # 'valid' KxK layers without a static-tap variant (7x7 fc6) as im2col + split-K GEMM
 CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
+# Matrix-pipe operand precision of the float32 path's wide 3x3 layers: 'f32' (exact fp32 MFMA, the
+# default: the path with tolerance claims) or 'bf16' (bf16 operands, fp32 accumulation -- statistical
+# parity only; BASELINE north_star's 16-bit MFMA target).  Per-Conv `mma=` overrides the default.
+DEFAULT_MMA = os.environ.get('IISEG_MMA', 'f32')
+# bf16 mode: 3x3 layers at least this wide run on the bf16 Winograd kernels (conv_wino_bf16.hip)
+BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '128'))
+BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '128'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
 
 
@@ -86,10 +93,14 @@ class Conv:
     'iohw' (DilatedConv2DLayer W[in,out,kh,kw], P11)."""
 
     def __init__(self, W, b, pad, relu, dil=1, layout='oihw', device='cuda', dtype=torch.float32,
-                 transposed=False):
+                 transposed=False, mma=None):
         """transposed=True: 3x3 stride-2 transposed convolution, crop='valid' (Deconv2DLayer
-        W[in,out,3,3] -> layout 'iohw'); output (2H+1, 2W+1)."""
+        W[in,out,3,3] -> layout 'iohw'); output (2H+1, 2W+1).  mma: 'f32' | 'bf16' operand
+        precision on the matrix pipe (float32 tensors only; None: ops.DEFAULT_MMA)."""
         self.lib = _lib.load()
+        self.mma = (mma or DEFAULT_MMA) if dtype == torch.float32 else 'f32'
+        if self.mma not in ('f32', 'bf16'):
+            raise ValueError("mma must be 'f32' or 'bf16'")
         self.transposed = bool(transposed)
         self.dtype = dtype
         self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
@@ -127,7 +138,11 @@ class Conv:
         self.wino = (dtype == torch.float32 and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
                      not self.transposed and self.Cin % 16 == 0 and
                      0 < WINO_MIN_CIN <= self.Cin and self.Cout >= WINO_MIN_COUT)
+        self.wino_bf16 = (self.mma == 'bf16' and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
+                          not self.transposed and self.Cin >= BF16_WINO_MIN_CIN and
+                          self.Cout >= BF16_WINO_MIN_COUT)
         self._U = None
+        self._U16 = None
         self._plans = {}
         self._packs = {}
 
@@ -259,6 +274,9 @@ class Conv:
         # profiling: every launch is bracketed by events recorded IMMEDIATELY around the ctypes
         # call (after all planning / workspace work), so a bracket holds the kernel and nothing else
         prof = CONV_PROFILE
+        if pool_out is None and self.wino_bf16 and \
+                self.lib.iiseg_conv_wino_bf16_supported(C.byref(d)):
+            return self._call_wino_bf16(d, x1, x2, pre, pooled, add, out, prof)
         if pool_out is None and self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
         if pool_out is not None:
@@ -357,6 +375,36 @@ class Conv:
         if region[1] + region[3] == fw:
             x1 = fw
         return (y0, x0, y1 - y0, x1 - x0)
+
+    def _call_wino_bf16(self, d, x1, x2, pre, pooled, add, out, prof):
+        """bf16-operand Winograd form (include/iiseg.h, iiseg_conv_wino_bf16): input transform ->
+        V16, then one kernel for the 16 GEMMs + output transform + epilogue."""
+        lib = self.lib
+        if self._U16 is None:
+            self._U16 = torch.empty(lib.iiseg_conv_wino_bf16_weight_bytes(C.byref(d)) // 2,
+                                    dtype=torch.bfloat16, device=self.W.device)
+            check(lib.iiseg_conv_wino_bf16_pack(_stream(), C.byref(d), _ptr(self.W), self.so,
+                                                self.sc, _ptr(self._U16, torch.bfloat16)),
+                  'iiseg_conv_wino_bf16_pack')
+        ws = _wino_workspace((lib.iiseg_conv_wino_bf16_workspace_bytes(C.byref(d)) + 3) // 4,
+                             x1.device)
+        args = (C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre), _ptr(pooled),
+                _ptr(self._U16, torch.bfloat16), _ptr(self.b), _ptr(add), _ptr(ws), _ptr(out))
+        if prof is None:
+            check(lib.iiseg_conv_wino_bf16(_stream(), *args, 3), 'iiseg_conv_wino_bf16')
+            return out
+        r0, c0 = d.oy0 - ((d.oy0 - d.tile_y0) & 1), d.ox0 - ((d.ox0 - d.tile_x0) & 1)
+        T = d.B * ((d.oy0 + d.OH - r0 + 1) // 2) * ((d.ox0 + d.OW - c0 + 1) // 2)
+        kc = (self.Cin + 63) // 64 * 64
+        gemm_flops = 16 * 2.0 * kc * self.Cout * T            # multiplies actually issued
+        ev0 = _ev()
+        for name, stage, fl in (('wino_input_bf16_kernel', 1, 0.0),
+                                ('wino_fused_bf16_kernel', 2, gemm_flops)):
+            check(lib.iiseg_conv_wino_bf16(_stream(), *args, stage), 'iiseg_conv_wino_bf16')
+            ev1 = _ev()
+            prof.append((name, fl, ev0, ev1))
+            ev0 = ev1
+        return out
 
     def _call_wino(self, d, x1, x2, pre, pooled, add, out, prof):
         """Winograd F(2x2,3x3) form of the layer (include/iiseg.h, iiseg_conv_wino_f32)."""

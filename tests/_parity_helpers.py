@@ -80,20 +80,23 @@ def assert_within_reference_sensitivity(ii32, ii64, o32, o64, steps, step=0.1, r
     profiles/r02_sensitivity.md).  A fixed tolerance on the free-running map is therefore not a
     property any float32 implementation can have.  What CAN be asserted: the fp32 path stays as
     close to the float64 path (= the reference's numerics) as the float64 path stays to ITSELF when
-    its input y0 is perturbed by `rel` relative (1e-5: the accumulated rounding of a float32 conv
-    stack with K up to 18432), i.e. the fp32 arithmetic is equivalent to a float32-level
+    its inputs (y0 and the h maps, both outputs of the segmentation net's float32 conv stack in the
+    fp32 path) are perturbed by `rel` (1e-5: the accumulated rounding of a float32 conv stack with
+    K up to 18432; absolute on the probability map y0 in [0, 1], relative on h), i.e. the fp32 arithmetic is equivalent to a float32-level
     perturbation of the reference's own input.  Compared: mean |err| (x `factor`), per step count."""
     H32, Y32, H64, Y64 = o32[:-1], o32[-1], o64[:-1], o64[-1]
     rng = np.random.default_rng(0)
     u = torch.from_numpy(rng.uniform(-1, 1, size=tuple(Y64.shape))).to(Y64.device)
+    H64p = [h * (1 + rel * torch.from_numpy(rng.uniform(-1, 1, size=tuple(h.shape))).to(h.device))
+            for h in H64]
     out = []
     for n in steps:
         base = ii64.refine(H64, Y64, step, n, early_stop=False)[0]
-        pert = ii64.refine(H64, (Y64 * (1 + rel * u)).clamp(0, 1), step, n, early_stop=False)[0]
+        pert = ii64.refine(H64p, (Y64 + rel * u).clamp(0, 1), step, n, early_stop=False)[0]
         got = ii32.refine(H32, Y32, step, n, early_stop=False)[0]
         a, b, c = host(base), host(pert), host(got).astype(np.float64)
         s_ref, s_got = agreement(a, b), agreement(a, c)
-        print('%s %d steps: float64 vs float64(y0 (1 + %g u)) argmax %.5f mean %.2e max %.2e | '
+        print('%s %d steps: float64 vs float64(inputs +- %g) argmax %.5f mean %.2e max %.2e | '
               'float64 vs fp32 argmax %.5f mean %.2e max %.2e'
               % (label, n, rel, s_ref[0], s_ref[1], s_ref[2], s_got[0], s_got[1], s_got[2]))
         assert s_got[1] <= factor * s_ref[1] + 1e-6, (label, n, s_got, s_ref)
