@@ -54,18 +54,20 @@ N_CLASSES = 11
 GFLOP_PER_IMAGE = 872.3          # 119.24 (FCN-8) + 10 x 75.31 (DAE), nominal
 PEAK_TFLOPS_F32_MFMA = 157.3     # MI355X_MICROARCH.md, fp32 matrix peak
 PEAK_TFLOPS_F64_MFMA = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix rate
+PEAK_TFLOPS_BF16_MFMA = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 / fp16 (no sparsity)
 
 
-def build_model(device, concat_h, dtype=torch.float32):
+def build_model(device, concat_h, dtype=torch.float32, mma=None):
     from iterative_inference_segm_amd.api import IterativeInference
     from iterative_inference_segm_amd.dae import StandardDAE
     from iterative_inference_segm_amd.fcn8 import FCN8
     fp = S.make_fcn8_params(seed=1234)      # same seed on every rank: replicated weights
     dp = S.make_dae_params(seed=4321)
-    fcn = FCN8(fp, N_CLASSES, layer=concat_h + ['probs_dimshuffle'], device=device, dtype=dtype)
+    fcn = FCN8(fp, N_CLASSES, layer=concat_h + ['probs_dimshuffle'], device=device, dtype=dtype,
+               mma=mma)
     dae = StandardDAE(dp, N_CLASSES, concat_h=concat_h, padding=100, n_filters=64,
                       additional_pool=2, skip=True, unpool_type='trackind', device=device,
-                      dtype=dtype)
+                      dtype=dtype, mma=mma)
     return IterativeInference(fcn, dae, N_CLASSES, [N_CLASSES], device=device, dtype=dtype), fp, dp
 
 
@@ -300,6 +302,7 @@ def main():
     ap.add_argument('--no-full-recompute', action='store_true',
                     help='skip the extra timed runs with the work eliminations off')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-bf16', action='store_true', help='skip the 16-bit MFMA (bf16) leg')
     ap.add_argument('--no-strict-f64', action='store_true',
                     help='skip the float64 (strict parity) leg')
     ap.add_argument('--dry-run', action='store_true',
@@ -416,6 +419,40 @@ def worker(args):
                  'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in full every '
                  'step and batch (same kernels)')
         ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
+    if not args.no_bf16:
+        # 16-bit MFMA leg (VERDICT row N1; north_star: ">= 1000 images/s at >= 40 % of fp16 MFMA
+        # peak"): bf16 operands + fp32 accumulation on the wide 3x3 layers, everything else as in
+        # the fp32 run.  Statistical parity only; the headline `value` stays the fp32 line.
+        ii16, _, _ = build_model(device, concat_h, mma='bf16')
+        ii16.prepare(B, 224, 224)
+        t1, res16 = timed_steps(ii16, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
+                                world, device)
+        acc16 = iidist.EvalAccumulator(N_CLASSES)
+        for ms in res16:
+            a, j, mse = ms[0].result()
+            acc16.add_batch(ms[0].cm.cpu().numpy(), a, mse)
+        acc16.all_reduce(device)
+        torch.cuda.synchronize()
+        iidist.barrier()
+        d16 = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([d16], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            d16 = float(tmax.item())
+        v16 = world * B * args.steps / d16
+        _, a16, miou16, _, _ = acc16.results()
+        leg16 = {'value': round(v16, 3), 'unit': 'images/s', 'dtype': 'bf16 operands, f32 accumulate',
+                 'ms_per_step': round(d16 / args.steps * 1e3, 2),
+                 'miou_iterative_inference': round(miou16, 5),
+                 'delta_miou_vs_f32': round(miou16 - miou, 5),
+                 'parity': 'statistical only (north_star: mIoU within +-0.05); per-layer relative '
+                           'RMS error ~3e-3 (tests/test_gpu_bf16.py)'}
+        if not args.no_roofline:
+            leg16['roofline'] = conv_roofline(ii16, X, T, args.num_iter, args.step_size,
+                                              d16 / args.steps * 1e3, PEAK_TFLOPS_BF16_MFMA)
+        line['bf16'] = leg16
+        del ii16
+        torch.cuda.empty_cache()
     if not args.no_strict_f64:
         # the float64 path (reference CPU numerics): same config at batch 16, the leg
         # that carries the end-to-end 1e-4 parity claim (tests/test_gpu_f64.py)

@@ -172,7 +172,10 @@ int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
  * per operand).  Any (C1 + C2) is accepted (channels are zero-padded to the 64-channel k-tile).
  *   iiseg_conv_wino_bf16_supported        1 if `d` can run on this path, else 0
  *   iiseg_conv_wino_bf16_weight_bytes     bytes of the packed bf16 weights U16
- *   iiseg_conv_wino_bf16_workspace_bytes  bytes of caller-owned workspace (transformed input V16)
+ *   iiseg_conv_wino_bf16_workspace_bytes  bytes of caller-owned workspace (transformed input V16;
+ *                                         for layers with >= 1024 channels, which run the GEMMs as
+ *                                         their own kernel with 256 x 128 blocks, also the fp32
+ *                                         products M)
  *   iiseg_conv_wino_bf16_pack             w (layout as in iiseg_conv_pack_f32) -> U16, once per layer
  *   iiseg_conv_wino_bf16                  stages: IISEG_WINO_INPUT | IISEG_WINO_GEMM (= all)
  * ------------------------------------------------------------------------------------- */
@@ -184,6 +187,32 @@ int iiseg_conv_wino_bf16_pack(void* stream, const iiseg_conv_desc* d, const floa
 int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
                          const float* pre, const float* pooled, const void* U16, const float* bias,
                          const float* add, void* workspace, float* out, uint32_t stages);
+
+/* bf16-operand GEMM form of the 'valid' K x K layers computed in full into a dense output (fc6 7x7,
+ * fc7 / score_fr 1x1: models/fcn8.py:75-85), the counterpart of iiseg_conv_gemm_f32: im2col to a
+ * bf16 workspace, one bf16 GEMM (no split-K), bias / ReLU / NCHW store.  U16: ..._weight_bytes bytes
+ * from iiseg_conv_gemm_bf16_pack (w layout as in iiseg_conv_pack_f32); workspace: ..._workspace_bytes. */
+int iiseg_conv_gemm_bf16_supported(const iiseg_conv_desc* d);
+int64_t iiseg_conv_gemm_bf16_weight_bytes(const iiseg_conv_desc* d);
+int64_t iiseg_conv_gemm_bf16_workspace_bytes(const iiseg_conv_desc* d);
+int iiseg_conv_gemm_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
+                              int64_t stride_o, int64_t stride_c, void* U16);
+int iiseg_conv_gemm_bf16(void* stream, const iiseg_conv_desc* d, const float* x, const void* U16,
+                         const float* bias, void* workspace, float* out);
+
+/* Halo-tile DIRECT 3x3 convolution with bf16 MFMA operands (fp32 accumulate) for the shallow layers
+ * the Winograd form does not pay for (few channels, large maps; HBM-bound): same descriptor
+ * semantics and fusions as iiseg_conv_f32 / iiseg_conv_pool_f32 for 3x3, dil 1, stride 1 layers
+ * (two sources need C1 % 16 == 0).  wp16: iiseg_conv_halo_bf16_weight_bytes bytes, filled by
+ * iiseg_conv_halo_bf16_pack from w (layout as in iiseg_conv_pack_f32).  pool_out (may be NULL): the
+ * FULL pooled tensor, as in iiseg_conv_pool_f32 (even window origin, whole pooling windows, no add). */
+int iiseg_conv_halo_bf16_supported(const iiseg_conv_desc* d);
+int64_t iiseg_conv_halo_bf16_weight_bytes(const iiseg_conv_desc* d);
+int iiseg_conv_halo_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
+                              int64_t stride_o, int64_t stride_c, void* wp16);
+int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                         const float* pre, const float* pooled, const void* wp16, const float* bias,
+                         const float* add, float* out, float* pool_out);
 
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 16
+ABI_VERSION = 18
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -59,6 +59,15 @@ SIGNATURES = {
     'iiseg_conv_wino_bf16_workspace_bytes': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_wino_bf16_pack': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
     'iiseg_conv_wino_bf16': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9 + [C.c_uint32]),
+    'iiseg_conv_gemm_bf16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_gemm_bf16_weight_bytes': (_i64, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_gemm_bf16_workspace_bytes': (_i64, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_gemm_bf16_pack': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
+    'iiseg_conv_gemm_bf16': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5),
+    'iiseg_conv_halo_bf16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_halo_bf16_weight_bytes': (_i64, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_halo_bf16_pack': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
+    'iiseg_conv_halo_bf16': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_conv_gemm_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5 + [C.c_uint32]),

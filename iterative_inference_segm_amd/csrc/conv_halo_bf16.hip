@@ -1,0 +1,419 @@
+// Halo-tile direct 3x3 convolution on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32
+// accumulation): the 16-bit MFMA kernel for the SHALLOW 3x3 layers of the hot path (few channels,
+// 113^2..422^2 maps), which are HBM-bound once the matrix work is 16x cheaper than in fp32.
+// Same tiling as conv_halo.hip: a workgroup owns a TH x 32 pixel tile of one image and BM output
+// channels; per k-tile (16 input channels) it stages the (TH+2) x 34 input patch ONCE, here as bf16
+// "k8 chunks" (the 8 channels one lane feeds to an MFMA are 16 contiguous bytes):
+//     Ps[h][py][px] = bf16(x[c0 + 8h .. c0 + 8h + 7][iy0 + py][ix0 + px])      h = 0, 1
+// built in registers (8 coalesced dword loads -> 4 v_cvt_pk_bf16_f32 -> 1 ds_write_b128; with
+// IISEG_CONV_UNPOOL the DePool2D equality mask of layers/mylayers.py:88-115 is applied to the fp32
+// values first: 3 loads + compare per patch element).  The MFMA B operand of tap (ky, kx) is one
+// conflict-free ds_read_b128 at Ps[lane >> 5][y + ky][x + kx]; the A operand comes from the packed
+// bf16 weights Wp16[kt][tap][h][co][8] streamed global -> LDS by 16-byte LDS-DMA.
+// Activations stay fp32 NCHW in HBM; fusions as in conv_halo.hip (bias / skip-add with crop / ReLU /
+// window / placement / channel slice, 2x2 max-pool in the epilogue).  Statistical parity only.
+// Same Lasagne Conv2DLayer call sites (models/fcn8.py:34-45, models/fcn_down.py:102-104,
+// models/fcn_up.py:83-86; FC-DenseNet's BN_ReLU_Conv convs, models/FCDenseNet.py:90).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int RSRC_W3 = 0x00027000;
+constexpr unsigned OOB = 0x80000000u;
+constexpr int CPT = 16;                 // channels per k-tile = one MFMA k-step per tap
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// Wp16[kt][tap][h][co][j] = bf16(w[co][c = 16 kt + 8 h + j][tap]), zero beyond Cin / Cout
+__global__ void halo_pack_bf16_kernel(const float* __restrict__ w, int64_t so, int64_t sc,
+                                      __bf16* __restrict__ wp, int Cin, int Cout, int nkt, int Mpad) {
+    const int64_t n = (int64_t)nkt * 9 * 2 * Mpad * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        int64_t r = i >> 3;
+        const int co = (int)(r % Mpad); r /= Mpad;
+        const int h = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 9);
+        const int kt = (int)(r / 9);
+        const int c = kt * CPT + h * 8 + j;
+        const float v = (c < Cin && co < Cout) ? w[co * so + c * sc + tap] : 0.f;
+        wp[i] = (__bf16)v;
+    }
+}
+
+template <int BM, int TH, int WM, int WN, bool UNPOOL>
+__global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(const ConvParams p, const int tiles_y,
+                                                                const int tiles_x) {
+    constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
+    constexpr int NCHK = 2 * PP;                  // patch chunks per k-tile
+    constexpr int NE = (NCHK + 255) / 256;        // ... per thread
+    constexpr int WTM = BM / WM, TM = WTM / 32;
+    constexpr int RW = TH / WN, TN = RW;          // output rows per wave = 32-pixel MFMA column tiles
+    constexpr int WCH = 9 * 2 * BM;               // weight chunks per k-tile
+    constexpr int WPT = (WCH + 255) / 256;
+    static_assert(WM * WN == 4 && TH % WN == 0 && BM % (WM * 32) == 0, "tile config");
+
+    __shared__ __attribute__((aligned(16))) uint4 Ws[2][WCH];     // [tap][h][BM] chunks
+    // (single patch buffer: 47.7 KB per workgroup at BM = 64, i.e. three workgroups per CU -- the
+    // kernel is bound by memory latency, occupancy is worth more than skipping one barrier)
+    __shared__ __attribute__((aligned(16))) uint4 Ps[1][NCHK];    // [h][PH][PW] chunks
+
+    int pt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
+    const int m0 = mt * BM;
+    const int tpi = tiles_y * tiles_x;
+    const int b = pt / tpi;
+    const int tr = pt - b * tpi;
+    const int ty = tr / tiles_x, tx = tr - ty * tiles_x;
+    const int wy0 = ty * TH, wx0 = tx * TW;                        // tile origin, window coords
+    const int iy0 = p.oy0 + wy0 - p.pad, ix0 = p.ox0 + wx0 - p.pad;  // patch origin, input coords
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW = p.H * p.W, hw2 = p.h2 * p.w2;
+    const int C1 = p.C1, Ctot = p.C1 + p.C2;
+
+    // ---- patch staging: chunk e = i*256 + tid -> (channel half h, patch y, patch x) -------------
+    unsigned voff[NE], voff2[UNPOOL ? NE : 1];
+    int ch0[NE];                                  // first channel of the chunk inside the k-tile
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = i * 256 + tid;
+        const int h = e / PP, rr = e - h * PP;
+        const int py = rr / PW, px = rr - py * PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        bool ok = e < NCHK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ch0[i] = 8 * h;
+        voff[i] = ok ? 4u * (unsigned)(iy * p.W + ix) : OOB;
+        if constexpr (UNPOOL) {
+            // DePool2D (layers/mylayers.py:95-114): only the 2h x 2w region has pooling windows
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+            voff2[i] = ok ? 4u * (unsigned)((iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+        }
+    }
+    // one image per tile: descriptors start at image b of each source
+    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
+    const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
+    const float* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
+    const float* baseu = UNPOOL ? p.x1 + (size_t)b * C1 * hw2 : nullptr;
+    const int nq = C1 * hw2 * 4;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float xv[NE][8];
+    float xq[UNPOOL ? NE : 1][8], xu[UNPOOL ? NE : 1][8];
+    const int nkt = p.Kpad;                        // bf16 plan: Kpad holds the number of k-tiles
+    const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, nkt * 9 * 2 * p.Mpad * 16);
+
+    // channels [c0, c0+16) of the logical (concatenated) input; the source is tile-uniform
+    // (C1 % 16 == 0 when there are two sources); channels beyond the layer's read as zero
+#define HBF_LOAD_X(KT)                                                                             \
+    {                                                                                              \
+        const int c0 = (KT) * CPT;                                                                 \
+        const bool s1 = UNPOOL || c0 < C1;                                                         \
+        const int crem = (s1 ? C1 : Ctot) - c0;                                                    \
+        const int cb = s1 ? c0 : c0 - C1;                                                          \
+        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
+                const bool cok = ch0[i] + j < crem;                                                \
+                const unsigned so = (unsigned)((cb + ch0[i] + j) * HW) * 4u;                       \
+                xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
+                if constexpr (UNPOOL) {                                                            \
+                    const unsigned so2 = (unsigned)((cb + ch0[i] + j) * hw2) * 4u;                 \
+                    xq[i][j] = buf_ld(mk_rsrc(baseq, nq), cok ? voff2[i] : OOB, so2);              \
+                    xu[i][j] = buf_ld(mk_rsrc(baseu, nq), cok ? voff2[i] : OOB, so2);              \
+                }                                                                                  \
+            }                                                                                      \
+        });                                                                                        \
+    }
+#define HBF_STORE_X(BUF)                                                                           \
+    static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
+        constexpr int i = decltype(I)::value;                                                      \
+        float v[8];                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+            /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */          \
+            if constexpr (UNPOOL) v[j] = (xv[i][j] == xq[i][j]) ? xu[i][j] : 0.f;                  \
+            else v[j] = xv[i][j];                                                                  \
+        }                                                                                          \
+        if (NE * 256 == NCHK || i * 256 + tid < NCHK)                                              \
+            Ps[BUF][i * 256 + tid] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),      \
+                                                pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));     \
+    });
+    // weights of k-tile KT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
+#define HBF_LOAD_W(KT, BUF)                                                                        \
+    static_for<0, WPT>([&](auto J) __attribute__((always_inline)) {                                \
+        constexpr int j = decltype(J)::value;                                                      \
+        const int f = j * 256 + tid;                                                               \
+        const int row = f / BM, col = f % BM;                                                      \
+        if ((j + 1) * 256 <= WCH || f < WCH)                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                wrsrc, (__attribute__((address_space(3))) void*)(&Ws[BUF][0] + j * 256 + wave * 64), \
+                16, (int)(16u * (unsigned)(((KT) * 18 + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
+    });
+
+    HBF_LOAD_X(0)
+    HBF_LOAD_W(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HBF_STORE_X(0)
+    __syncthreads();
+
+    const int lrow = wn * RW;   // first output row of this wave inside the tile
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            HBF_LOAD_W(kt + 1, buf ^ 1)
+            HBF_LOAD_X(kt + 1)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
+            constexpr int tap = decltype(TAP)::value;
+            constexpr int ky = tap / 3, kx = tap % 3;
+            uint4 a[TM], bq[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ws[buf][(tap * 2 + lh) * BM + wm * WTM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[j] = Ps[0][(lh * PH + lrow + j + ky) * PW + l31 + kx];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bq[j]), acc[i][j],
+                        0, 0, 0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                 // every wave has read the patch of k-tile kt
+            HBF_STORE_X(0)
+        }
+        __syncthreads();
+    }
+#undef HBF_LOAD_X
+#undef HBF_STORE_X
+#undef HBF_LOAD_W
+
+    // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store ---------------------------
+    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh
+    const int wx = wx0 + l31;
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    if (p.pool) {
+        // fused 2x2 max-pool: a wave owns the row pairs (2m, 2m+1) of its rows (window origin and
+        // RW are even), the column pair is the neighbouring lane.  No lane leaves early here: the
+        // cross-lane max needs every lane; stores are predicated.
+        if constexpr (TN % 2 == 0) {
+            const size_t PPL = (size_t)p.pool_H * p.pool_W;
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int wy = wy0 + wn * RW + j;
+                const bool ok0 = wy < p.OH && wx < p.OW, ok1 = wy + 1 < p.OH && wx < p.OW;
+                float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                              (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+                const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
+                const bool okp = ok1 && wx + 1 < p.OW && !(l31 & 1) && py < p.pool_H && px < p.pool_W;
+                float* poolp = p.pool + (size_t)b * p.Cout * PPL + (size_t)py * p.pool_W + px;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float bias = p.bias ? p.bias[min(co, p.Cout - 1)] : 0.f;
+                        float v0 = acc[i][j][r] + bias, v1 = acc[i][j + 1][r] + bias;
+                        if (p.relu) {
+                            v0 = fmaxf(v0, 0.f);
+                            v1 = fmaxf(v1, 0.f);
+                        }
+                        const bool cv = co < p.Cout;
+                        if (cv && ok0) outp[(size_t)co * OPL] = v0;
+                        if (cv && ok1) outp[(size_t)co * OPL + p.out_W] = v1;
+                        float m = fmaxf(v0, v1);
+                        m = fmaxf(m, __shfl_xor(m, 1));
+                        if (cv && okp) poolp[(size_t)co * PPL] = m;
+                    }
+            }
+        }
+        return;
+    }
+    if (wx >= p.OW) return;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int wy = wy0 + wn * RW + j;
+        if (wy >= p.OH) continue;
+        float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                      (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        // skip-add values first, all loads in flight together (channel index clamped), then the
+        // stores: out and add may alias as far as the compiler knows
+        float addv[TM][16];
+        if (p.add) {
+            const float* addp = p.add + (size_t)b * p.Cout * APL + (size_t)(p.ay0 + wy) * p.AW +
+                                p.ax0 + wx;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    addv[i][r] = addp[(size_t)min(co, p.Cout - 1) * APL];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[min(co, p.Cout - 1)];
+                if (p.add) v += addv[i][r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (co < p.Cout) outp[(size_t)co * OPL] = v;
+            }
+    }
+}
+
+template <int BM, int TH, int WM, int WN>
+int launch_halo_bf16(hipStream_t s, const ConvParams& cp, bool unpool) {
+    ConvParams p = cp;
+    const int tiles_y = (p.OH + TH - 1) / TH, tiles_x = (p.OW + 31) / 32;
+    p.n_ptiles = p.B * tiles_y * tiles_x;
+    p.n_mtiles = p.Mpad / BM;
+    const int grid = p.n_ptiles * p.n_mtiles;
+    if (unpool)
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
+                           p, tiles_y, tiles_x);
+    else
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, false>), dim3(grid), dim3(256), 0, s,
+                           p, tiles_y, tiles_x);
+    return iiseg_check_launch();
+}
+
+int halo_bf16_bm(int Cout) { return Cout > 32 ? 64 : 32; }
+
+int halo_bf16_check(const iiseg_conv_desc* d) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2))
+        return IISEG_ERR_UNSUPPORTED;
+    if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
+        d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
+        return IISEG_ERR_SHAPE;
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
+    if ((d->flags & IISEG_CONV_UNPOOL) && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
+    if (d->C2 > 0 && d->C1 % CPT) return IISEG_ERR_UNSUPPORTED;  // a k-tile must not straddle sources
+    if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot)) return IISEG_ERR_SHAPE;
+    if (d->out_H != 0 && (d->out_y0 < 0 || d->out_x0 < 0 || d->out_y0 + d->OH > d->out_H ||
+                          d->out_x0 + d->OW > d->out_W))
+        return IISEG_ERR_SHAPE;
+    const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+    if (cmax * d->H * d->W * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;  // 32-bit byte offsets
+    const int nkt = (d->C1 + d->C2 + CPT - 1) / CPT;
+    const int bm = halo_bf16_bm(d->Cout), mpad = (d->Cout + bm - 1) / bm * bm;
+    if ((int64_t)nkt * 18 * mpad * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if ((int64_t)d->B * ((d->OH + 3) / 4) * ((d->OW + 31) / 32) * (mpad / 32) >= (1ll << 31))
+        return IISEG_ERR_UNSUPPORTED;
+    return IISEG_OK;
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_halo_bf16_supported(const iiseg_conv_desc* d) {
+    return halo_bf16_check(d) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int64_t iiseg_conv_halo_bf16_weight_bytes(const iiseg_conv_desc* d) {
+    if (halo_bf16_check(d) != IISEG_OK) return 0;
+    const int nkt = (d->C1 + d->C2 + CPT - 1) / CPT;
+    const int bm = halo_bf16_bm(d->Cout), mpad = (d->Cout + bm - 1) / bm * bm;
+    return (int64_t)nkt * 18 * mpad * 16;
+}
+
+extern "C" int iiseg_conv_halo_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
+                                         int64_t stride_o, int64_t stride_c, void* wp16) {
+    const int st = halo_bf16_check(d);
+    if (st) return st;
+    if (!w || !wp16) return IISEG_ERR_NULL;
+    if ((uintptr_t)wp16 & 15) return IISEG_ERR_ALIGN;
+    const int nkt = (d->C1 + d->C2 + CPT - 1) / CPT;
+    const int bm = halo_bf16_bm(d->Cout), mpad = (d->Cout + bm - 1) / bm * bm;
+    const int64_t n = (int64_t)nkt * 18 * mpad * 8;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(halo_pack_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                       stride_o, stride_c, (__bf16*)wp16, d->C1 + d->C2, d->Cout, nkt, mpad);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1,
+                                    const float* x2, const float* pre, const float* pooled,
+                                    const void* wp16, const float* bias, const float* add, float* out,
+                                    float* pool_out) {
+    const int st = halo_bf16_check(d);
+    if (st) return st;
+    if (!x1 || !wp16 || !out) return IISEG_ERR_NULL;
+    if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    if ((uintptr_t)wp16 & 15) return IISEG_ERR_ALIGN;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
+        return IISEG_ERR_SHAPE;
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (pool_out) {
+        // whole pooling windows only: even origin, even extent unless the window ends at the map's
+        // last (unpaired) row / column; no skip-add together with the pool
+        if (add || ((d->oy0 | d->ox0) & 1) || ((d->OH & 1) && d->oy0 + d->OH != fullH) ||
+            ((d->OW & 1) && d->ox0 + d->OW != fullW))
+            return IISEG_ERR_UNSUPPORTED;
+    }
+    const int bm = halo_bf16_bm(d->Cout);
+    ConvParams p = {};
+    p.x1 = x1; p.x2 = x2; p.pre = pre; p.pooled = pooled;
+    p.wp = (const float*)wp16;
+    p.bias = bias; p.add = add; p.out = out;
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    p.Kpad = (d->C1 + d->C2 + CPT - 1) / CPT;            // number of k-tiles
+    p.Mpad = (d->Cout + bm - 1) / bm * bm;
+    p.pad = d->pad; p.dil = 1;
+    p.pool = pool_out;
+    p.pool_H = fullH / 2; p.pool_W = fullW / 2;
+    p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
+    p.out_H = d->out_H ? d->out_H : d->OH;
+    p.out_W = d->out_H ? d->out_W : d->OW;
+    p.out_y0 = d->out_H ? d->out_y0 : 0;
+    p.out_x0 = d->out_H ? d->out_x0 : 0;
+    p.P = d->B * d->OH * d->OW;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (bm == 64) return launch_halo_bf16<64, 8, 1, 4>(s, p, unpool);
+    return launch_halo_bf16<32, 8, 1, 4>(s, p, unpool);
+}

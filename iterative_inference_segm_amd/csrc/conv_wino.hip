@@ -779,6 +779,34 @@ void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
 
 }  // namespace
 
+// Output transform + epilogue for products M[16][Mpad][Tpad] that another GEMM kernel wrote (the
+// bf16-operand path of conv_wino_bf16.hip): same kernel, tile geometry recomputed from `d`.
+int iiseg_wino_output_launch(hipStream_t s, const iiseg_conv_desc* d, const float* M, int Mpad,
+                             int Tpad, const float* bias, const float* add, float* out) {
+    WinoParams p = {};
+    p.M = const_cast<float*>(M);
+    p.bias = bias; p.add = add; p.out = out;
+    p.B = d->B; p.Cout = d->Cout; p.pad = d->pad;
+    p.oy0 = d->oy0; p.ox0 = d->ox0; p.OH = d->OH; p.OW = d->OW;
+    p.ty0 = d->oy0 - ((d->oy0 - d->tile_y0) & 1);
+    p.tx0 = d->ox0 - ((d->ox0 - d->tile_x0) & 1);
+    p.nty = (d->oy0 + d->OH - p.ty0 + 1) >> 1;
+    p.ntx = (d->ox0 + d->OW - p.tx0 + 1) >> 1;
+    p.T = d->B * p.nty * p.ntx;
+    p.Tpad = Tpad; p.Mpad = Mpad;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot > 0 ? d->out_c0 : 0;
+    p.out_H = d->out_H > 0 ? d->out_H : d->OH;
+    p.out_W = d->out_H > 0 ? d->out_W : d->OW;
+    p.out_y0 = d->out_H > 0 ? d->out_y0 : 0;
+    p.out_x0 = d->out_H > 0 ? d->out_x0 : 0;
+    hipLaunchKernelGGL(wino_output_kernel, dim3((p.T + 255) / 256, (d->Cout + OCH - 1) / OCH),
+                       dim3(256), 0, s, p);
+    return iiseg_check_launch();
+}
+
 extern "C" int iiseg_conv_wino_supported(const iiseg_conv_desc* d) {
     WinoGeom g;
     return wino_geom(d, g) == IISEG_OK ? 1 : 0;
@@ -1016,6 +1044,15 @@ int gemm_conv_geom(const iiseg_conv_desc* d, GemmConvGeom& g) {
 }
 
 }  // namespace
+
+// bias + ReLU + NCHW store of a GEMM result M[Mpad][Tpad] (S = 1) for the bf16 GEMM path
+int iiseg_gemm_output_launch(hipStream_t s, const float* M, const float* bias, float* out, int Cout,
+                             int OHW, int T, int Tpad, int Mpad, int relu) {
+    const int cy = Cout < 1024 ? Cout : 1024;
+    hipLaunchKernelGGL(gemm_output_kernel, dim3((T + 255) / 256, cy), dim3(256), 0, s, M, bias, out,
+                       Cout, OHW, T, Tpad, Mpad, 1, relu);
+    return iiseg_check_launch();
+}
 
 extern "C" int iiseg_conv_gemm_supported(const iiseg_conv_desc* d) {
     GemmConvGeom g;

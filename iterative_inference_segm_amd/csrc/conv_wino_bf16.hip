@@ -225,9 +225,12 @@ __global__ __launch_bounds__(256) void wino_input_bf16_kernel(const WinoBfParams
 }
 
 // ---- 2+3. the 16 GEMMs + output transform + epilogue in one kernel --------------------------------
-// As / Bs hold k-tiles of BK channels as BK/8 rows of 16-byte chunks.  A wave owns TM x TN blocks of
-// 32 channels x 32 tiles; k-step s of a k-tile reads chunk rows 2s + (lane >> 5).
-template <int BM, int BN, int WM, int WN, int BK, int MINW>
+// As / Bs hold k-tiles of BK channels as BK/8 rows of 16-byte chunks, in an NBUF-deep ring: the
+// bf16 matrix pipe needs only ~256 cycles per k-tile and wave, far less than a global -> LDS
+// transfer takes to land, so NBUF-1 k-tiles are kept in flight (counted vmcnt, raw s_barrier: a
+// __syncthreads() would drain the LDS-DMA queue).  A wave owns TM x TN blocks of 32 channels x 32
+// tiles; k-step s of a k-tile reads chunk rows 2s + (lane >> 5).
+template <int BM, int BN, int WM, int WN, int BK, int NBUF, int MINW>
 __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(const WinoBfParams p) {
     constexpr int KR = BK / 8, NS = BK / 16;   // chunk rows per k-tile, MFMA k-steps per k-tile
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -235,10 +238,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
     constexpr int NT = WM * WN * 64;
     constexpr int AV = KR * BM, BV = KR * BN;  // chunks per operand tile
     constexpr int APT = AV / NT, BPT = BV / NT;
-    static_assert(AV % NT == 0 && BV % NT == 0 && BK % 16 == 0, "tile config");
+    constexpr int OPS = APT + BPT;             // LDS-DMA instructions per thread and stage
+    static_assert(AV % NT == 0 && BV % NT == 0 && BK % 16 == 0 && NBUF >= 2, "tile config");
 
-    __shared__ __attribute__((aligned(16))) uint4 As[2][KR][BM];
-    __shared__ __attribute__((aligned(16))) uint4 Bs[2][KR][BN];
+    __shared__ __attribute__((aligned(16))) uint4 As[NBUF][KR][BM];
+    __shared__ __attribute__((aligned(16))) uint4 Bs[NBUF][KR][BN];
 
     int tt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ttiles, p.n_mtiles, tt, mt);
@@ -251,18 +255,19 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
     const size_t ustride = (size_t)kcr * p.Mpad, vstride = (size_t)kcr * p.Tpad;
     const int ubytes = kcr * p.Mpad * 16, vbytes = kcr * p.Tpad * 16;
 
-    // stage k-tile KT of transform point XI into LDS buffer BUF (global -> LDS, 16 B per lane)
-#define WBF_STAGE(XI, KT, BUF)                                                                     \
+    // stage k-tile number S (= xi * nkt + kt) into ring slot BUF (global -> LDS, 16 B per lane)
+#define WBF_STAGE(S, BUF)                                                                          \
     {                                                                                              \
-        const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)(XI) * ustride, ubytes);           \
-        const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)(XI) * vstride, vbytes);           \
+        const int sxi = (S) / nkt, skt = (S) - sxi * nkt;                                          \
+        const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)sxi * ustride, ubytes);            \
+        const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)sxi * vstride, vbytes);            \
         static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
             const int f = j * NT + tid;                                                            \
             const int row = f / BM, col = f % BM;                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 ar, (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + j * NT + wave * 64), \
-                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
+                16, (int)(16u * (unsigned)((skt * KR + row) * p.Mpad + m0 + col)), 0, 0, 0);       \
         });                                                                                        \
         static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
             const int row = f / BN, col = f % BN;                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 br, (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + j * NT + wave * 64), \
-                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Tpad + t0 + col)), 0, 0, 0);      \
+                16, (int)(16u * (unsigned)((skt * KR + row) * p.Tpad + t0 + col)), 0, 0, 0);       \
         });                                                                                        \
     }
 
@@ -285,17 +290,20 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
                 Y[0][i][j][r] = Y[1][i][j][r] = Y[2][i][j][r] = Y[3][i][j][r] = 0.f;
             }
 
-    WBF_STAGE(0, 0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    int xi = 0, kt = 0;              // the k-tile being multiplied
     const int total = 16 * nkt;
+    // prologue: NBUF-1 stages in flight, the first one landed
+#pragma unroll
+    for (int q = 0; q < NBUF - 1; ++q)
+        if (q < total) WBF_STAGE(q, q)
+    if (total >= NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * OPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int kt = 0, xi = 0, buf = 0;
     for (int s = 0; s < total; ++s) {
-        const int buf = s & 1;
-        int nxi = xi, nkt1 = kt + 1;  // the k-tile being staged
-        if (nkt1 == nkt) { nkt1 = 0; ++nxi; }
-        const bool more = s + 1 < total;
+        const bool more = s + NBUF - 1 < total;   // a stage is issued in this iteration
+        int sbuf = buf + NBUF - 1;                // ring slot of the tile requested now
+        if (sbuf >= NBUF) sbuf -= NBUF;
         uint4 a[2][TM], b[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lh][wm * WTM + i * 32 + l31];
@@ -318,11 +326,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
                         __builtin_bit_cast(bf16x8, a[st & 1][i]), __builtin_bit_cast(bf16x8, b[st & 1][j]),
                         acc[i][j], 0, 0, 0);
             if constexpr (st == 0) {
-                if (more) WBF_STAGE(nxi, nkt1, buf ^ 1)
+                if (more) WBF_STAGE(s + NBUF - 1, sbuf)
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (nkt1 == 0) {
+        if (++kt == nkt) {
+            kt = 0;
             // M_xi complete: Y_ab += AT[a][xi/4] * AT[b][xi%4] * M_xi,  AT = [1 1 1 0; 0 1 -1 -1]
             const int wi = xi >> 2, wj = xi & 3;
             const float r0 = wi < 3 ? 1.f : 0.f, r1 = wi == 0 ? 0.f : (wi == 1 ? 1.f : -1.f);
@@ -346,11 +355,14 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            ++xi;
         }
-        xi = nxi;
-        kt = nkt1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the next tile (issued NBUF-1 iterations ago) must have landed: all but the NBUF-2 most
+        // recent stages of this thread; then every wave's reads of `buf` are done (barrier)
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++buf == NBUF) buf = 0;
     }
 #undef WBF_STAGE
 
@@ -406,13 +418,170 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
     }
 }
 
+
+// ---- 2'. the GEMMs alone: M[xi][co][t] = sum_c U16[xi][c][co] * V16[xi][c][t], fp32 M ----------------
+// For the DEEP layers (>= 1024 channels on 10^2..19^2 windows: few tiles, long K) the fused kernel's
+// 128 x 64 / 128 x 128 output blocks re-read U16 / V16 too often for what a CU can pull through
+// LDS-DMA (~25-30 GB/s per CU beyond L2): there the 16 points become 16x more independent
+// workgroups with 256 x 128 blocks (85 flop/B), M makes one round trip through HBM (small: few
+// tiles) and conv_wino.hip's output-transform kernel finishes the layer.  Also the plain GEMM of
+// the 'valid' K x K layers (fc6 / fc7 / score_fr: n_xi = 1).
+template <int BM, int BN, int WM, int WN, int BK, int NBUF>
+__global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_bf16_kernel(const WinoBfParams p, float* M) {
+    constexpr int KR = BK / 8, NS = BK / 16;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int NT = WM * WN * 64;
+    constexpr int AV = KR * BM, BV = KR * BN;
+    constexpr int APT = AV / NT, BPT = BV / NT;
+    constexpr int OPS = APT + BPT;
+    static_assert(AV % NT == 0 && BV % NT == 0 && BK % 16 == 0 && NBUF >= 2, "tile config");
+
+    __shared__ __attribute__((aligned(16))) uint4 As[NBUF][KR][BM];
+    __shared__ __attribute__((aligned(16))) uint4 Bs[NBUF][KR][BN];
+
+    // XCD-aware order: each XCD (bid % 8) walks a contiguous run of (xi, tile) work, inside a run
+    // groups of 8 pixel-tiles x all channel-tiles share U and V rows in that XCD's L2
+    const int per_xi = p.n_ttiles * p.n_mtiles;
+    int xi, tt, mt;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb / 8, r = nb % 8, xcd = bid % 8, l = bid / 8;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + l;
+        xi = v / per_xi;
+        const int w = v - xi * per_xi;
+        constexpr int GP = 8;
+        const int gsize = GP * p.n_mtiles;
+        const int g = w / gsize, rr = w % gsize;
+        const int gp = min(GP, p.n_ttiles - g * GP);
+        tt = g * GP + rr % gp;
+        mt = rr / gp;
+    }
+    const int m0 = mt * BM, t0 = tt * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nkt = p.Kc / BK;
+    const int kcr = p.Kc >> 3;
+    const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)xi * kcr * p.Mpad, kcr * p.Mpad * 16);
+    const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)xi * kcr * p.Tpad, kcr * p.Tpad * 16);
+
+#define WBG_STAGE(KT, BUF)                                                                         \
+    {                                                                                              \
+        static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            const int f = j * NT + tid;                                                            \
+            const int row = f / BM, col = f % BM;                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                ar, (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + j * NT + wave * 64), \
+                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
+        });                                                                                        \
+        static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            const int f = j * NT + tid;                                                            \
+            const int row = f / BN, col = f % BN;                                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
+                br, (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + j * NT + wave * 64), \
+                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Tpad + t0 + col)), 0, 0, 0);      \
+        });                                                                                        \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int q = 0; q < NBUF - 1; ++q)
+        if (q < nkt) WBG_STAGE(q, q)
+    if (nkt >= NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * OPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + NBUF - 1 < nkt;
+        int sbuf = buf + NBUF - 1;
+        if (sbuf >= NBUF) sbuf -= NBUF;
+        uint4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][lh][wm * WTM + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][lh][wn * WTN + j * 32 + l31];
+        static_for<0, NS>([&](auto ST) __attribute__((always_inline)) {
+            constexpr int st = decltype(ST)::value;
+            if constexpr (st + 1 < NS) {
+                const int kr = (st + 1) * 2 + lh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(st + 1) & 1][i] = As[buf][kr][wm * WTM + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[(st + 1) & 1][j] = Bs[buf][kr][wn * WTN + j * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[st & 1][i]), __builtin_bit_cast(bf16x8, b[st & 1][j]),
+                        acc[i][j], 0, 0, 0);
+            if constexpr (st == 0) {
+                if (more) WBG_STAGE(kt + NBUF - 1, sbuf)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * OPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++buf == NBUF) buf = 0;
+    }
+#undef WBG_STAGE
+
+    // M[xi][co][t]: rows of the C/D layout are channels, columns (lane & 31) are tiles
+    float* Mx = M + (size_t)xi * p.Mpad * p.Tpad;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int t = t0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                Mx[(size_t)co * p.Tpad + t] = acc[i][j][r];
+            }
+    }
+}
+
+// launches the GEMM kernel for n_xi points: 256 x 128 blocks when Mpad allows, else 128 x 128
+void launch_gemm_bf16(hipStream_t s, WinoBfParams p, float* M, int n_xi) {
+    p.n_ttiles = p.Tpad / 128;
+    if (p.Mpad % 256 == 0) {
+        p.n_mtiles = p.Mpad / 256;
+        hipLaunchKernelGGL((wino_gemm_bf16_kernel<256, 128, 4, 2, 64, 3>),
+                           dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
+    } else {
+        p.n_mtiles = p.Mpad / 128;
+        hipLaunchKernelGGL((wino_gemm_bf16_kernel<128, 128, 2, 2, 64, 3>),
+                           dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p, M);
+    }
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 constexpr int WBF_BK = 64;   // k-tile of the GEMM kernel: channels are padded to it
 
 struct WinoBfGeom {
     int Kc, Mpad, bm, ty0, tx0, nty, ntx, T, Tpad;
+    bool fused;   // GEMMs + output transform in one kernel (else: GEMM kernel -> M -> output kernel)
 };
+
+// channels from which the separate GEMM (256 x 128 blocks, M through HBM) beats the fused kernel
+int split_min_kc() {
+    static const int v = getenv("IISEG_BF16_SPLIT_MIN_KC") ? atoi(getenv("IISEG_BF16_SPLIT_MIN_KC")) : 1024;
+    return v;
+}
 
 int wino_bf16_geom(const iiseg_conv_desc* d, WinoBfGeom& g) {
     if (!d) return IISEG_ERR_NULL;
@@ -439,10 +608,16 @@ int wino_bf16_geom(const iiseg_conv_desc* d, WinoBfGeom& g) {
         return IISEG_ERR_UNSUPPORTED;
     g.T = (int)T;
     g.Tpad = (int)Tpad;
+    g.fused = g.Kc < split_min_kc() || g.Mpad % 128 != 0;
     return IISEG_OK;
 }
 
 }  // namespace
+
+int iiseg_wino_output_launch(hipStream_t s, const iiseg_conv_desc* d, const float* M, int Mpad,
+                             int Tpad, const float* bias, const float* add, float* out);
+int iiseg_gemm_output_launch(hipStream_t s, const float* M, const float* bias, float* out, int Cout,
+                             int OHW, int T, int Tpad, int Mpad, int relu);
 
 extern "C" int iiseg_conv_wino_bf16_supported(const iiseg_conv_desc* d) {
     WinoBfGeom g;
@@ -458,7 +633,7 @@ extern "C" int64_t iiseg_conv_wino_bf16_weight_bytes(const iiseg_conv_desc* d) {
 extern "C" int64_t iiseg_conv_wino_bf16_workspace_bytes(const iiseg_conv_desc* d) {
     WinoBfGeom g;
     if (wino_bf16_geom(d, g) != IISEG_OK) return 0;
-    return (int64_t)16 * g.Kc * g.Tpad * 2;
+    return (int64_t)16 * g.Kc * g.Tpad * 2 + (g.fused ? 0 : (int64_t)16 * g.Mpad * g.Tpad * 4);
 }
 
 extern "C" int iiseg_conv_wino_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
@@ -525,11 +700,17 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
             else hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 0>), grid, block, 0, s, p);
         }
     }
+    if ((stages & IISEG_WINO_GEMM) && !g.fused) {
+        float* M = (float*)((char*)workspace + (size_t)16 * g.Kc * g.Tpad * 2);
+        launch_gemm_bf16(s, p, M, 16);
+        if (iiseg_check_launch()) return IISEG_ERR_LAUNCH;
+        return iiseg_wino_output_launch(s, d, M, g.Mpad, g.Tpad, bias, add, out);
+    }
     if (stages & IISEG_WINO_GEMM) {
         if (g.bm == 64) {
             p.n_ttiles = g.Tpad / 128;
             p.n_mtiles = g.Mpad / 64;
-            hipLaunchKernelGGL((wino_fused_bf16_kernel<64, 128, 1, 4, WBF_BK, 2>),
+            hipLaunchKernelGGL((wino_fused_bf16_kernel<64, 128, 1, 4, WBF_BK, 3, 2>),
                                dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
             return iiseg_check_launch();
         }
@@ -538,13 +719,147 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
         const int w128 = (g.Tpad / 128) * p.n_mtiles;
         if (w128 < 2 * 256) {
             p.n_ttiles = g.Tpad / 64;
-            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, WBF_BK, 2>),
+            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, WBF_BK, 3, 2>),
                                dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
         } else {
             p.n_ttiles = g.Tpad / 128;
-            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, WBF_BK, 2>),
+            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, WBF_BK, 3, 2>),
                                dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
         }
     }
     return iiseg_check_launch();
+}
+
+// ================================================================================================
+// 'valid' K x K layers computed in full (FCN-8's fc6 7x7, fc7 / score_fr 1x1; models/fcn8.py:75-85)
+// as im2col -> bf16 GEMM (the kernel above, one "point", no split-K: K = 25088 is 392 k-tiles of
+// cheap bf16 MFMAs) -> bias / ReLU / NCHW store.  k = (c * KH + ky) * KW + kx.
+// ================================================================================================
+namespace {
+
+struct GemmBfGeom {
+    int K, Kc, Mpad, T, Tpad;
+};
+
+int gemm_bf16_geom(const iiseg_conv_desc* d, GemmBfGeom& g) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->pad != 0 || d->dil != 1 || d->C2 != 0 ||
+        (d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2)))
+        return IISEG_ERR_UNSUPPORTED;
+    const int fullH = d->H - d->KH + 1, fullW = d->W - d->KW + 1;
+    if (d->B <= 0 || d->C1 <= 0 || d->Cout <= 0 || fullH <= 0 || fullW <= 0) return IISEG_ERR_SHAPE;
+    if (d->oy0 != 0 || d->ox0 != 0 || d->OH != fullH || d->OW != fullW || d->out_ctot != 0 ||
+        d->out_H != 0)
+        return IISEG_ERR_UNSUPPORTED;
+    g.K = d->C1 * d->KH * d->KW;
+    g.Kc = round_up(g.K, WBF_BK);
+    g.Mpad = round_up(d->Cout, 128);
+    const int64_t T = (int64_t)d->B * fullH * fullW;
+    const int64_t Tpad = (T + 127) / 128 * 128;
+    if (Tpad * g.Kc * 2 >= (int64_t)1 << 31 || (int64_t)g.Kc * g.Mpad * 2 >= (int64_t)1 << 31)
+        return IISEG_ERR_UNSUPPORTED;
+    g.T = (int)T;
+    g.Tpad = (int)Tpad;
+    return IISEG_OK;
+}
+
+// U16[k/8][co][k%8] = bf16(w[co][k]), zero beyond K / Cout
+__global__ void gemm_weight_bf16_kernel(const float* __restrict__ w, int64_t so, int64_t sc,
+                                        __bf16* __restrict__ U, int KK, int K, int Cout, int Kc, int Mpad) {
+    const int64_t n = (int64_t)Kc * Mpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int64_t r = i >> 3;
+        const int co = (int)(r % Mpad), k = (int)(r / Mpad) * 8 + j;
+        float v = 0.f;
+        if (k < K && co < Cout) {
+            const int c = k / KK, tap = k - c * KK;
+            v = w[co * so + c * sc + tap];
+        }
+        U[i] = (__bf16)v;
+    }
+}
+
+// V16[k/8][t][k%8] = bf16(x[b][c][oy + ky][ox + kx]); one thread = one pixel x one 8-k chunk
+__global__ __launch_bounds__(256) void gemm_im2col_bf16_kernel(const float* __restrict__ x,
+                                                               uint4* __restrict__ V, int C, int H,
+                                                               int W, int KH, int KW, int OH, int OW,
+                                                               int K, int Kc, int T, int Tpad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int OHW = OH * OW;
+    const int b = t / OHW, r = t - b * OHW;
+    const int oy = r / OW, ox = r - oy * OW;
+    const int KK = KH * KW;
+    const float* xb = x + (size_t)b * C * H * W + (size_t)oy * W + ox;
+    for (int kc = blockIdx.y; kc < (Kc >> 3); kc += gridDim.y) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kc * 8 + j;
+            const int c = k / KK, tap = k - c * KK;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            v[j] = k < K ? xb[(size_t)c * H * W + ky * W + kx] : 0.f;
+        }
+        V[(size_t)kc * Tpad + t] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
+                                              pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+    }
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_gemm_bf16_supported(const iiseg_conv_desc* d) {
+    GemmBfGeom g;
+    return gemm_bf16_geom(d, g) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int64_t iiseg_conv_gemm_bf16_weight_bytes(const iiseg_conv_desc* d) {
+    GemmBfGeom g;
+    if (gemm_bf16_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)g.Kc * g.Mpad * 2;
+}
+
+extern "C" int64_t iiseg_conv_gemm_bf16_workspace_bytes(const iiseg_conv_desc* d) {
+    GemmBfGeom g;
+    if (gemm_bf16_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)g.Kc * g.Tpad * 2 + (int64_t)g.Mpad * g.Tpad * 4;
+}
+
+extern "C" int iiseg_conv_gemm_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
+                                         int64_t stride_o, int64_t stride_c, void* U16) {
+    GemmBfGeom g;
+    const int st = gemm_bf16_geom(d, g);
+    if (st) return st;
+    if (!w || !U16) return IISEG_ERR_NULL;
+    if ((uintptr_t)U16 & 15) return IISEG_ERR_ALIGN;
+    const int64_t n = (int64_t)g.Kc * g.Mpad;
+    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gemm_weight_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                       stride_o, stride_c, (__bf16*)U16, d->KH * d->KW, g.K, d->Cout, g.Kc, g.Mpad);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_conv_gemm_bf16(void* stream, const iiseg_conv_desc* d, const float* x,
+                                    const void* U16, const float* bias, void* workspace, float* out) {
+    GemmBfGeom g;
+    const int st = gemm_bf16_geom(d, g);
+    if (st) return st;
+    if (!x || !U16 || !workspace || !out) return IISEG_ERR_NULL;
+    if (((uintptr_t)U16 & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    uint4* V = (uint4*)workspace;
+    float* M = (float*)((char*)workspace + (size_t)g.Kc * g.Tpad * 2);
+    const int kcr = g.Kc >> 3;
+    hipLaunchKernelGGL(gemm_im2col_bf16_kernel, dim3((g.T + 255) / 256, kcr < 512 ? kcr : 512),
+                       dim3(256), 0, s, x, V, d->C1, d->H, d->W, d->KH, d->KW, d->OH, d->OW, g.K,
+                       g.Kc, g.T, g.Tpad);
+    WinoBfParams p = {};
+    p.U = (const uint4*)U16;
+    p.V = V;
+    p.Kc = g.Kc; p.Mpad = g.Mpad; p.Tpad = g.Tpad; p.T = g.T;
+    launch_gemm_bf16(s, p, M, 1);
+    if (iiseg_check_launch()) return IISEG_ERR_LAUNCH;
+    return iiseg_gemm_output_launch(s, M, bias, out, d->Cout, d->OH * d->OW, g.T, g.Tpad, g.Mpad,
+                                    (d->flags & IISEG_CONV_RELU) ? 1 : 0);
 }

@@ -141,8 +141,12 @@ class Conv:
         self.wino_bf16 = (self.mma == 'bf16' and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
                           not self.transposed and self.Cin >= BF16_WINO_MIN_CIN and
                           self.Cout >= BF16_WINO_MIN_COUT)
+        # bf16 mode: every other plain 3x3 layer on the bf16 halo kernel (conv_halo_bf16.hip)
+        self.halo_bf16 = (self.mma == 'bf16' and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
+                          not self.transposed and not self.wino_bf16)
         self._U = None
         self._U16 = None
+        self._W16 = None
         self._plans = {}
         self._packs = {}
 
@@ -277,6 +281,25 @@ class Conv:
         if pool_out is None and self.wino_bf16 and \
                 self.lib.iiseg_conv_wino_bf16_supported(C.byref(d)):
             return self._call_wino_bf16(d, x1, x2, pre, pooled, add, out, prof)
+        if self.halo_bf16 and self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
+            if pool_out is not None:
+                fh, fw = self.out_hw(H, W)
+                if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2):
+                    raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
+            if self._W16 is None:
+                self._W16 = torch.empty(self.lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(d)) // 2,
+                                        dtype=torch.bfloat16, device=self.W.device)
+                check(self.lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(d), _ptr(self.W), self.so,
+                                                         self.sc, _ptr(self._W16, torch.bfloat16)),
+                      'iiseg_conv_halo_bf16_pack')
+            ev0 = _ev() if prof is not None else None
+            check(self.lib.iiseg_conv_halo_bf16(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
+                                                _ptr(pooled), _ptr(self._W16, torch.bfloat16),
+                                                _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out)),
+                  'iiseg_conv_halo_bf16')
+            if prof is not None:
+                prof.append(('conv_halo_bf16_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
+            return out
         if pool_out is None and self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
         if pool_out is not None:
@@ -296,6 +319,24 @@ class Conv:
             # deep 1x1 layers on few pixels (fc7, score_fr): the same split-K GEMM beats the 1x1 tap
             # kernel
             dt == torch.float32 and (self.KH, self.KW) == (1, 1) and self.Cin >= 1024)
+        if gemm_shape and CONV_GEMM and self.mma == 'bf16' and x2 is None and not unpool and \
+                add is None and self.lib.iiseg_conv_gemm_bf16_supported(C.byref(d)):
+            lib = self.lib
+            if self._W16 is None:
+                self._W16 = torch.empty(lib.iiseg_conv_gemm_bf16_weight_bytes(C.byref(d)) // 2,
+                                        dtype=torch.bfloat16, device=self.W.device)
+                check(lib.iiseg_conv_gemm_bf16_pack(_stream(), C.byref(d), _ptr(self.W), self.so,
+                                                    self.sc, _ptr(self._W16, torch.bfloat16)),
+                      'iiseg_conv_gemm_bf16_pack')
+            ws = _wino_workspace((lib.iiseg_conv_gemm_bf16_workspace_bytes(C.byref(d)) + 3) // 4,
+                                 x1.device)
+            ev0 = _ev() if prof is not None else None
+            check(lib.iiseg_conv_gemm_bf16(_stream(), C.byref(d), _ptr(x1),
+                                           _ptr(self._W16, torch.bfloat16), _ptr(self.b), _ptr(ws),
+                                           _ptr(out)), 'iiseg_conv_gemm_bf16')
+            if prof is not None:
+                prof.append(('wino_gemm_bf16_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
+            return out
         if gemm_shape and CONV_GEMM and x2 is None and not unpool and \
                 add is None and self.lib.iiseg_conv_gemm_supported(C.byref(d)):
             ws = _wino_workspace(self.lib.iiseg_conv_gemm_workspace_elems(C.byref(d)), x1.device)
@@ -362,8 +403,12 @@ class Conv:
         window (y0, x0, h, w) to launch so that every pooling window touching `region` (of the
         conv output; None = the whole map) is whole -- even origin, even extent unless it ends at
         the map's last row / column.  None if the layer does not run on the halo kernel."""
-        if not POOL_FUSE or self.dtype != torch.float32 or self.wino or \
-                self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256:
+        if not POOL_FUSE or self.dtype != torch.float32:
+            return None
+        if self.mma == 'bf16':
+            if not self.halo_bf16:
+                return None
+        elif self.wino or self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256:
             return None
         fh, fw = self.out_hw(H, W)
         if region is None:

@@ -7,8 +7,9 @@ import torch
 import bench
 from iterative_inference_segm_amd import ops, synthetic as S
 
-ii, fp, dp = bench.build_model('cuda', ['pool4'])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+MMA = sys.argv[2] if len(sys.argv) > 2 else None          # 'bf16': the 16-bit MFMA path
+ii, fp, dp = bench.build_model('cuda', ['pool4'], mma=MMA)
 NIT = 2
 Xs = [torch.from_numpy(S.make_images(B, 224, 224, seed=s)).cuda() for s in (1, 2)]
 T = torch.from_numpy(S.make_labels(B, 224, 224)).cuda()
@@ -31,6 +32,7 @@ def wrapped(self, *a, **kw):
                   n0, len(prof)))
     return out
 ops.Conv.__call__ = wrapped
+torch.cuda._sleep(int(8e8))     # the host enqueues the whole step behind this: no launch gaps in the brackets
 bench.one_step(ii, Xs[1], T, NIT, 0.1)
 torch.cuda.synchronize()
 tot = gap_tot = 0

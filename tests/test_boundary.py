@@ -40,6 +40,21 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert b'shape' in loaded.iiseg_strerror(-2)
 
 
+def test_binding_argument_counts_match_the_header():
+    """Every ctypes signature has exactly as many arguments as the header's prototype (a wrong
+    count only shows up as a TypeError at the first GPU call otherwise)."""
+    from iterative_inference_segm_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'iiseg.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    protos = dict(re.findall(r'\b(iiseg_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', text))
+    assert sorted(protos) == sorted(_lib.SIGNATURES)
+    for name, args in protos.items():
+        args = args.strip()
+        n = 0 if args in ('', 'void') else len(args.split(','))
+        assert n == len(_lib.SIGNATURES[name][1]), '%s: header %d arguments, binding %d' % (
+            name, n, len(_lib.SIGNATURES[name][1]))
+
+
 def test_library_contains_gfx950_code_object(built_lib):
     blob = open(built_lib, 'rb').read()
     assert b'gfx950' in blob and b'conv_taps_f32_kernel' in blob and b'conv_igemm_f32_kernel' in blob

@@ -124,3 +124,159 @@ def test_wino_bf16_statistical_at_layer_size(ops, shape):
     assert np.array_equal(part, got[:, :, 2:H - 2, 4:W - 2])
     # and bit-identical across batch compositions
     assert np.array_equal(host(conv(xt[1:2].contiguous())), got[1:2])
+
+
+HALO_CASES = [  # B, Cin, H, W, Cout, pad, relu
+    (2, 3, 20, 37, 64, 4, True),          # FCN conv1_1-like: 3 channels zero-padded to the k-tile
+    (1, 11, 33, 70, 64, 3, True),         # DAE conv1_1-like
+    (2, 64, 17, 40, 64, 1, True),
+    (1, 64, 30, 33, 128, 1, True),        # two 64-channel output tiles
+    (2, 64, 25, 45, 11, 1, False),        # up_conv1-like: 11 output channels in a 32-row tile
+    (1, 48, 19, 19, 16, 1, False),        # FC-DenseNet growth-rate-16 layer, ragged Cin
+    (1, 100, 9, 9, 40, 1, True),
+]
+
+
+@pytest.mark.parametrize('case', HALO_CASES)
+def test_halo_bf16_exact_on_integer_data(ops, case):
+    B, Cin, H, W, Cout, pad, relu = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x = ints(rng, B, Cin, H, W)
+    Wt, b = ints(rng, Cout, Cin, 3, 3), ints(rng, Cout)
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, mma='bf16')
+    assert conv.halo_bf16 and not conv.wino_bf16
+    got = host(conv(dev(x)))
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref.astype(np.float32)), np.abs(got - ref).max()
+
+
+def test_halo_bf16_fusions_exact(ops):
+    rng = np.random.default_rng(17)
+    # two-source concat (h first; C1 a multiple of the 16-channel k-tile)
+    h, t = ints(rng, 2, 32, 21, 35), ints(rng, 2, 24, 21, 35)
+    Wt, b = ints(rng, 64, 56, 3, 3), ints(rng, 64)
+    ref = onn.conv2d(onn.concat_h_first(h, t), Wt, b, pad=1, relu=True)
+    got = host(ops.Conv(Wt, b, pad=1, relu=True, mma='bf16')(dev(h), x2=dev(t)))
+    assert np.array_equal(got, ref.astype(np.float32))
+    # DePool2D input (odd trailing row / column) + skip-add with crop + window + placement
+    pre = np.maximum(ints(rng, 2, 64, 27, 41), 0)
+    pooled = onn.maxpool2(pre)
+    up = ints(rng, *pooled.shape)
+    Wt, b = ints(rng, 40, 64, 3, 3), ints(rng, 40)
+    other = ints(rng, 2, 40, 31, 43)
+    full = onn.conv2d(onn.depool_eqmask(up, pre, pooled), Wt, b, pad=1)
+    conv = ops.Conv(Wt, b, pad=1, relu=False, mma='bf16')
+    for (oy, ox, oh, ow) in [(1, 2, 23, 37), (0, 0, 27, 41), (5, 7, 9, 30)]:
+        ref = full[:, :, oy:oy + oh, ox:ox + ow] + other[:, :, 2 + oy:2 + oy + oh, 1 + ox:1 + ox + ow]
+        out = torch.full((2, 40, 35, 50), -9.0, device='cuda')
+        conv(dev(up), pre=dev(pre), pooled=dev(pooled), add=dev(other), add_off=(2 + oy, 1 + ox),
+             window=(oy, ox, oh, ow), out=out, place=(4, 5))
+        o = host(out)
+        assert np.array_equal(o[:, :, 4:4 + oh, 5:5 + ow], ref.astype(np.float32)), (oy, ox)
+        o[:, :, 4:4 + oh, 5:5 + ow] = -9.0
+        assert np.all(o == -9.0)
+    # 2x2 max-pool in the epilogue: full map (odd sizes) and an even-origin window placed in place
+    x = ints(rng, 2, 64, 23, 37)
+    Wt, b = ints(rng, 64, 64, 3, 3), ints(rng, 64)
+    conv = ops.Conv(Wt, b, pad=2, relu=True, mma='bf16')
+    ref = onn.conv2d(x, Wt, b, pad=2, relu=True)            # (2, 64, 25, 39)
+    pw = conv.pool_window(23, 37)
+    assert pw == (0, 0, 25, 39)
+    pool = torch.full((2, 64, 12, 19), -1.0, device='cuda')
+    got = host(conv(dev(x), pool_out=pool))
+    assert np.array_equal(got, ref.astype(np.float32))
+    assert np.array_equal(host(pool), onn.maxpool2(ref).astype(np.float32))
+    win = conv.pool_window(23, 37, (5, 9, 11, 13))
+    assert win[0] % 2 == 0 and win[1] % 2 == 0
+    full_out = torch.zeros((2, 64, 25, 39), device='cuda')
+    pool2 = torch.full((2, 64, 12, 19), -1.0, device='cuda')
+    conv(dev(x), window=win, out=full_out, place=(win[0], win[1]), pool_out=pool2)
+    y0, x0, hh, ww = win
+    assert np.array_equal(host(full_out)[:, :, y0:y0 + hh, x0:x0 + ww],
+                          ref[:, :, y0:y0 + hh, x0:x0 + ww].astype(np.float32))
+    p2, pr = host(pool2), onn.maxpool2(ref)
+    ys, xs = slice(y0 // 2, (y0 + hh) // 2), slice(x0 // 2, (x0 + ww) // 2)
+    assert np.array_equal(p2[:, :, ys, xs], pr[:, :, ys, xs].astype(np.float32))
+    p2[:, :, ys, xs] = -1.0
+    assert np.all(p2 == -1.0)
+
+
+def test_bf16_dae_forward_statistical(built_lib):
+    """The whole standard DAE of configs[1] (64 filters, pool4, 224x224) with bf16 MFMA operands
+    against the float64 oracle on the SAME h, y: with the oracle's DePool2D masks injected (the
+    discontinuity taken out) the reconstruction must agree to the bf16 error level; free (own masks)
+    the argmax must still agree on almost every pixel."""
+    from oracle import dae as odae
+    from iterative_inference_segm_amd import ops, synthetic as S
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from _parity_helpers import eq_masks, to64
+    dp = S.make_dae_params()
+    rng = np.random.default_rng(5)
+    y = rng.random((1, 11, 224, 224)).astype(np.float32); y /= y.sum(1, keepdims=True)
+    h = rng.random((1, 512, 26, 26)).astype(np.float32)
+    r_ref, net = odae.dae_forward(to64(dp), [h.astype(np.float64)], y.astype(np.float64),
+                                  return_net=True)
+    dae = StandardDAE(dp, 11, mma='bf16')
+    yt, ht = torch.from_numpy(y).cuda(), torch.from_numpy(h).cuda()
+    free = host(dae(ht, yt))
+    override = {}
+    for p in range(1, 7):
+        mo = eq_masks(net['pre%d' % p], net['pool%d' % p])
+        full = np.zeros(net['pre%d' % p].shape, dtype=np.float32)
+        full[:, :, :mo.shape[2], :mo.shape[3]] = mo
+        override[p] = (torch.from_numpy(full).cuda(),
+                       torch.ones(net['pool%d' % p].shape, dtype=torch.float32, device='cuda'))
+    score = dae.scores([ht], yt, mask_override=override)
+    forced = host(ops.crop_softmax(score, 224, 224, off=(0, 0)))
+    e = np.abs(forced - r_ref)
+    agree_f = float((forced.argmax(1) == r_ref.argmax(1)).mean())
+    agree = float((free.argmax(1) == r_ref.argmax(1)).mean())
+    print('bf16 DAE forward: teacher-forced max %.2e mean %.2e argmax %.5f | free-running mean %.2e '
+          'argmax %.5f' % (e.max(), e.mean(), agree_f, np.abs(free - r_ref).mean(), agree))
+    assert e.mean() <= 2e-3 and agree_f >= 0.99
+    # own masks: 8-bit operands flip far more near-tied pooling windows than fp32 does (measured
+    # 0.85 agreement after ONE forward); the loop's statistical criterion is the mIoU of north_star
+    assert agree >= 0.8
+
+
+def test_wino_bf16_split_form_exact(ops):
+    """>= 1024 channels: the GEMMs run as their own kernel (256 x 128 or 128 x 128 blocks, fp32
+    products M through the workspace) followed by the output-transform kernel.  Exact on integer
+    data, incl. DePool2D input, skip-add, window and placement."""
+    rng = np.random.default_rng(23)
+    x = ints(rng, 2, 1024, 6, 7, lo=-1, hi=2)
+    Wt, b = ints(rng, 256, 1024, 3, 3, lo=-1, hi=2, mult=4), ints(rng, 256)
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=True)
+    got = host(ops.Conv(Wt, b, pad=1, relu=True, mma='bf16')(dev(x)))
+    assert np.array_equal(got, ref.astype(np.float32))
+    pre = np.maximum(ints(rng, 1, 1024, 9, 9, lo=-1, hi=2), 0)
+    pooled = onn.maxpool2(pre)
+    up = ints(rng, *pooled.shape, lo=-1, hi=2)
+    Wt, b = ints(rng, 128, 1024, 3, 3, lo=-1, hi=2, mult=4), ints(rng, 128)
+    other = ints(rng, 1, 128, 12, 12)
+    full = onn.conv2d(onn.depool_eqmask(up, pre, pooled), Wt, b, pad=1)
+    ref = full[:, :, 1:8, 2:9] + other[:, :, 3:10, 3:10]
+    out = torch.full((1, 128, 10, 11), -9.0, device='cuda')
+    ops.Conv(Wt, b, pad=1, relu=False, mma='bf16')(
+        dev(up), pre=dev(pre), pooled=dev(pooled), add=dev(other), add_off=(3, 3),
+        window=(1, 2, 7, 7), out=out, place=(2, 3), anchor=(1, 0))
+    o = host(out)
+    assert np.array_equal(o[:, :, 2:9, 3:10], ref.astype(np.float32))
+    o[:, :, 2:9, 3:10] = -9.0
+    assert np.all(o == -9.0)
+
+
+@pytest.mark.parametrize('case', [(3, 40, 9, 11, 200, 7), (2, 1030, 5, 4, 130, 1), (4, 1024, 3, 3, 11, 1)])
+def test_gemm_bf16_valid_layers_exact(ops, case):
+    """fc6 (7x7 'valid'), fc7 / score_fr (deep 1x1) as im2col + bf16 GEMM; ragged K / Cout."""
+    B, Cin, H, W, Cout, k = case
+    rng = np.random.default_rng(sum(case))
+    x = ints(rng, B, Cin, H, W, lo=-2, hi=3)
+    Wt, b = ints(rng, Cout, Cin, k, k, lo=-1, hi=2), ints(rng, Cout)
+    ref = onn.conv2d(x, Wt, b, pad=0, relu=True)
+    conv = ops.Conv(Wt, b, pad=0, relu=True, mma='bf16')
+    got = host(conv(dev(x)))
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref.astype(np.float32)), np.abs(got - ref).max()
+    assert conv._W16 is not None                      # took the bf16 GEMM path
