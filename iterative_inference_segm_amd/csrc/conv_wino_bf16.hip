@@ -32,6 +32,7 @@ using namespace iiseg;
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte store, 4-byte aligned
 
 struct WinoBfParams {
     const float* x1;
@@ -54,6 +55,7 @@ struct WinoBfParams {
     int relu;
     int out_ctot, out_c0, out_H, out_W, out_y0, out_x0;
     int n_ttiles, n_mtiles;
+    int debug;               // timing experiments only (IISEG_BF16_DEBUG): 1 no A DMA, 2 no B DMA, 4 no MFMA
 };
 
 constexpr int RSRC_W3 = 0x00027000;
@@ -224,6 +226,167 @@ __global__ __launch_bounds__(256) void wino_input_bf16_kernel(const WinoBfParams
         v[(size_t)xi * xis] = make_uint4(res[xi][0], res[xi][1], res[xi][2], res[xi][3]);
 }
 
+
+// LDS-staged input transform for maps with >= 128 tiles per image (as conv_wino.hip's
+// wino_input_lds_kernel): a workgroup takes NT consecutive tiles of ONE image and the 8 channels of
+// one k8 chunk; per channel it stages the input rows those tiles touch (whole rows of the tile grid:
+// coalesced loads, ~1.3 loads per tile and channel instead of 16; the DePool2D mask is applied per
+// staged element) and every thread reads its 4x4 patch from LDS, transforms it and keeps the 16
+// results; after the 8th channel the 16 chunks are stored.
+constexpr int IBF_E = 12;   // staged elements per thread and channel
+template <bool UNPOOL, int NT>
+__global__ __launch_bounds__(NT) void wino_input_lds_bf16_kernel(const WinoBfParams p, const int chunks) {
+    constexpr int CAP = IBF_E * NT;
+    __shared__ __attribute__((aligned(16))) float Ls[2][CAP];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x - b * chunks;
+    const int ntt = p.nty * p.ntx;
+    const int tl0 = chunk * NT, tl = tl0 + tid;
+    const bool tvalid = tl < ntt;
+    const int row_first = tl0 / p.ntx;
+    const int row_last = min(ntt - 1, tl0 + NT - 1) / p.ntx;
+    const int NR = 2 * (row_last - row_first + 1) + 2, NC = 2 * p.ntx + 2, NE = NR * NC;
+    const int iyb = p.ty0 + 2 * row_first - p.pad, ixb = p.tx0 - p.pad;
+    int goff[IBF_E], qoff[UNPOOL ? IBF_E : 1];
+#pragma unroll
+    for (int i = 0; i < IBF_E; ++i) {
+        const int e = i * NT + tid;
+        const int r = e / NC, c = e - r * NC;
+        const int iy = iyb + r, ix = ixb + c;
+        bool ok = e < NE && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        goff[i] = ok ? iy * p.W + ix : -1;
+        if constexpr (UNPOOL) {
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+            qoff[i] = ok ? (iy >> 1) * p.w2 + (ix >> 1) : -1;
+        }
+    }
+    const int tyl = tl / p.ntx, txl = tl - tyl * p.ntx;
+    const int lbase = 2 * (tyl - row_first) * NC + 2 * txl;
+    const size_t HW = (size_t)p.H * p.W, hw2 = (size_t)p.h2 * p.w2;
+    const int Ctot = p.C1 + p.C2;
+    const int kc = blockIdx.y;
+    float v[IBF_E];
+
+    auto fetch = [&](int c) __attribute__((always_inline)) {
+        if (c >= Ctot) {                       // padded k-tile: zero channel
+#pragma unroll
+            for (int i = 0; i < IBF_E; ++i) v[i] = 0.f;
+            return;
+        }
+        if constexpr (UNPOOL) {
+            const float* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
+            const float* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
+            const float* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
+#pragma unroll
+            for (int i = 0; i < IBF_E; ++i) {
+                float r = 0.f;
+                if (qoff[i] >= 0) {
+                    const float pv = prep[goff[i]], pq = poolp[qoff[i]], uq = upp[qoff[i]];
+                    r = pv == pq ? uq : 0.f;
+                }
+                v[i] = r;
+            }
+        } else {
+            const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
+                                        : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+#pragma unroll
+            for (int i = 0; i < IBF_E; ++i) v[i] = goff[i] >= 0 ? src[goff[i]] : 0.f;
+        }
+    };
+
+    uint32_t res[16][4];
+    float even[16];
+    fetch(kc * 8);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc) {
+        float* L = Ls[cc & 1];
+#pragma unroll
+        for (int i = 0; i < IBF_E; ++i)
+            if (i * NT + tid < NE) L[i * NT + tid] = v[i];
+        if (cc + 1 < 8) fetch(kc * 8 + cc + 1);
+        __syncthreads();
+        float vv[16];
+        if (tvalid) {
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 lo = *reinterpret_cast<const float2*>(L + lbase + i * NC);
+                const float2 hi = *reinterpret_cast<const float2*>(L + lbase + i * NC + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
+            float e[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // B^T d
+                e[0][j] = d[0][j] - d[2][j];
+                e[1][j] = d[1][j] + d[2][j];
+                e[2][j] = d[2][j] - d[1][j];
+                e[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // (B^T d) B
+                vv[i * 4 + 0] = e[i][0] - e[i][2];
+                vv[i * 4 + 1] = e[i][1] + e[i][2];
+                vv[i * 4 + 2] = e[i][2] - e[i][1];
+                vv[i * 4 + 3] = e[i][1] - e[i][3];
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) vv[x] = 0.f;
+        }
+        if (cc & 1) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) res[x][cc >> 1] = pack_bf16(even[x], vv[x]);
+        } else {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) even[x] = vv[x];
+        }
+    }
+    if (tvalid) {
+        const size_t xis = (size_t)(p.Kc >> 3) * p.Tpad;
+        uint4* vo = p.V + (size_t)kc * p.Tpad + (size_t)b * ntt + tl;
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+            vo[(size_t)xi * xis] = make_uint4(res[xi][0], res[xi][1], res[xi][2], res[xi][3]);
+    }
+}
+
+void launch_wino_input_bf16(hipStream_t s, const WinoBfParams& p, bool unpool) {
+    static const int lds = getenv("IISEG_WINO_INPUT_LDS") ? atoi(getenv("IISEG_WINO_INPUT_LDS")) : 1;
+    const int ntt = p.nty * p.ntx;
+    // tiles per workgroup (one image per workgroup): the size that leaves the fewest idle lanes
+    int nt = 0;
+    double best = 0.0;
+    for (int cand = 256; cand >= 128; cand >>= 1) {
+        const int span = (cand - 1 + p.ntx - 1) / p.ntx + 1;
+        const int rows = span < p.nty ? span : p.nty;
+        if ((2 * rows + 2) * (2 * p.ntx + 2) > IBF_E * cand) continue;
+        const double util = (double)ntt / (((ntt + cand - 1) / cand) * cand);
+        if (util > best + 0.02) { best = util; nt = cand; }
+    }
+    if (lds && nt && best >= 0.8) {
+        const int chunks = (ntt + nt - 1) / nt;
+        const dim3 g2(p.B * chunks, p.Kc / 8);
+        if (unpool) {
+            if (nt == 256) hipLaunchKernelGGL((wino_input_lds_bf16_kernel<true, 256>), g2, dim3(256), 0, s, p, chunks);
+            else hipLaunchKernelGGL((wino_input_lds_bf16_kernel<true, 128>), g2, dim3(128), 0, s, p, chunks);
+        } else {
+            if (nt == 256) hipLaunchKernelGGL((wino_input_lds_bf16_kernel<false, 256>), g2, dim3(256), 0, s, p, chunks);
+            else hipLaunchKernelGGL((wino_input_lds_bf16_kernel<false, 128>), g2, dim3(128), 0, s, p, chunks);
+        }
+        return;
+    }
+    const dim3 grid((p.T + 255) / 256, p.Kc / 8), block(256);
+    if (!unpool) {
+        hipLaunchKernelGGL((wino_input_bf16_kernel<false, 0, 0>), grid, block, 0, s, p);
+        return;
+    }
+    const int py = (p.ty0 - p.pad) & 1, px = (p.tx0 - p.pad) & 1;  // patch-origin parity
+    if (py && px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 1>), grid, block, 0, s, p);
+    else if (py) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 0>), grid, block, 0, s, p);
+    else if (px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 0>), grid, block, 0, s, p);
+}
+
 // ---- 2+3. the 16 GEMMs + output transform + epilogue in one kernel --------------------------------
 // As / Bs hold k-tiles of BK channels as BK/8 rows of 16-byte chunks, in an NBUF-deep ring: the
 // bf16 matrix pipe needs only ~256 cycles per k-tile and wave, far less than a global -> LDS
@@ -244,39 +407,64 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
     __shared__ __attribute__((aligned(16))) uint4 As[NBUF][KR][BM];
     __shared__ __attribute__((aligned(16))) uint4 Bs[NBUF][KR][BN];
 
-    int tt, mt;
-    tile_of_block(blockIdx.x, gridDim.x, p.n_ttiles, p.n_mtiles, tt, mt);
-    const int m0 = mt * BM, t0 = tt * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
     const int nkt = p.Kc / BK;
     const int kcr = p.Kc >> 3;                             // chunk rows per transform point
-    const size_t ustride = (size_t)kcr * p.Mpad, vstride = (size_t)kcr * p.Tpad;
-    const int ubytes = kcr * p.Mpad * 16, vbytes = kcr * p.Tpad * 16;
+    // one descriptor per operand over all 16 points (sizes checked < 4 GB by the host)
+    const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U, (int)(16u * 16u * (unsigned)kcr * (unsigned)p.Mpad));
+    const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V, (int)(16u * 16u * (unsigned)kcr * (unsigned)p.Tpad));
 
-    // stage k-tile number S (= xi * nkt + kt) into ring slot BUF (global -> LDS, 16 B per lane)
-#define WBF_STAGE(S, BUF)                                                                          \
+    // PERSISTENT workgroups: the grid is one residency round (a multiple of 8 blocks, or every
+    // tile), and each workgroup walks tiles vb = blockIdx.x, + gridDim.x, ...  All workgroups start
+    // together and every tile costs the same, so the workgroups of an XCD stay in step through the
+    // (xi, k-tile) sequence: a U16 / V16 slab one of them pulls into that XCD's L2 is a hit for the
+    // others.  (Non-persistent, the second and later rounds start out of phase, all 16 points'
+    // slabs are live at once, nothing stays in the 4 MB L2 and every operand byte comes from beyond
+    // it: measured 73 % of wave time parked on vmcnt at ~5 TB/s.)
+    const int ntiles = p.n_ttiles * p.n_mtiles;
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    int tt, mt;
+    tile_of_block(vb, ntiles, p.n_ttiles, p.n_mtiles, tt, mt);
+    const int m0 = mt * BM, t0 = tt * BN;
+
+    // Staging addresses.  The U16 / V16 images are row-major in (xi, chunk row), so k-tile number S
+    // (= xi * nkt + kt) starts at chunk row S * KR of both: the per-thread part of a DMA address
+    // (row inside the k-tile, column inside the block) is loop-invariant and lives in VGPRs, the
+    // k-tile part is ONE scalar byte offset per operand that advances by a constant per stage --
+    // no per-stage vector arithmetic, no division, one buffer descriptor per operand.
+    unsigned avo[APT], bvo[BPT];
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+        const int f = j * NT + tid;
+        avo[j] = 16u * (unsigned)((f / BM) * p.Mpad + m0 + f % BM);
+    }
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+        const int f = j * NT + tid;
+        bvo[j] = 16u * (unsigned)((f / BN) * p.Tpad + t0 + f % BN);
+    }
+    unsigned sa = 0, sb = 0;                   // byte offsets of the next k-tile to stage
+    const unsigned sa_step = 16u * KR * (unsigned)p.Mpad, sb_step = 16u * KR * (unsigned)p.Tpad;
+#define WBF_STAGE(BUF)                                                                             \
     {                                                                                              \
-        const int sxi = (S) / nkt, skt = (S) - sxi * nkt;                                          \
-        const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)sxi * ustride, ubytes);            \
-        const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)sxi * vstride, vbytes);            \
+        if (!(p.debug & 1))                                                                        \
         static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
-            const int f = j * NT + tid;                                                            \
-            const int row = f / BM, col = f % BM;                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 ar, (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + j * NT + wave * 64), \
-                16, (int)(16u * (unsigned)((skt * KR + row) * p.Mpad + m0 + col)), 0, 0, 0);       \
+                16, (int)avo[j], (int)sa, 0, 0);                                                   \
         });                                                                                        \
+        if (!(p.debug & 2))                                                                        \
         static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
-            const int f = j * NT + tid;                                                            \
-            const int row = f / BN, col = f % BN;                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 br, (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + j * NT + wave * 64), \
-                16, (int)(16u * (unsigned)((skt * KR + row) * p.Tpad + t0 + col)), 0, 0, 0);       \
+                16, (int)bvo[j], (int)sb, 0, 0);                                                   \
         });                                                                                        \
+        sa += sa_step;                                                                             \
+        sb += sb_step;                                                                             \
     }
 
     f32x16 acc[TM][TN], Y[4][TM][TN];
@@ -294,7 +482,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
     // prologue: NBUF-1 stages in flight, the first one landed
 #pragma unroll
     for (int q = 0; q < NBUF - 1; ++q)
-        if (q < total) WBF_STAGE(q, q)
+        if (q < total) WBF_STAGE(q)
     if (total >= NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * OPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -318,6 +506,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[(st + 1) & 1][j] = Bs[buf][kr][wn * WTN + j * 32 + l31];
             }
+            if (!(p.debug & 4)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -325,8 +514,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, a[st & 1][i]), __builtin_bit_cast(bf16x8, b[st & 1][j]),
                         acc[i][j], 0, 0, 0);
+            }
             if constexpr (st == 0) {
-                if (more) WBF_STAGE(s + NBUF - 1, sbuf)
+                if (more) WBF_STAGE(sbuf)
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -405,17 +595,28 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_bf16_kernel(con
                 const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Cout) continue;
                 const float bias = p.bias ? p.bias[co] : 0.f;
+                float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (!ok[q]) continue;
-                    float v = Y[q][i][j][r] + bias;
-                    if (ab) v += av[r][q];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    ob[(size_t)co * OPL + (size_t)(q >> 1) * p.out_W + (q & 1)] = v;
+                    v[q] = Y[q][i][j][r] + bias;
+                    if (ab) v[q] += av[r][q];
+                    if (p.relu) v[q] = fmaxf(v[q], 0.f);
+                }
+                // the two pixels of a tile row as ONE 8-byte store (lanes = consecutive tiles: a
+                // half-wave writes 256 contiguous bytes); 4-byte alignment is all gfx950 needs
+                float* o = ob + (size_t)co * OPL;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (ok[2 * a] && ok[2 * a + 1])
+                        *reinterpret_cast<f32x2u*>(o + (size_t)a * p.out_W) = f32x2u{v[2 * a], v[2 * a + 1]};
+                    else if (ok[2 * a]) o[(size_t)a * p.out_W] = v[2 * a];
+                    else if (ok[2 * a + 1]) o[(size_t)a * p.out_W + 1] = v[2 * a + 1];
                 }
             }
         }
     }
+    __syncthreads();   // next tile: the ring is refilled from slot 0
+  }
 }
 
 
@@ -466,24 +667,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_bf16_kernel(const W
     const __amdgpu_buffer_rsrc_t ar = mk_rsrc(p.U + (size_t)xi * kcr * p.Mpad, kcr * p.Mpad * 16);
     const __amdgpu_buffer_rsrc_t br = mk_rsrc(p.V + (size_t)xi * kcr * p.Tpad, kcr * p.Tpad * 16);
 
-#define WBG_STAGE(KT, BUF)                                                                         \
+    // loop-invariant per-thread chunk offsets; the k-tile is one scalar byte offset per operand
+    unsigned avo[APT], bvo[BPT];
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+        const int f = j * NT + tid;
+        avo[j] = 16u * (unsigned)((f / BM) * p.Mpad + m0 + f % BM);
+    }
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+        const int f = j * NT + tid;
+        bvo[j] = 16u * (unsigned)((f / BN) * p.Tpad + t0 + f % BN);
+    }
+    unsigned sa = 0, sb = 0;
+    const unsigned sa_step = 16u * KR * (unsigned)p.Mpad, sb_step = 16u * KR * (unsigned)p.Tpad;
+#define WBG_STAGE(BUF)                                                                             \
     {                                                                                              \
         static_for<0, APT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
-            const int f = j * NT + tid;                                                            \
-            const int row = f / BM, col = f % BM;                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 ar, (__attribute__((address_space(3))) void*)(&As[BUF][0][0] + j * NT + wave * 64), \
-                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
+                16, (int)avo[j], (int)sa, 0, 0);                                                   \
         });                                                                                        \
         static_for<0, BPT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
-            const int f = j * NT + tid;                                                            \
-            const int row = f / BN, col = f % BN;                                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 br, (__attribute__((address_space(3))) void*)(&Bs[BUF][0][0] + j * NT + wave * 64), \
-                16, (int)(16u * (unsigned)(((KT) * KR + row) * p.Tpad + t0 + col)), 0, 0, 0);      \
+                16, (int)bvo[j], (int)sb, 0, 0);                                                   \
         });                                                                                        \
+        sa += sa_step;                                                                             \
+        sb += sb_step;                                                                             \
     }
 
     f32x16 acc[TM][TN];
@@ -496,7 +709,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_bf16_kernel(const W
 
 #pragma unroll
     for (int q = 0; q < NBUF - 1; ++q)
-        if (q < nkt) WBG_STAGE(q, q)
+        if (q < nkt) WBG_STAGE(q)
     if (nkt >= NBUF - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * OPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -528,7 +741,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_bf16_kernel(const W
                         __builtin_bit_cast(bf16x8, a[st & 1][i]), __builtin_bit_cast(bf16x8, b[st & 1][j]),
                         acc[i][j], 0, 0, 0);
             if constexpr (st == 0) {
-                if (more) WBG_STAGE(kt + NBUF - 1, sbuf)
+                if (more) WBG_STAGE(sbuf)
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -572,6 +785,14 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 constexpr int WBF_BK = 64;   // k-tile of the GEMM kernel: channels are padded to it
 
+// grid of a persistent launch: every tile if they all fit one residency round, else one round
+// (256 CUs x workgroups per CU; a multiple of 8 so that a workgroup's tiles stay on "its" XCD run)
+int persistent_grid(int ntiles, int per_cu) {
+    static const int on = getenv("IISEG_BF16_PERSISTENT") ? atoi(getenv("IISEG_BF16_PERSISTENT")) : 1;
+    const int round = 256 * per_cu;
+    return (!on || ntiles <= round) ? ntiles : round;
+}
+
 struct WinoBfGeom {
     int Kc, Mpad, bm, ty0, tx0, nty, ntx, T, Tpad;
     bool fused;   // GEMMs + output transform in one kernel (else: GEMM kernel -> M -> output kernel)
@@ -603,8 +824,9 @@ int wino_bf16_geom(const iiseg_conv_desc* d, WinoBfGeom& g) {
     g.ntx = (d->ox0 + d->OW - g.tx0 + 1) >> 1;
     const int64_t T = (int64_t)d->B * g.nty * g.ntx;
     const int64_t Tpad = (T + 127) / 128 * 128;
-    // buffer descriptors address one xi-slice of U16 / V16 with 32-bit byte offsets
-    if (Tpad * g.Kc * 2 >= (int64_t)1 << 31 || (int64_t)g.Kc * g.Mpad * 2 >= (int64_t)1 << 31)
+    // one buffer descriptor addresses all 16 points of U16 / V16 with 32-bit byte offsets
+    if (16 * Tpad * g.Kc * 2 >= ((int64_t)1 << 32) - (1 << 20) ||
+        (int64_t)16 * g.Kc * g.Mpad * 2 >= ((int64_t)1 << 32) - (1 << 20))
         return IISEG_ERR_UNSUPPORTED;
     g.T = (int)T;
     g.Tpad = (int)Tpad;
@@ -678,6 +900,8 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
     if (add && (d->ay0 < 0 || d->ax0 < 0 || d->ay0 + d->OH > d->AH || d->ax0 + d->OW > d->AW))
         return IISEG_ERR_SHAPE;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    static const int dbg = getenv("IISEG_BF16_DEBUG") ? atoi(getenv("IISEG_BF16_DEBUG")) : 0;
+    p.debug = dbg;
     p.out_ctot = d->out_ctot > 0 ? d->out_ctot : d->Cout;
     p.out_c0 = d->out_ctot > 0 ? d->out_c0 : 0;
     if (p.out_c0 < 0 || p.out_c0 + d->Cout > p.out_ctot) return IISEG_ERR_SHAPE;
@@ -688,18 +912,7 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
     if (p.out_y0 < 0 || p.out_x0 < 0 || p.out_y0 + d->OH > p.out_H || p.out_x0 + d->OW > p.out_W)
         return IISEG_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (stages & IISEG_WINO_INPUT) {
-        const dim3 grid((p.T + 255) / 256, p.Kc / 8), block(256);
-        if (!unpool) {
-            hipLaunchKernelGGL((wino_input_bf16_kernel<false, 0, 0>), grid, block, 0, s, p);
-        } else {
-            const int py = (p.ty0 - p.pad) & 1, px = (p.tx0 - p.pad) & 1;  // patch-origin parity
-            if (py && px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 1>), grid, block, 0, s, p);
-            else if (py) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 0>), grid, block, 0, s, p);
-            else if (px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 1>), grid, block, 0, s, p);
-            else hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 0>), grid, block, 0, s, p);
-        }
-    }
+    if (stages & IISEG_WINO_INPUT) launch_wino_input_bf16(s, p, unpool);
     if ((stages & IISEG_WINO_GEMM) && !g.fused) {
         float* M = (float*)((char*)workspace + (size_t)16 * g.Kc * g.Tpad * 2);
         launch_gemm_bf16(s, p, M, 16);
@@ -711,20 +924,21 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
             p.n_ttiles = g.Tpad / 128;
             p.n_mtiles = g.Mpad / 64;
             hipLaunchKernelGGL((wino_fused_bf16_kernel<64, 128, 1, 4, WBF_BK, 3, 2>),
-                               dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+                               dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 2)), dim3(256), 0, s, p);
             return iiseg_check_launch();
         }
         p.n_mtiles = g.Mpad / 128;
         // few tiles: 4-wave workgroups of 128 x 64 fill the CUs better than 8-wave 128 x 128 ones
         const int w128 = (g.Tpad / 128) * p.n_mtiles;
-        if (w128 < 2 * 256) {
+        static const int force = getenv("IISEG_BF16_FUSED_TILE") ? atoi(getenv("IISEG_BF16_FUSED_TILE")) : 0;
+        if (force ? force == 64 : w128 < 2 * 256) {
             p.n_ttiles = g.Tpad / 64;
             hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, WBF_BK, 3, 2>),
-                               dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+                               dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 2)), dim3(256), 0, s, p);
         } else {
             p.n_ttiles = g.Tpad / 128;
             hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, WBF_BK, 3, 2>),
-                               dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
+                               dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 1)), dim3(512), 0, s, p);
         }
     }
     return iiseg_check_launch();

@@ -1,0 +1,21 @@
+"""Runs ONE conv layer a few times (for rocprofv3 --pmc / --kernel-trace on a single kernel).
+Usage: python3 scripts/pmc_layer.py <cin> <cout> <H> <mma f32|bf16> [batch] [window]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from iterative_inference_segm_amd import ops
+cin, cout, H = (int(a) for a in sys.argv[1:4])
+mma = sys.argv[4]
+B = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+win = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+g = torch.Generator(device='cuda').manual_seed(0)
+W = torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * (2.0 / (cin * 9)) ** 0.5
+b = torch.randn(cout, device='cuda', generator=g) * 0.1
+x = torch.rand(B, cin, H, H, device='cuda', generator=g)
+conv = ops.Conv(W, b, pad=1, relu=True, mma=mma)
+kw = dict(window=((H - win) // 2, (H - win) // 2, win, win)) if win else {}
+out = conv(x, **kw)
+for _ in range(3):
+    conv(x, out=out, **kw)
+torch.cuda.synchronize()
+print('done')
