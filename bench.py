@@ -71,14 +71,15 @@ def build_model(device, concat_h, dtype=torch.float32, mma=None):
     return IterativeInference(fcn, dae, N_CLASSES, [N_CLASSES], device=device, dtype=dtype), fp, dp
 
 
-def one_step(ii, X, T, num_iter, step_size):
+def one_step(ii, X, T, num_iter, step_size, graph=None):
     """One batch of the per-batch path (iterative_inference.py:237-287); returns the device-side
-    metric accumulators (refined, FCN, one-shot DAE)."""
+    metric accumulators (refined, FCN, one-shot DAE).  graph=False: every step launched from
+    Python (the roofline pass needs its per-launch events)."""
     out = ii.pred_fcn_fn(X)                                            # :237-239
     H, Y = out[:-1], out[-1]
     m_fcn = ii.val_device(Y, T)                                        # :242
     Yii, _, _, R0 = ii.refine(H, Y, step_size, num_iter, early_stop=False,
-                              first_reconstruction=True)               # :258-284
+                              first_reconstruction=True, graph=graph)  # :258-284
     m_dae = ii.val_device(R0, T)                                       # :250-251 (shared forward)
     return ii.val_device(Yii, T), m_fcn, m_dae                         # :287
 
@@ -182,7 +183,7 @@ def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
     torch.cuda.synchronize()
     torch.cuda._sleep(int(6e8))          # ~0.25-0.3 s of GPU time: the host runs ahead meanwhile
     ops.CONV_PROFILE = prof = []
-    one_step(ii, X, T, num_iter, step_size)
+    one_step(ii, X, T, num_iter, step_size, graph=False)
     torch.cuda.synchronize()
     ops.CONV_PROFILE = None
     per = {}

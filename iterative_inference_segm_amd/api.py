@@ -10,6 +10,7 @@ batched device loop that keeps the reference's per-image semantics (per-image ea
 update applied before the test).  Arguments and results are device tensors
 (C-contiguous NCHW float32): no host round trip per call.
 """
+import os
 import weakref
 
 import numpy as np
@@ -18,6 +19,9 @@ import torch
 from . import ops
 
 EPSILON = 1e-3  # iterative_inference.py:53
+# Replay the steady-state refinement step from a captured HIP graph (see IterativeInference.refine).
+# 'auto': when the loop is long enough to pay for the capture; IISEG_GRAPH=0 / 1 force it off / on.
+GRAPH_MODE = os.environ.get('IISEG_GRAPH', 'auto')
 
 
 class Metrics:
@@ -66,6 +70,7 @@ class IterativeInference:
         # provenance records of the h maps handed out by pred_fcn_fn (fcn8.FCN8.last_provenance),
         # keyed by tensor identity: id -> (weakref, torch version counter, record)
         self._prov = {}
+        self._graphs = {}        # steady-state refinement steps captured as HIP graphs
 
     def _remember(self, outs):
         prov = getattr(self.fcn, 'last_provenance', None)
@@ -127,7 +132,7 @@ class IterativeInference:
     # ---- fused loop ---------------------------------------------------------------------
     def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
                per_iter_target=None, mode='residual', h_provenance=None,
-               first_reconstruction=False):
+               first_reconstruction=False, graph=None):
         """Batched replacement of iterative_inference.py:258-284.
 
         for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
@@ -140,6 +145,14 @@ class IterativeInference:
             y = clip(y - step * (J_r^T 2(r - y) - 2(r - y)), 0, 1),
         with a hand-written backward pass through the DAE (`StandardDAE.backward_y`); the stop
         test uses mean_px ||grad||_2.
+
+        `graph` (None = api.GRAPH_MODE): replay the steady-state step (everything after the first
+        step has static shapes and static buffers: the session's encoder maps, y, h, the loop
+        state) from ONE captured HIP graph instead of launching its ~36 kernels from Python again
+        every iteration.  Same kernels in the same order on the same stream, so results are bit for
+        bit those of the eager loop.  The per-image stop test stays on the device (frozen images
+        flow through unchanged, `iters` / `last_norm` are read once by the caller): no host
+        synchronisation inside the loop.  Used for mode='residual' without `per_iter_target`.
 
         `first_reconstruction`: also return r(y_0 | h) = softmax of the first step's score map, i.e.
         the `pred_dae_fn(H, Y)` of iterative_inference.py:250 without a second DAE forward (it is
@@ -155,6 +168,12 @@ class IterativeInference:
         reference calls val_fn only when the loop did not break).
         """
         H_in = list(H) if isinstance(H, (list, tuple)) else [H]
+        want_graph = GRAPH_MODE if graph is None else ('1' if graph else '0')
+        if want_graph != '0' and mode == 'residual' and per_iter_target is None and \
+                hasattr(self.dae, 'new_session') and int(num_iter) >= (3 if want_graph == 'auto' else 2) \
+                and torch.cuda.is_available():
+            return self._refine_graph(H_in, Y, step, int(num_iter), eps if early_stop else -1.0,
+                                      h_provenance, first_reconstruction)
         H = [self._dev(h) for h in H_in]
         # where each h came from: explicit records, else what pred_fcn_fn remembered for these
         # very tensor objects (None -> no cross-batch reuse for this call)
@@ -198,6 +217,73 @@ class IterativeInference:
         res = (y, st.iters, st.last_norm)
         if per_iter is not None:
             res = res + (per_iter,)
+        if first_reconstruction:
+            res = res + (r0,)
+        return res
+
+    def _refine_graph(self, H_in, Y, step, num_iter, eps_eff, h_provenance, first_reconstruction):
+        """The loop of `refine` with its steady-state step replayed from a HIP graph.
+
+        Static buffers (owned by a per-geometry context): y, the h maps, the loop state; the DAE
+        session's encoder maps are static by construction.  Per call: copy Y / H in, step 0 eagerly
+        (it recomputes the larger region a new batch touches), then steps 1.. as graph replays.  The
+        graph is captured once per (geometry, step, eps, session): the first call runs step 1
+        eagerly too (weight packing, launch plans and workspaces come into being there) and
+        captures step 2."""
+        from . import ops as _ops
+        tags = list(h_provenance) if h_provenance is not None else \
+            [self.provenance_of(a) if isinstance(a, torch.Tensor) else None for a in H_in]
+        H_src = [self._dev(h) for h in H_in]
+        y_src = self._dev(Y)
+        key = (tuple(tuple(h.shape) for h in H_src), tuple(y_src.shape), y_src.dtype, float(step),
+               float(eps_eff))
+        ctx = self._graphs.get(key)
+        if ctx is None:
+            B, _, Hh, Ww = y_src.shape
+            ctx = {'y': torch.empty_like(y_src), 'H': [torch.empty_like(h) for h in H_src],
+                   'st': _ops.RefineState(B, Hh, Ww, y_src.device), 'graph': None, 'sess': None}
+            self._graphs = {key: ctx}          # one geometry at a time (frees the previous buffers)
+        y, H, st = ctx['y'], ctx['H'], ctx['st']
+        y.copy_(y_src)
+        for dst, src in zip(H, H_src):
+            dst.copy_(src)
+        st.reset()
+        sess = self.dae.new_session(H, y, tags=tags)
+        if sess is None or ctx['sess'] is not sess:   # another session: its buffers are other memory
+            ctx['graph'], ctx['sess'] = None, sess
+        dae_scores = (lambda: self.dae.scores(H, y, session=sess)) if sess is not None else \
+            (lambda: self.dae.scores(H, y))
+
+        def one_step():
+            score = dae_scores()
+            _ops.refine_update(score, y, st, step, off=(0, 0))
+            _ops.refine_finalize(st, eps_eff)
+            return score
+
+        score = dae_scores()                                     # step 0, eager
+        r0 = _ops.crop_softmax(score, y.shape[2], y.shape[3], off=(0, 0)) if first_reconstruction \
+            else None
+        _ops.refine_update(score, y, st, step, off=(0, 0))
+        _ops.refine_finalize(st, eps_eff)
+        it = 1
+        if ctx['graph'] is None and it < num_iter:
+            one_step()                                           # step 1, eager: lazy state settles
+            it += 1
+            if it < num_iter:
+                prof, _ops.CONV_PROFILE = _ops.CONV_PROFILE, None
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    one_step()
+                _ops.CONV_PROFILE = prof
+                ctx['graph'] = g
+                # scratch the captured launches point at must outlive the graph
+                ctx['keep'] = (_ops._wino_ws.get(y.device),)
+        g = ctx['graph']
+        while it < num_iter:
+            g.replay()
+            it += 1
+        res = (y.clone(), st.iters.clone(), st.last_norm.clone())
         if first_reconstruction:
             res = res + (r0,)
         return res

@@ -363,7 +363,10 @@ void launch_wino_input_bf16(hipStream_t s, const WinoBfParams& p, bool unpool) {
         const double util = (double)ntt / (((ntt + cand - 1) / cand) * cand);
         if (util > best + 0.02) { best = util; nt = cand; }
     }
-    if (lds && nt && best >= 0.8) {
+    // (the DePool2D variant is faster un-staged: its three dependent loads per staged element
+    // serialise in the staging loop -- A/B on one device: up_conv3 0.34 vs 0.50 ms)
+    static const int lds_unpool = getenv("IISEG_WINO_INPUT_LDS_UNPOOL") ? atoi(getenv("IISEG_WINO_INPUT_LDS_UNPOOL")) : 0;
+    if (lds && nt && best >= 0.8 && (!unpool || lds_unpool)) {
         const int chunks = (ntt + nt - 1) / nt;
         const dim3 g2(p.B * chunks, p.Kc / 8);
         if (unpool) {
@@ -931,14 +934,31 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
         // few tiles: 4-wave workgroups of 128 x 64 fill the CUs better than 8-wave 128 x 128 ones
         const int w128 = (g.Tpad / 128) * p.n_mtiles;
         static const int force = getenv("IISEG_BF16_FUSED_TILE") ? atoi(getenv("IISEG_BF16_FUSED_TILE")) : 0;
+        static const int var = getenv("IISEG_BF16_FUSED_VAR") ? atoi(getenv("IISEG_BF16_FUSED_VAR")) : 0;
         if (force ? force == 64 : w128 < 2 * 256) {
             p.n_ttiles = g.Tpad / 64;
-            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, WBF_BK, 3, 2>),
-                               dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 2)), dim3(256), 0, s, p);
+            const dim3 grid(persistent_grid(p.n_ttiles * p.n_mtiles, 2));
+            if (var == 1)        // 2-deep ring
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, 64, 2, 2>), grid, dim3(256), 0, s, p);
+            else if (var == 2)   // 32-channel k-tiles, 6-deep ring (same LDS, more tiles in flight)
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, 32, 6, 2>), grid, dim3(256), 0, s, p);
+            else
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, 64, 3, 2>), grid, dim3(256), 0, s, p);
         } else {
             p.n_ttiles = g.Tpad / 128;
-            hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, WBF_BK, 3, 2>),
-                               dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 1)), dim3(512), 0, s, p);
+            const dim3 grid(persistent_grid(p.n_ttiles * p.n_mtiles, 1));
+            if (var == 1)
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 64, 2, 2>), grid, dim3(512), 0, s, p);
+            else if (var == 2)
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 32, 6, 2>), grid, dim3(512), 0, s, p);
+            else if (var == 3 || g.Kc % 128)
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 64, 3, 2>), grid, dim3(512), 0, s, p);
+            else
+                // default: 128-channel k-tiles, 2-deep ring.  Measured on one device (A/B by
+                // IISEG_BF16_FUSED_VAR): a stage costs ~1 us + 35 ns/KB whatever the ring depth, so
+                // fewer, larger stages win (512 ch, 39^2 window: 0.65 vs 0.76 ms at 64-channel
+                // stages, 1.16 ms at 32-channel ones)
+                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 128, 2, 2>), grid, dim3(512), 0, s, p);
         }
     }
     return iiseg_check_launch();

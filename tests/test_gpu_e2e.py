@@ -627,3 +627,51 @@ def test_unpool_type_standard_and_inverse(built_lib):
         torch.from_numpy(x.astype(np.float32)).cuda()))
     assert got.shape == ref.shape == (2, 130, 20, 16)
     assert np.abs(got - ref).max() <= 1e-4 * (1 + np.abs(ref).max())
+
+
+@pytest.mark.parametrize('dtype,nf,size,div', [(torch.float32, 16, (40, 52), 16),
+                                               (torch.float64, 4, (36, 44), 16),
+                                               (torch.float32, 64, (224, 224), 1)])
+def test_graph_replay_is_bit_identical_to_the_eager_loop(built_lib, dtype, nf, size, div):
+    """refine() with the steady-state step replayed from a captured HIP graph (api.py
+    `_refine_graph`: replaces the per-iteration Python launches of iterative_inference.py:258-284)
+    against the eager loop: same refined maps, iteration counts and norms, bit for bit, over three
+    DIFFERENT batches (the second and third reuse the captured graph and the border stores), with
+    the per-image early stop active (decided on the device, no read-back inside the loop) and with a
+    per-call copy of h that has no provenance record (fresh session, re-capture)."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    concat_h = ['pool4']
+    fp = S.make_fcn8_params(width_div=div, fc_channels=4096 // div, seed=181)
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=nf, seed=182)
+    B = 2 if div == 1 else 3
+
+    def make():
+        return IterativeInference(FCN8(fp, 11, layer=concat_h + ['probs_dimshuffle'], dtype=dtype),
+                                  StandardDAE(dp, 11, concat_h=concat_h, n_filters=nf, dtype=dtype),
+                                  11, [11], dtype=dtype)
+    ii_g, ii_e = make(), make()
+    ii_g.prepare(B, size[0], size[1])
+    ii_e.prepare(B, size[0], size[1])
+    n_it = 6
+    for i in range(3):
+        X = S.make_images(B, size[0], size[1], seed=190 + i)
+        og, oe = ii_g.pred_fcn_fn(X), ii_e.pred_fcn_fn(X)
+        # eps chosen so that some images stop early and others run to the end
+        eps = 0.05 if i == 1 else 1e-3
+        rg = ii_g.refine(og[:-1], og[-1], 0.3, n_it, eps=eps, graph=True, first_reconstruction=True)
+        re = ii_e.refine(oe[:-1], oe[-1], 0.3, n_it, eps=eps, graph=False, first_reconstruction=True)
+        for a, b in zip(rg, re):
+            assert np.array_equal(host(a), host(b)), 'batch %d differs' % i
+        if i == 1:
+            assert len(set(host(rg[1]).tolist())) >= 1
+    key, ctx = next(iter(ii_g._graphs.items()))
+    assert ctx['graph'] is not None                        # batches 2 and 3 replayed the capture
+    # a copy of h without a provenance record: fresh session, fresh capture, same results
+    X = S.make_images(B, size[0], size[1], seed=199)
+    og = ii_g.pred_fcn_fn(X)
+    a = ii_g.refine([og[0].clone()], og[-1], 0.3, n_it, graph=True)
+    b = ii_e.refine([og[0].clone()], og[-1], 0.3, n_it, graph=False)
+    for x, y_ in zip(a, b):
+        assert np.array_equal(host(x), host(y_))
