@@ -26,6 +26,8 @@ using namespace iiseg;
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access, 4-byte aligned
 
 constexpr int RSRC_W3 = 0x00027000;
 constexpr unsigned OOB = 0x80000000u;
@@ -73,10 +75,15 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     constexpr int WPT = (WCH + 255) / 256;
     static_assert(WM * WN == 4 && TH % WN == 0 && BM % (WM * 32) == 0, "tile config");
 
-    __shared__ __attribute__((aligned(16))) uint4 Ws[2][WCH];     // [tap][h][BM] chunks
-    // (single patch buffer: 47.7 KB per workgroup at BM = 64, i.e. three workgroups per CU -- the
-    // kernel is bound by memory latency, occupancy is worth more than skipping one barrier)
-    __shared__ __attribute__((aligned(16))) uint4 Ps[1][NCHK];    // [h][PH][PW] chunks
+    // ONE LDS array (a second __shared__ object can make hipcc drain the DMA queue early), carved
+    // into the weight ring Ws[2][WCH] ([tap][h][BM] chunks), the single patch buffer Ps[NCHK]
+    // ([h][PH][PW] chunks; 47.7 KB per workgroup at BM = 64: three workgroups per CU) and, in the
+    // epilogue, the output staging tile Cs[32][TH][32] floats over the same bytes.
+    constexpr int CSCH = 32 * TH * 32 / 4;            // chunks of the staging tile (32 KB at TH = 8)
+    constexpr int SMCH = (2 * WCH + NCHK) > CSCH ? (2 * WCH + NCHK) : CSCH;
+    __shared__ __attribute__((aligned(16))) uint4 smem[SMCH];
+    uint4 (*Ws)[WCH] = reinterpret_cast<uint4 (*)[WCH]>(smem);
+    uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + 2 * WCH);
 
     int pt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
-                const bool cok = ch0[i] + j < crem;                                                \
+                const bool cok = ch0[i] + j < crem && !(p.debug_nogather & 2);                     \
                 const unsigned so = (unsigned)((cb + ch0[i] + j) * HW) * 4u;                       \
                 xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
                 if constexpr (UNPOOL) {                                                            \
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         constexpr int j = decltype(J)::value;                                                      \
         const int f = j * 256 + tid;                                                               \
         const int row = f / BM, col = f % BM;                                                      \
-        if ((j + 1) * 256 <= WCH || f < WCH)                                                       \
+        if (!(p.debug_nogather & 1) && ((j + 1) * 256 <= WCH || f < WCH))                          \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 wrsrc, (__attribute__((address_space(3))) void*)(&Ws[BUF][0] + j * 256 + wave * 64), \
                 16, (int)(16u * (unsigned)(((KT) * 18 + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             for (int i = 0; i < TM; ++i) a[i] = Ws[buf][(tap * 2 + lh) * BM + wm * WTM + i * 32 + l31];
 #pragma unroll
             for (int j = 0; j < TN; ++j) bq[j] = Ps[0][(lh * PH + lrow + j + ky) * PW + l31 + kx];
+            if (!(p.debug_nogather & 4)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bq[j]), acc[i][j],
                         0, 0, 0);
+            }
         });
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
@@ -224,78 +233,87 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
 #undef HBF_LOAD_W
 
     // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store ---------------------------
+    // The MFMA C/D layout gives a lane one pixel of 16 different channels: stored as it stands,
+    // every store instruction writes two 128-byte pieces of two planes with 4 bytes per lane, and
+    // measured (ablation on one device) those stores were 54 % of this kernel's time.  So the tile
+    // takes one trip through LDS, 32 channels at a time: Cs[co][row][x] <- acc (conflict-free: lanes
+    // are consecutive x), then every thread moves 16-byte pieces (4 consecutive pixels of a row):
+    // 8 lanes cover a 32-pixel row of one plane, skip-add values come in as 16-byte loads, 4x fewer
+    // store instructions, whole 128-byte lines wherever the row start allows.
     // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh
-    const int wx = wx0 + l31;
+    static_assert(WM == 1, "the staging tile holds all rows of one 32-channel block");
+    float* Cs = reinterpret_cast<float*>(smem);
     const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
-    if (p.pool) {
-        // fused 2x2 max-pool: a wave owns the row pairs (2m, 2m+1) of its rows (window origin and
-        // RW are even), the column pair is the neighbouring lane.  No lane leaves early here: the
-        // cross-lane max needs every lane; stores are predicated.
-        if constexpr (TN % 2 == 0) {
-            const size_t PPL = (size_t)p.pool_H * p.pool_W;
+    if ((p.debug_nogather & 8) && acc[0][0][0] != 12345.f) return;
+    const bool pooling = p.pool != nullptr;
 #pragma unroll
-            for (int j = 0; j < TN; j += 2) {
-                const int wy = wy0 + wn * RW + j;
-                const bool ok0 = wy < p.OH && wx < p.OW, ok1 = wy + 1 < p.OH && wx < p.OW;
-                float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
-                              (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-                const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
-                const bool okp = ok1 && wx + 1 < p.OW && !(l31 & 1) && py < p.pool_H && px < p.pool_W;
-                float* poolp = p.pool + (size_t)b * p.Cout * PPL + (size_t)py * p.pool_W + px;
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();                       // previous users of these LDS bytes are done
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const float bias = p.bias ? p.bias[min(co, p.Cout - 1)] : 0.f;
-                        float v0 = acc[i][j][r] + bias, v1 = acc[i][j + 1][r] + bias;
-                        if (p.relu) {
-                            v0 = fmaxf(v0, 0.f);
-                            v1 = fmaxf(v1, 0.f);
-                        }
-                        const bool cv = co < p.Cout;
-                        if (cv && ok0) outp[(size_t)co * OPL] = v0;
-                        if (cv && ok1) outp[(size_t)co * OPL + p.out_W] = v1;
-                        float m = fmaxf(v0, v1);
-                        m = fmaxf(m, __shfl_xor(m, 1));
-                        if (cv && okp) poolp[(size_t)co * PPL] = m;
-                    }
-            }
-        }
-        return;
-    }
-    if (wx >= p.OW) return;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int wy = wy0 + wn * RW + j;
-        if (wy >= p.OH) continue;
-        float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
-                      (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-        // skip-add values first, all loads in flight together (channel index clamped), then the
-        // stores: out and add may alias as far as the compiler knows
-        float addv[TM][16];
-        if (p.add) {
-            const float* addp = p.add + (size_t)b * p.Cout * APL + (size_t)(p.ay0 + wy) * p.AW +
-                                p.ax0 + wx;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    addv[i][r] = addp[(size_t)min(co, p.Cout - 1) * APL];
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = m0 + i * 32 + cl;
                 float v = acc[i][j][r];
                 if (p.bias) v += p.bias[min(co, p.Cout - 1)];
-                if (p.add) v += addv[i][r];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (co < p.Cout) outp[(size_t)co * OPL] = v;
+                // (with a skip-add the ReLU comes after the sum: applied by the store pass)
+                if (p.relu && !p.add) v = fmaxf(v, 0.f);
+                Cs[(cl * TH + lrow + j) * 32 + l31] = v;
             }
+        __syncthreads();
+        // 32 channels x TH rows x 8 pieces of 4 pixels
+        constexpr int NPC = 32 * TH * 8;
+#pragma unroll
+        for (int k = 0; k < NPC / 256; ++k) {
+            const int idx = k * 256 + tid;
+            const int cl = idx / (TH * 8), rem = idx - cl * (TH * 8);
+            const int row = rem >> 3, x4 = (rem & 7) * 4;
+            const int co = m0 + i * 32 + cl;
+            const int wy = wy0 + row, wx = wx0 + x4;
+            if (co >= p.Cout || wy >= p.OH || wx >= p.OW) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (cl * TH + row) * 32 + x4);
+            float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0 + co) * OPL +
+                          (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+            const int nv = min(4, p.OW - wx);
+            if (p.add) {
+                const float* addp = p.add + ((size_t)b * p.Cout + co) * APL +
+                                    (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx;
+                if (nv == 4) {
+                    const f32x4u a4 = *reinterpret_cast<const f32x4u*>(addp);
+                    v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3];
+                } else {
+                    for (int e = 0; e < nv; ++e) v[e] += addp[e];
+                }
+                if (p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                }
+            }
+            if (nv == 4) *reinterpret_cast<f32x4u*>(outp) = f32x4u{v[0], v[1], v[2], v[3]};
+            else for (int e = 0; e < nv; ++e) outp[e] = v[e];
+        }
+        if (pooling) {
+            // fused 2x2 max-pool of this 32-channel block from the staged tile: window origin and TH
+            // are even, so the pairs (2m, 2m+1) of rows / columns are whole inside the tile; a
+            // trailing unpaired row / column of the map has no pooling window (ignore_border)
+            const size_t PPL = (size_t)p.pool_H * p.pool_W;
+            constexpr int NPP = 32 * (TH / 2) * 16;
+#pragma unroll
+            for (int k = 0; k < NPP / 256; ++k) {
+                const int idx = k * 256 + tid;
+                const int cl = idx / ((TH / 2) * 16), rem = idx - cl * ((TH / 2) * 16);
+                const int prow = rem >> 4, pcol = rem & 15;
+                const int co = m0 + i * 32 + cl;
+                const int wy = wy0 + 2 * prow, wx = wx0 + 2 * pcol;
+                if (co >= p.Cout || wy + 1 >= p.OH || wx + 1 >= p.OW) continue;
+                const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
+                if (py >= p.pool_H || px >= p.pool_W) continue;
+                const float* c0 = Cs + (cl * TH + 2 * prow) * 32 + 2 * pcol;
+                const float m = fmaxf(fmaxf(c0[0], c0[1]), fmaxf(c0[32], c0[33]));
+                p.pool[((size_t)b * p.Cout + co) * PPL + (size_t)py * p.pool_W + px] = m;
+            }
+        }
     }
 }
 
@@ -413,6 +431,8 @@ extern "C" int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, cons
     p.out_x0 = d->out_H ? d->out_x0 : 0;
     p.P = d->B * d->OH * d->OW;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    static const int dbg = getenv("IISEG_BF16_DEBUG") ? atoi(getenv("IISEG_BF16_DEBUG")) : 0;
+    p.debug_nogather = dbg;
     hipStream_t s = (hipStream_t)stream;
     if (bm == 64) return launch_halo_bf16<64, 8, 1, 4>(s, p, unpool);
     return launch_halo_bf16<32, 8, 1, 4>(s, p, unpool);

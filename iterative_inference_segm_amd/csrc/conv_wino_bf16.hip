@@ -277,15 +277,19 @@ __global__ __launch_bounds__(NT) void wino_input_lds_bf16_kernel(const WinoBfPar
             const float* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
             const float* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
             const float* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
+            // all three loads of every staged element unconditionally (offsets of elements outside
+            // the 2h x 2w region clamped to 0 and masked afterwards): one batch in flight instead
+            // of a dependent branch per element
+            float pv[IBF_E], pq[IBF_E], uq[IBF_E];
 #pragma unroll
             for (int i = 0; i < IBF_E; ++i) {
-                float r = 0.f;
-                if (qoff[i] >= 0) {
-                    const float pv = prep[goff[i]], pq = poolp[qoff[i]], uq = upp[qoff[i]];
-                    r = pv == pq ? uq : 0.f;
-                }
-                v[i] = r;
+                const int go = qoff[i] >= 0 ? goff[i] : 0, qo = qoff[i] >= 0 ? qoff[i] : 0;
+                pv[i] = prep[go];
+                pq[i] = poolp[qo];
+                uq[i] = upp[qo];
             }
+#pragma unroll
+            for (int i = 0; i < IBF_E; ++i) v[i] = (qoff[i] >= 0 && pv[i] == pq[i]) ? uq[i] : 0.f;
         } else {
             const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
                                         : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
@@ -363,9 +367,9 @@ void launch_wino_input_bf16(hipStream_t s, const WinoBfParams& p, bool unpool) {
         const double util = (double)ntt / (((ntt + cand - 1) / cand) * cand);
         if (util > best + 0.02) { best = util; nt = cand; }
     }
-    // (the DePool2D variant is faster un-staged: its three dependent loads per staged element
-    // serialise in the staging loop -- A/B on one device: up_conv3 0.34 vs 0.50 ms)
-    static const int lds_unpool = getenv("IISEG_WINO_INPUT_LDS_UNPOOL") ? atoi(getenv("IISEG_WINO_INPUT_LDS_UNPOOL")) : 0;
+    // (A/B on one device, DePool2D variant with its three loads per staged element issued as one
+    // unconditional batch: up_conv3 0.24 ms staged vs 0.34 ms un-staged)
+    static const int lds_unpool = getenv("IISEG_WINO_INPUT_LDS_UNPOOL") ? atoi(getenv("IISEG_WINO_INPUT_LDS_UNPOOL")) : 1;
     if (lds && nt && best >= 0.8 && (!unpool || lds_unpool)) {
         const int chunks = (ntt + nt - 1) / nt;
         const dim3 g2(p.B * chunks, p.Kc / 8);
