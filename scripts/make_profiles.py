@@ -30,10 +30,11 @@ def find(d, pat):
     return f[0]
 
 
-def stats(d, out, steady=False):
-    """steady=True drops the first batch of the run (every dispatch up to the second
-    confusion_kernel = the end of batch 1): that batch computes the weights-only borders in full and
-    packs the weights, so it is not what bench.py's timed steps (and its roofline leg) run."""
+def stats(d, out, steady=False, nconf=3):
+    """steady=True drops the warm-up batch of the run (every dispatch up to the `nconf`-th
+    confusion_kernel = the end of the first batch; a bench step calls val_fn three times since round
+    2, twice in round 1) together with the load-time border folding and the weight packing in front
+    of it, so what is left is what bench.py's timed steps (and its roofline pass) run."""
     rows = sorted(csv.DictReader(open(find(d, 'kernel_trace.csv'))),
                   key=lambda r: int(r['Start_Timestamp']))
     if steady:
@@ -41,7 +42,7 @@ def stats(d, out, steady=False):
         for i, r in enumerate(rows):
             if 'confusion_kernel' in r['Kernel_Name']:
                 seen += 1
-                if seen == 2:
+                if seen == nconf:
                     rows = rows[i + 1:]
                     break
     per = collections.OrderedDict()
@@ -101,6 +102,6 @@ if __name__ == '__main__':
     if sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == 'steady':
-        stats(sys.argv[2], sys.argv[3], steady=True)
+        stats(sys.argv[2], sys.argv[3], steady=True, nconf=int(sys.argv[4]) if len(sys.argv) > 4 else 3)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)

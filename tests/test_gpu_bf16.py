@@ -280,3 +280,76 @@ def test_gemm_bf16_valid_layers_exact(ops, case):
     assert got.shape == ref.shape
     assert np.array_equal(got, ref.astype(np.float32)), np.abs(got - ref).max()
     assert conv._W16 is not None                      # took the bf16 GEMM path
+
+
+def test_bf16_mode_statistical_parity_64_images(built_lib):
+    """Mode (i) of the 16-bit path on BASELINE configs[1] (FCN-8 + 64-filter DAE, 224x224, 10 steps)
+    against the float64 path (= the reference's CPU numerics) over 64 images -- north_star's
+    criterion for reduced precision: mIoU within +-0.05 of the reference (mIoU against the synthetic
+    labels is a consistency metric: weights are random); plus the agreement of the FCN-8 output,
+    where no feedback loop amplifies the operand rounding."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference, Metrics
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, dp = S.make_fcn8_params(), S.make_dae_params()
+
+    def make(dtype, mma=None):
+        return IterativeInference(
+            FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=dtype, mma=mma),
+            StandardDAE(dp, 11, dtype=dtype, mma=mma), 11, [11], dtype=dtype)
+    ii16, ii64 = make(torch.float32, 'bf16'), make(torch.float64)
+    assert ii16.dae.enc['conv3_1'].wino_bf16 and ii16.dae.enc['conv2_1'].halo_bf16
+    cm = {k: np.zeros((11, 12)) for k in ('bf16', 'f64')}
+    agree_fcn, agree_ii = [], []
+    for i in range(4):                                   # 4 batches of 16 = 64 images
+        X = S.make_images(16, 224, 224, seed=500 + i)
+        T = S.make_labels(16, 224, 224, seed=600 + i)
+        res = {}
+        for k, ii in (('bf16', ii16), ('f64', ii64)):
+            out = ii.pred_fcn_fn(X)
+            Yii = ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)[0]
+            m = ii.val_device(Yii, T)
+            cm[k] += m.cm.cpu().numpy().reshape(11, 12)
+            res[k] = (host(out[-1]), host(Yii))
+        agree_fcn.append(float((res['bf16'][0].argmax(1) == res['f64'][0].argmax(1)).mean()))
+        agree_ii.append(float((res['bf16'][1].argmax(1) == res['f64'][1].argmax(1)).mean()))
+    miou = {}
+    for k in cm:
+        c = cm[k][:, :11]
+        tp = np.diag(c)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            miou[k] = float(np.nanmean(tp / (c.sum(1) + c.sum(0) - tp)))
+    print('bf16 vs float64 over 64 images: mIoU %.5f vs %.5f, FCN argmax agreement %.4f, refined '
+          '(10 chaotic steps) %.4f' % (miou['bf16'], miou['f64'], np.mean(agree_fcn), np.mean(agree_ii)))
+    assert abs(miou['bf16'] - miou['f64']) <= 0.05
+    assert np.mean(agree_fcn) >= 0.97
+
+
+def test_config3_densenet_runs_in_bf16(built_lib):
+    """BASELINE configs[2] as written ("bf16 with fp32 accumulate"): FC-DenseNet103 + standard DAE
+    (padding 0, h = pool4 464 ch), 224x224, batch 32, 10 steps with bf16 MFMA operands.  The dense
+    blocks' 3x3 growth-rate-16 convs run on the bf16 halo kernel, the DAE's wide layers on the bf16
+    Winograd kernels.  Statistical check against the fp32 path on the segmentation output."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    params = S.make_densenet_params(layer_plan())
+    dp = S.make_dae_params(h_channels=(464,))
+
+    def make(mma):
+        return IterativeInference(FCDenseNet(params, 11, layer=['pool4'], mma=mma),
+                                  StandardDAE(dp, 11, padding=0, mma=mma), 11, [11])
+    ii16, ii32 = make('bf16'), make(None)
+    n16 = sum(1 for e in ii16.fcn.layers if e['conv'].halo_bf16)
+    assert n16 >= 90                                       # the 3x3 BN_ReLU_Conv layers
+    X = S.make_images(32, 224, 224, seed=303)
+    o16, o32 = ii16.pred_fcn_fn(X), ii32.pred_fcn_fn(X)
+    y16, y32 = host(o16[-1]), host(o32[-1])
+    agree = float((y16.argmax(1) == y32.argmax(1)).mean())
+    print('DenseNet103 bf16 vs fp32: argmax agreement %.4f, mean |dy| %.2e' % (agree, np.abs(y16 - y32).mean()))
+    assert np.abs(y16.sum(1) - 1).max() <= 1e-5 and agree >= 0.9
+    Yii, iters, norms = ii16.refine(o16[:-1], o16[-1], 0.1, 10, early_stop=False)
+    a = host(Yii)
+    assert list(host(iters)) == [10] * 32 and a.min() >= 0 and a.max() <= 1 and np.isfinite(a).all()
