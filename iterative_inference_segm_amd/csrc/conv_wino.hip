@@ -306,9 +306,9 @@ __global__ __launch_bounds__(NT) void wino_input_lds_kernel(const WinoParams p, 
 }
 
 // ---- 2. the 16 GEMMs ---------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, int BK = 16>
 __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_kernel(const WinoParams p) {
-    constexpr int BK = 16, NCH = BK / 2;
+    constexpr int NCH = BK / 2;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -904,11 +904,21 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
             // in the last round (work per CU is quantised in whole workgroups)
             const int w0 = p.n_ttiles * p.n_mtiles, w2 = (g.Tpad / 64) * p.n_mtiles;
             const double cost0 = (w0 + 255) / 256, cost2 = 0.5 * 1.03 * ((w2 + 255) / 256);
+            // 64-channel stages (see the GEMM launch below for why): same k order, same bits
+            static const int bk64 = getenv("IISEG_WINO_FUSED_BK") ? atoi(getenv("IISEG_WINO_FUSED_BK")) == 64 : 0;
+            const bool big = bk64 && g.Kc % 64 == 0;
             if (g.Kc <= 128 || cost2 < cost0) {
                 p.n_ttiles = g.Tpad / 64;
+                if (big)
+                    hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 2, 64, 2>),
+                                       dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+                else
                 hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 2, 32, 2>),
                                    dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
-            } else
+            } else if (big)
+                hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 64, 2>),
+                                   dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
+            else
             hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 32, 2>),
                                dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
         }
@@ -932,6 +942,17 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         }
         const int grid2 = bm ? 16 * p.n_ttiles * (g.Mpad / bm) : 0;
         if (bm) p.n_mtiles = g.Mpad / bm;
+        // k-tile of 32 channels: a global -> LDS stage completes at ~1 us + 35 ns/KB whatever the
+        // ring depth (measured on the bf16 kernels), and a 16-channel stage holds only
+        // ~0.85 us of fp32 MFMA work per wave: twice the work per stage takes the GEMM off that pace.
+        // Same k order, so the results do not change by a bit.
+        static const int bk32 = getenv("IISEG_WINO_GEMM_BK") ? atoi(getenv("IISEG_WINO_GEMM_BK")) == 32 : 1;
+        if (bm && bk32 && g.Kc % 32 == 0 && nbuf != 3) {
+            if (bm == 256)
+                hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2, 32>), dim3(grid), dim3(512), 0, s, p);
+            else
+                hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2, 32>), dim3(grid2), dim3(256), 0, s, p);
+        } else
         if (bm == 0) {
         } else if (bm == 256 && nbuf == 3)
             hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 3>), dim3(grid), dim3(512), 0, s, p);

@@ -939,7 +939,8 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
         const int w128 = (g.Tpad / 128) * p.n_mtiles;
         static const int force = getenv("IISEG_BF16_FUSED_TILE") ? atoi(getenv("IISEG_BF16_FUSED_TILE")) : 0;
         static const int var = getenv("IISEG_BF16_FUSED_VAR") ? atoi(getenv("IISEG_BF16_FUSED_VAR")) : 0;
-        if (force ? force == 64 : w128 < 2 * 256) {
+        static const int min128 = getenv("IISEG_BF16_FUSED_128_MIN") ? atoi(getenv("IISEG_BF16_FUSED_128_MIN")) : 512;
+        if (force ? force == 64 : w128 < min128) {
             p.n_ttiles = g.Tpad / 64;
             const dim3 grid(persistent_grid(p.n_ttiles * p.n_mtiles, 2));
             if (var == 1)        // 2-deep ring

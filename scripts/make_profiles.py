@@ -47,6 +47,8 @@ def stats(d, out, steady=False, nconf=3):
                     break
     per = collections.OrderedDict()
     for r in rows:
+        if 'spin_kernel' in r['Kernel_Name']:      # torch.cuda._sleep: the roofline pass's stream blocker
+            continue
         e = per.setdefault(short(r['Kernel_Name']), [0, 0.0])
         e[0] += 1
         e[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
@@ -73,6 +75,20 @@ def pmc(fd, wd, out, commit=None):
                 e[0] += 1
             e[1] += float(r['Counter_Value'])
         return per
+    def load_summary(d, counter):
+        """scripts/profile_r02.sh reduces the per-dispatch CSV on the GPU box to one row per
+        (kernel, counter): Kernel_Name, Counter_Name, dispatches, Counter_Sum."""
+        per = collections.OrderedDict()
+        for r in csv.DictReader(open(d + '/summary.csv')):
+            if r['Counter_Name'] != counter:
+                continue
+            e = per.setdefault(short(r['Kernel_Name']), [0, 0.0])
+            e[0] += int(r['dispatches'])
+            e[1] += float(r['Counter_Sum'])
+        return per
+    import os
+    if os.path.exists(fd + '/summary.csv'):
+        load = load_summary
     fe, wr = load(fd, 'FETCH_SIZE'), load(wd, 'WRITE_SIZE')
     rows = []
     for k in fe:
