@@ -904,7 +904,8 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
             // in the last round (work per CU is quantised in whole workgroups)
             const int w0 = p.n_ttiles * p.n_mtiles, w2 = (g.Tpad / 64) * p.n_mtiles;
             const double cost0 = (w0 + 255) / 256, cost2 = 0.5 * 1.03 * ((w2 + 255) / 256);
-            // 64-channel stages (see the GEMM launch below for why): same k order, same bits
+            // IISEG_WINO_FUSED_BK=64: 64-channel stages (same bits); measured slower (conv2_2 1.38 ->
+            // 1.71 ms: one workgroup per CU instead of two), 32 stays the default
             static const int bk64 = getenv("IISEG_WINO_FUSED_BK") ? atoi(getenv("IISEG_WINO_FUSED_BK")) == 64 : 0;
             const bool big = bk64 && g.Kc % 64 == 0;
             if (g.Kc <= 128 || cost2 < cost0) {
@@ -942,11 +943,10 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         }
         const int grid2 = bm ? 16 * p.n_ttiles * (g.Mpad / bm) : 0;
         if (bm) p.n_mtiles = g.Mpad / bm;
-        // k-tile of 32 channels: a global -> LDS stage completes at ~1 us + 35 ns/KB whatever the
-        // ring depth (measured on the bf16 kernels), and a 16-channel stage holds only
-        // ~0.85 us of fp32 MFMA work per wave: twice the work per stage takes the GEMM off that pace.
-        // Same k order, so the results do not change by a bit.
-        static const int bk32 = getenv("IISEG_WINO_GEMM_BK") ? atoi(getenv("IISEG_WINO_GEMM_BK")) == 32 : 1;
+        // IISEG_WINO_GEMM_BK=32: 32-channel k-tiles (same k order, same bits).  Tried because the bf16
+        // kernels are paced per LDS-DMA stage; the fp32 GEMM is not -- measured 2.5 %
+        // SLOWER (conv6_1 1.133 -> 1.198 ms, A/B on one device), so 16 stays the default.
+        static const int bk32 = getenv("IISEG_WINO_GEMM_BK") ? atoi(getenv("IISEG_WINO_GEMM_BK")) == 32 : 0;
         if (bm && bk32 && g.Kc % 32 == 0 && nbuf != 3) {
             if (bm == 256)
                 hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2, 32>), dim3(grid), dim3(512), 0, s, p);
