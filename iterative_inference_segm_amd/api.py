@@ -170,10 +170,18 @@ class IterativeInference:
         H_in = list(H) if isinstance(H, (list, tuple)) else [H]
         want_graph = GRAPH_MODE if graph is None else ('1' if graph else '0')
         if want_graph != '0' and mode == 'residual' and per_iter_target is None and \
-                hasattr(self.dae, 'new_session') and int(num_iter) >= (3 if want_graph == 'auto' else 2) \
-                and torch.cuda.is_available():
-            return self._refine_graph(H_in, Y, step, int(num_iter), eps if early_stop else -1.0,
-                                      h_provenance, first_reconstruction)
+                hasattr(self.dae, 'new_session') and int(num_iter) >= 3 and torch.cuda.is_available():
+            # 'auto': a capture costs about as much as the launches it saves in one short loop, so
+            # it must be reusable -- the DAE session (whose buffers the graph points into) has to be
+            # the persistent one that the next batch gets again (every h with a provenance record;
+            # StandardDAE.new_session) -- or the loop long enough to amortise it
+            tags = list(h_provenance) if h_provenance is not None else \
+                [self.provenance_of(a) if isinstance(a, torch.Tensor) else None for a in H_in]
+            persistent = bool(tags) and all(t is not None for t in tags) and \
+                getattr(self.dae, 'licm', False) and getattr(self.dae, 'fold_border', False)
+            if want_graph == '1' or persistent or int(num_iter) >= 16:
+                return self._refine_graph(H_in, Y, step, int(num_iter), eps if early_stop else -1.0,
+                                          tags, first_reconstruction)
         H = [self._dev(h) for h in H_in]
         # where each h came from: explicit records, else what pred_fcn_fn remembered for these
         # very tensor objects (None -> no cross-batch reuse for this call)
