@@ -776,6 +776,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void wino_gemm_bf16_kernel(const W
 
 // launches the GEMM kernel for n_xi points: 256 x 128 blocks when Mpad allows, else 128 x 128
 void launch_gemm_bf16(hipStream_t s, WinoBfParams p, float* M, int n_xi) {
+    static const int big = getenv("IISEG_BF16_GEMM_256") ? atoi(getenv("IISEG_BF16_GEMM_256")) : 1;
+    if (big && p.Mpad % 256 == 0 && p.Tpad % 256 == 0 &&
+        n_xi * (p.Mpad / 256) * (p.Tpad / 256) >= 200) {
+        // 256 x 256 blocks, 8 waves of 128 x 64: a k-tile stage (1 us + 35 ns/KB)
+        // carries twice the flops of the 256 x 128 form for 1.2x its time
+        p.n_ttiles = p.Tpad / 256;
+        p.n_mtiles = p.Mpad / 256;
+        hipLaunchKernelGGL((wino_gemm_bf16_kernel<256, 256, 2, 4, 64, 2>),
+                           dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
+        return;
+    }
     p.n_ttiles = p.Tpad / 128;
     if (p.Mpad % 256 == 0) {
         p.n_mtiles = p.Mpad / 256;
@@ -830,14 +841,16 @@ int wino_bf16_geom(const iiseg_conv_desc* d, WinoBfGeom& g) {
     g.nty = (d->oy0 + d->OH - g.ty0 + 1) >> 1;
     g.ntx = (d->ox0 + d->OW - g.tx0 + 1) >> 1;
     const int64_t T = (int64_t)d->B * g.nty * g.ntx;
-    const int64_t Tpad = (T + 127) / 128 * 128;
+    const bool split = g.Kc >= split_min_kc() && g.Mpad % 128 == 0;
+    // (the separate GEMM kernel may use 256-tile blocks)
+    const int64_t Tpad = split ? (T + 255) / 256 * 256 : (T + 127) / 128 * 128;
     // one buffer descriptor addresses all 16 points of U16 / V16 with 32-bit byte offsets
     if (16 * Tpad * g.Kc * 2 >= ((int64_t)1 << 32) - (1 << 20) ||
         (int64_t)16 * g.Kc * g.Mpad * 2 >= ((int64_t)1 << 32) - (1 << 20))
         return IISEG_ERR_UNSUPPORTED;
     g.T = (int)T;
     g.Tpad = (int)Tpad;
-    g.fused = g.Kc < split_min_kc() || g.Mpad % 128 != 0;
+    g.fused = !split;
     return IISEG_OK;
 }
 
@@ -994,7 +1007,7 @@ int gemm_bf16_geom(const iiseg_conv_desc* d, GemmBfGeom& g) {
     g.Kc = round_up(g.K, WBF_BK);
     g.Mpad = round_up(d->Cout, 128);
     const int64_t T = (int64_t)d->B * fullH * fullW;
-    const int64_t Tpad = (T + 127) / 128 * 128;
+    const int64_t Tpad = (T + 255) / 256 * 256;
     if (Tpad * g.Kc * 2 >= (int64_t)1 << 31 || (int64_t)g.Kc * g.Mpad * 2 >= (int64_t)1 << 31)
         return IISEG_ERR_UNSUPPORTED;
     g.T = (int)T;
