@@ -117,6 +117,24 @@ int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
                         const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
                         const float* bias, const float* add, float* out, float* pool_out);
 
+/* DePool2D equality masks as BYTES (halo-tile kernels only): the reference's DePool2D needs
+ * pre == pooled per element (layers/mylayers.py:111-114); instead of keeping the pre-pool map for
+ * that comparison, the conv whose epilogue does the pooling can write
+ *     mask[b][c][y/2][x/2] bit (y & 1) * 2 + (x & 1) = (pre[b][c][y][x] == pooled[b][c][y/2][x/2])
+ * (B, Cout, fullH/2, fullW/2 bytes, same placement rules as pool_out) and the decoder conv can take
+ * its IISEG_CONV_UNPOOL input from x1 = up and mask_in = that tensor instead of pre / pooled: 5 bytes
+ * read per unpooled element instead of 12, and the largest map of every level is never written or
+ * re-read.  iiseg_conv_mask_f32 is iiseg_conv_pool_f32 with both options: `out` may be NULL when
+ * pool_out and mask_out are given (the pre-pool map is then not stored at all); with mask_in, pre
+ * and pooled are ignored (pass NULL).  Same decisions, bit for bit, as the pre / pooled form.
+ * iiseg_conv_mask_supported: 1 if the request runs on a halo kernel (3x3, dil 1, Cout < 256; the
+ * pool / mask_out part needs 16 < Cout and whole pooling windows, as iiseg_conv_pool_supported). */
+int iiseg_conv_mask_supported(const iiseg_conv_desc* d);
+int iiseg_conv_mask_f32(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
+                        const float* pre, const float* pooled, const uint8_t* mask_in,
+                        const float* wp, const int32_t* ktab, const float* bias, const float* add,
+                        float* out, float* pool_out, uint8_t* mask_out);
+
 /* 3x3 convolution with at most 16 output channels whose INPUT is normalised and rectified while it
  * is staged: x <- max((x - mean[c]) * (gamma[c] * inv_std[c]) + beta[c], 0) per input channel --
  * BN_ReLU_Conv of FC-DenseNet (models/FCDenseNet.py:12,90,109,123) as one kernel instead of
@@ -205,14 +223,16 @@ int iiseg_conv_gemm_bf16(void* stream, const iiseg_conv_desc* d, const float* x,
  * semantics and fusions as iiseg_conv_f32 / iiseg_conv_pool_f32 for 3x3, dil 1, stride 1 layers
  * (two sources need C1 % 16 == 0).  wp16: iiseg_conv_halo_bf16_weight_bytes bytes, filled by
  * iiseg_conv_halo_bf16_pack from w (layout as in iiseg_conv_pack_f32).  pool_out (may be NULL): the
- * FULL pooled tensor, as in iiseg_conv_pool_f32 (even window origin, whole pooling windows, no add). */
+ * FULL pooled tensor, as in iiseg_conv_pool_f32 (even window origin, whole pooling windows, no add).
+ * mask_in / mask_out (may be NULL): DePool2D masks as bytes, see iiseg_conv_mask_f32. */
 int iiseg_conv_halo_bf16_supported(const iiseg_conv_desc* d);
 int64_t iiseg_conv_halo_bf16_weight_bytes(const iiseg_conv_desc* d);
 int iiseg_conv_halo_bf16_pack(void* stream, const iiseg_conv_desc* d, const float* w,
                               int64_t stride_o, int64_t stride_c, void* wp16);
 int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
                          const float* pre, const float* pooled, const void* wp16, const float* bias,
-                         const float* add, float* out, float* pool_out);
+                         const float* add, float* out, float* pool_out, const uint8_t* mask_in,
+                         uint8_t* mask_out);
 
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,

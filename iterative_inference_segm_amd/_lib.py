@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -47,6 +47,8 @@ SIGNATURES = {
     'iiseg_conv_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_conv_pool_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pool_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 10),
+    'iiseg_conv_mask_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_mask_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 12),
     'iiseg_conv_bnrelu_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_bnrelu_f32': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64] + [_vp] * 8),
     'iiseg_conv_wino_supported': (C.c_int, [C.POINTER(ConvDesc)]),
@@ -67,7 +69,7 @@ SIGNATURES = {
     'iiseg_conv_halo_bf16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_halo_bf16_weight_bytes': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_halo_bf16_pack': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
-    'iiseg_conv_halo_bf16': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
+    'iiseg_conv_halo_bf16': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 11),
     'iiseg_conv_gemm_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5 + [C.c_uint32]),

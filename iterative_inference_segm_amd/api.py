@@ -201,6 +201,8 @@ class IterativeInference:
             scratch = torch.zeros(2, dtype=torch.float64, device=y.device)
         # h is fixed and only y evolves: the DAE may keep loop-invariant parts of its maps
         sess = self.dae.new_session(H, y, tags=tags) if hasattr(self.dae, 'new_session') else None
+        if hasattr(self.dae, 'keep_pre'):
+            self.dae.keep_pre = mode == 'gradient'     # backward_y reads the pre-pool maps
         for it in range(int(num_iter)):
             score = self.dae.scores(H, y, session=sess) if sess is not None \
                 else self.dae.scores(H, y)

@@ -44,6 +44,13 @@ struct ConvParams {
     int out_H, out_W, out_y0, out_x0;  // destination planes / placement (dense: OH, OW, 0, 0)
     float* pool;           // fused 2x2 max-pool of the output (conv_halo only), full (fullH/2, fullW/2) planes
     int pool_H, pool_W;
+    // DePool2D equality masks as BYTES instead of the pre-pool map (conv_halo kernels only):
+    // mask[b][c][y/2][x/2] bit (y&1)*2 + (x&1) = (pre[y][x] == pooled[y/2][x/2]).  mask_out: written
+    // by the fused-pool epilogue next to `pool` (then `out` may be NULL: the pre-pool map is not
+    // stored at all); mask_in: the unpool input gather reads it instead of pre / pooled
+    // (x1 = up as before).
+    const unsigned char* mask_in;
+    unsigned char* mask_out;
     // fused input BatchNorm + ReLU (conv_halo16 only): x <- max((x - mean[c]) * (gamma[c] * inv_std[c])
     // + beta[c], 0) while the patch is staged; in_bstride = elements between images of x1 (0: dense)
     const float *bn_beta, *bn_gamma, *bn_mean, *bn_inv_std;

@@ -32,11 +32,20 @@ constexpr unsigned OOB = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const float* base, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
 }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc_b(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
+}
 __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
-template <int BM, int TH, int WM, int WN, bool UNPOOL>
+__device__ __forceinline__ unsigned buf_ld_u8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r, (int)voff, (int)soff, 0);
+}
+
+// MASKIN (with UNPOOL): the DePool2D mask comes as bytes (ConvParams::mask_in) instead of being
+// formed from pre == pooled: 2 loads (1 + 4 bytes) per patch element instead of 3 (12 bytes)
+template <int BM, int TH, int WM, int WN, bool UNPOOL, bool MASKIN = false>
 __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams p, const int tiles_y,
                                                                const int tiles_x) {
     constexpr int CPT = 4, BK = 9 * CPT, NCH = BK / 2;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
 
     // ---- patch staging: element e = i*256 + tid  ->  (channel of the k-tile, patch y, patch x) ----
     unsigned voff[NE], voff2[UNPOOL ? NE : 1];
-    int cl[NE];
+    int cl[NE], bsel[UNPOOL ? NE : 1];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = i * 256 + tid;
@@ -83,10 +92,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
             // DePool2D (layers/mylayers.py:95-114): only the 2h x 2w region has pooling windows
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
             voff2[i] = ok ? 4u * (unsigned)(c * hw2 + (iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+            bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
     // one image per tile: descriptors start at image b of each source
-    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
+    const float* base1 = (UNPOOL && !MASKIN) ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
     const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
     const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
     const float* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
@@ -117,8 +128,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
                 constexpr int i = decltype(I)::value;                                              \
                 const bool cok = cl[i] < crem;                                                     \
                 const unsigned vo = cok ? voff[i] : OOB, vo2 = cok ? voff2[i] : OOB;               \
-                xv[i] = buf_ld(mk_rsrc(base1, n1), vo, (unsigned)(c0 * HW) * 4u);                  \
-                xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+                if constexpr (MASKIN) {                                                            \
+                    xq[i] = __builtin_bit_cast(float, buf_ld_u8(mk_rsrc_b(basem, nq >> 2),         \
+                                                                vo2 == OOB ? OOB : vo2 >> 2,       \
+                                                                (unsigned)(c0 * hw2)));            \
+                } else {                                                                           \
+                    xv[i] = buf_ld(mk_rsrc(base1, n1), vo, (unsigned)(c0 * HW) * 4u);              \
+                    xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);            \
+                }                                                                                  \
                 xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
             });                                                                                    \
         } else {                                                                                   \
@@ -140,6 +157,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */          \
+            if constexpr (MASKIN)                                                                  \
+                Ps[BUF][i * 256 + tid] =                                                           \
+                    ((__builtin_bit_cast(unsigned, xq[i]) >> bsel[i]) & 1u) ? xu[i] : 0.f;         \
+            else                                                                                   \
             Ps[BUF][i * 256 + tid] = (xv[i] == xq[i]) ? xu[i] : 0.f;                               \
         });                                                                                        \
     }
@@ -245,11 +266,22 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
                         v1 = fmaxf(v1, 0.f);
                     }
                     const bool cv = co < p.Cout;
-                    if (cv && ok0) outp[(size_t)co * OPL] = v0;
-                    if (cv && ok1) outp[(size_t)co * OPL + p.out_W] = v1;
+                    if (p.out) {
+                        if (cv && ok0) outp[(size_t)co * OPL] = v0;
+                        if (cv && ok1) outp[(size_t)co * OPL + p.out_W] = v1;
+                    }
                     float m = fmaxf(v0, v1);
                     m = fmaxf(m, __shfl_xor(m, 1));
                     if (cv && okp) poolp[(size_t)co * PPL] = m;
+                    if (p.mask_out) {
+                        // bit (row & 1) * 2 + (col & 1) of the window's byte: pre == pooled
+                        unsigned bits = (v0 == m ? (l31 & 1 ? 2u : 1u) : 0u) |
+                                        (v1 == m ? (l31 & 1 ? 8u : 4u) : 0u);
+                        bits |= __shfl_xor(bits, 1);
+                        if (cv && okp)
+                            p.mask_out[(size_t)b * p.Cout * PPL + (size_t)co * PPL +
+                                       (size_t)py * p.pool_W + px] = (unsigned char)bits;
+                    }
                 }
         }
         return;
@@ -297,7 +329,10 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_ptiles = p.B * tiles_y * tiles_x;
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
-    if (unpool)
+    if (unpool && p.mask_in)
+        hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, true, true>), dim3(grid), dim3(256),
+                           0, s, p, tiles_y, tiles_x);
+    else if (unpool)
         hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
                            p, tiles_y, tiles_x);
     else
@@ -313,7 +348,7 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
 // is still sequential in k (4 at a time), results agree with the 32-row kernels to fp32 rounding.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int TH, bool UNPOOL, int DIL, bool BNRELU = false>
+template <int TH, bool UNPOOL, int DIL, bool BNRELU = false, bool MASKIN = false>
 __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParams p, const int tiles_y,
                                                                  const int tiles_x) {
     constexpr int BM = 16, CPT = 4, BK = 9 * CPT, NS = BK / 4;
@@ -348,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
     const int C1 = p.C1, Ctot = p.C1 + p.C2;
 
     unsigned voff[NE], voff2[UNPOOL ? NE : 1];
-    int cl[NE];
+    int cl[NE], bsel[UNPOOL ? NE : 1];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = i * 256 + tid;
@@ -361,9 +396,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
         if constexpr (UNPOOL) {
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
             voff2[i] = ok ? 4u * (unsigned)(c * hw2 + (iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+            bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
-    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW
+    const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
+    const float* base1 = (UNPOOL && !MASKIN) ? p.pre + (size_t)b * C1 * HW
                                 : p.x1 + (size_t)b * (p.in_bstride ? (size_t)p.in_bstride : (size_t)C1 * HW);
     const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
     const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
@@ -391,8 +428,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
                 constexpr int i = decltype(I)::value;                                              \
                 const bool cok = cl[i] < crem;                                                     \
                 const unsigned vo = cok ? voff[i] : OOB, vo2 = cok ? voff2[i] : OOB;               \
-                xv[i] = buf_ld(mk_rsrc(base1, n1), vo, (unsigned)(c0 * HW) * 4u);                  \
-                xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+                if constexpr (MASKIN) {                                                            \
+                    xq[i] = __builtin_bit_cast(float, buf_ld_u8(mk_rsrc_b(basem, nq >> 2),         \
+                                                                vo2 == OOB ? OOB : vo2 >> 2,       \
+                                                                (unsigned)(c0 * hw2)));            \
+                } else {                                                                           \
+                    xv[i] = buf_ld(mk_rsrc(base1, n1), vo, (unsigned)(c0 * HW) * 4u);              \
+                    xq[i] = buf_ld(mk_rsrc(baseq, nq), vo2, (unsigned)(c0 * hw2) * 4u);            \
+                }                                                                                  \
                 xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
             });                                                                                    \
         } else if constexpr (BNRELU) {                                                             \
@@ -432,6 +475,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
     if constexpr (UNPOOL) {                                                                        \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
+            if constexpr (MASKIN)                                                                  \
+                Ps[BUF][i * 256 + tid] =                                                           \
+                    ((__builtin_bit_cast(unsigned, xq[i]) >> bsel[i]) & 1u) ? xu[i] : 0.f;         \
+            else                                                                                   \
             Ps[BUF][i * 256 + tid] = (xv[i] == xq[i]) ? xu[i] : 0.f;                               \
         });                                                                                        \
     }
@@ -528,6 +575,9 @@ int launch_halo16(hipStream_t s, const ConvParams& cp, bool unpool) {
         if (unpool || p.dil != 1 || p.C2 != 0) return IISEG_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, false, 1, true>), grid, block, 0, s, p, tiles_y,
                            tiles_x);
+    } else if (unpool && p.mask_in) {
+        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, true, 1, false, true>), grid, block, 0, s, p,
+                           tiles_y, tiles_x);
     } else if (unpool) H16(true, 1);
     else switch (p.dil) {
         case 1: H16(false, 1); break;

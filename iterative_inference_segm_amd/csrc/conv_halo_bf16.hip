@@ -63,7 +63,8 @@ __global__ void halo_pack_bf16_kernel(const float* __restrict__ w, int64_t so, i
     }
 }
 
-template <int BM, int TH, int WM, int WN, bool UNPOOL>
+// MASKIN (with UNPOOL): DePool2D mask from bytes (ConvParams::mask_in) instead of pre == pooled
+template <int BM, int TH, int WM, int WN, bool UNPOOL, bool MASKIN = false>
 __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(const ConvParams p, const int tiles_y,
                                                                 const int tiles_x) {
     constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
 
     // ---- patch staging: chunk e = i*256 + tid -> (channel half h, patch y, patch x) -------------
     unsigned voff[NE], voff2[UNPOOL ? NE : 1];
+    int bsel[UNPOOL ? NE : 1];
     int ch0[NE];                                  // first channel of the chunk inside the k-tile
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -117,10 +119,12 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             // DePool2D (layers/mylayers.py:95-114): only the 2h x 2w region has pooling windows
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
             voff2[i] = ok ? 4u * (unsigned)((iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+            bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
+    const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
     // one image per tile: descriptors start at image b of each source
-    const float* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const float* base1 = (UNPOOL && !MASKIN) ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
     const float* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
     const int n1 = C1 * HW * 4, n2 = p.C2 > 0 ? p.C2 * HW * 4 : n1;
     const float* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
@@ -153,11 +157,17 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
                 const bool cok = ch0[i] + j < crem && !(p.debug_nogather & 2);                     \
                 const unsigned so = (unsigned)((cb + ch0[i] + j) * HW) * 4u;                       \
-                xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
+                if constexpr (!MASKIN)                                                             \
+                    xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
                 if constexpr (UNPOOL) {                                                            \
                     const unsigned so2 = (unsigned)((cb + ch0[i] + j) * hw2) * 4u;                 \
-                    xq[i][j] = buf_ld(mk_rsrc(baseq, nq), cok ? voff2[i] : OOB, so2);              \
-                    xu[i][j] = buf_ld(mk_rsrc(baseu, nq), cok ? voff2[i] : OOB, so2);              \
+                    const unsigned vo2 = cok ? voff2[i] : OOB;                                     \
+                    if constexpr (MASKIN)                                                          \
+                        xq[i][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8( \
+                            mk_rsrc(basem, nq >> 2), (int)(vo2 == OOB ? OOB : vo2 >> 2), (int)(so2 >> 2), 0)); \
+                    else                                                                           \
+                        xq[i][j] = buf_ld(mk_rsrc(baseq, nq), vo2, so2);                           \
+                    xu[i][j] = buf_ld(mk_rsrc(baseu, nq), vo2, so2);                               \
                 }                                                                                  \
             }                                                                                      \
         });                                                                                        \
@@ -168,7 +178,9 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         float v[8];                                                                                \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
             /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */          \
-            if constexpr (UNPOOL) v[j] = (xv[i][j] == xq[i][j]) ? xu[i][j] : 0.f;                  \
+            if constexpr (MASKIN)                                                                  \
+                v[j] = ((__builtin_bit_cast(unsigned, xq[i][j]) >> bsel[i]) & 1u) ? xu[i][j] : 0.f; \
+            else if constexpr (UNPOOL) v[j] = (xv[i][j] == xq[i][j]) ? xu[i][j] : 0.f;             \
             else v[j] = xv[i][j];                                                                  \
         }                                                                                          \
         if (NE * 256 == NCHK || i * 256 + tid < NCHK)                                              \
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             const int row = rem >> 3, x4 = (rem & 7) * 4;
             const int co = m0 + i * 32 + cl;
             const int wy = wy0 + row, wx = wx0 + x4;
-            if (co >= p.Cout || wy >= p.OH || wx >= p.OW) continue;
+            if (co >= p.Cout || wy >= p.OH || wx >= p.OW || !p.out) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (cl * TH + row) * 32 + x4);
             float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0 + co) * OPL +
                           (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
@@ -312,6 +324,10 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
                 const float* c0 = Cs + (cl * TH + 2 * prow) * 32 + 2 * pcol;
                 const float m = fmaxf(fmaxf(c0[0], c0[1]), fmaxf(c0[32], c0[33]));
                 p.pool[((size_t)b * p.Cout + co) * PPL + (size_t)py * p.pool_W + px] = m;
+                if (p.mask_out)      // bit (row & 1) * 2 + (col & 1): pre == pooled
+                    p.mask_out[((size_t)b * p.Cout + co) * PPL + (size_t)py * p.pool_W + px] =
+                        (unsigned char)((c0[0] == m ? 1u : 0u) | (c0[1] == m ? 2u : 0u) |
+                                        (c0[32] == m ? 4u : 0u) | (c0[33] == m ? 8u : 0u));
             }
         }
     }
@@ -324,7 +340,10 @@ int launch_halo_bf16(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_ptiles = p.B * tiles_y * tiles_x;
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
-    if (unpool)
+    if (unpool && p.mask_in)
+        hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, true, true>), dim3(grid), dim3(256),
+                           0, s, p, tiles_y, tiles_x);
+    else if (unpool)
         hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
                            p, tiles_y, tiles_x);
     else
@@ -391,14 +410,18 @@ extern "C" int iiseg_conv_halo_bf16_pack(void* stream, const iiseg_conv_desc* d,
 extern "C" int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1,
                                     const float* x2, const float* pre, const float* pooled,
                                     const void* wp16, const float* bias, const float* add, float* out,
-                                    float* pool_out) {
+                                    float* pool_out, const unsigned char* mask_in,
+                                    unsigned char* mask_out) {
     const int st = halo_bf16_check(d);
     if (st) return st;
-    if (!x1 || !wp16 || !out) return IISEG_ERR_NULL;
+    if (!x1 || !wp16) return IISEG_ERR_NULL;
+    if (!out && !(pool_out && mask_out)) return IISEG_ERR_NULL;   // pre-pool map may be skipped
+    if (mask_out && !pool_out) return IISEG_ERR_UNSUPPORTED;
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
     if ((uintptr_t)wp16 & 15) return IISEG_ERR_ALIGN;
     const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
-    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if (unpool && !mask_in && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if (mask_in && !unpool) return IISEG_ERR_UNSUPPORTED;
     if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
         return IISEG_ERR_SHAPE;
     const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
@@ -422,6 +445,7 @@ extern "C" int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, cons
     p.Mpad = (d->Cout + bm - 1) / bm * bm;
     p.pad = d->pad; p.dil = 1;
     p.pool = pool_out;
+    p.mask_in = mask_in; p.mask_out = mask_out;
     p.pool_H = fullH / 2; p.pool_W = fullW / 2;
     p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
     p.out_c0 = d->out_ctot ? d->out_c0 : 0;

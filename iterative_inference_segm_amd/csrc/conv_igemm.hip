@@ -438,7 +438,27 @@ struct BnIn {   // fused input BatchNorm + ReLU (conv_halo16 only)
 static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
                     const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
                     const float* bias, const float* add, float* out, float* pool_out,
-                    const BnIn* bn);
+                    const BnIn* bn, const unsigned char* mask_in = nullptr,
+                    unsigned char* mask_out = nullptr);
+
+extern "C" int iiseg_conv_mask_supported(const iiseg_conv_desc* d) {
+    if (!d || check_desc(d)) return 0;
+    static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
+    return halo && d->KH == 3 && d->KW == 3 && d->dil == 1 && !(d->flags & IISEG_CONV_TRANSPOSED2) &&
+           d->Cout < 256 && d->Kpad % 36 == 0 && !(d->C2 > 0 && d->C1 % 4);
+}
+
+extern "C" int iiseg_conv_mask_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
+                                   const float* x2, const float* pre, const float* pooled,
+                                   const uint8_t* mask_in, const float* wp, const int32_t* ktab,
+                                   const float* bias, const float* add, float* out, float* pool_out,
+                                   uint8_t* mask_out) {
+    if (!iiseg_conv_mask_supported(d)) return IISEG_ERR_UNSUPPORTED;
+    if (mask_out && !pool_out) return IISEG_ERR_UNSUPPORTED;
+    if (mask_in && !(d->flags & IISEG_CONV_UNPOOL)) return IISEG_ERR_UNSUPPORTED;
+    return conv_run(stream, d, x1, x2, pre, pooled, wp, ktab, bias, add, out, pool_out, nullptr,
+                    mask_in, mask_out);
+}
 
 extern "C" int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1,
                                    const float* x2, const float* pre, const float* pooled,
@@ -468,15 +488,16 @@ extern "C" int iiseg_conv_bnrelu_f32(void* stream, const iiseg_conv_desc* d, con
 static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
                     const float* pre, const float* pooled, const float* wp, const int32_t* ktab,
                     const float* bias, const float* add, float* out, float* pool_out,
-                    const BnIn* bn) {
+                    const BnIn* bn, const unsigned char* mask_in, unsigned char* mask_out) {
     int st = check_desc(d);
     if (pool_out && !iiseg_conv_pool_supported(d)) return IISEG_ERR_UNSUPPORTED;
     if (st) return st;
-    if (!x1 || !wp || !ktab || !out) return IISEG_ERR_NULL;
+    if (!x1 || !wp || !ktab) return IISEG_ERR_NULL;
+    if (!out && !(pool_out && mask_out)) return IISEG_ERR_NULL;   // pre-pool map may be skipped
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
     if (((uintptr_t)wp & 15) || ((uintptr_t)ktab & 15)) return IISEG_ERR_ALIGN;
     const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
-    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if (unpool && !mask_in && (!pre || !pooled)) return IISEG_ERR_NULL;
     if (unpool && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
     if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
         return IISEG_ERR_SHAPE;
@@ -493,6 +514,7 @@ static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, con
     p.pad = d->pad; p.dil = d->dil;
     p.debug_nogather = 0;
     p.pool = pool_out;
+    p.mask_in = mask_in; p.mask_out = mask_out;
     p.bn_beta = bn ? bn->beta : nullptr;
     p.bn_gamma = bn ? bn->gamma : nullptr;
     p.bn_mean = bn ? bn->mean : nullptr;
@@ -517,6 +539,7 @@ static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, con
     const bool use_halo = halo && (halo > 1 || d->Cout < 256) && iiseg_conv_halo_ok(p, d->KH, d->KW);
     if (pool_out && (!use_halo || add || d->Cout <= 16)) return IISEG_ERR_UNSUPPORTED;
     if (bn && !use_halo) return IISEG_ERR_UNSUPPORTED;
+    if ((mask_in || mask_out) && !use_halo) return IISEG_ERR_UNSUPPORTED;
     if (use_halo) return iiseg_launch_conv_halo(s, p, pick_bm(d->Cout), unpool);
     if (iiseg_taps_cpt(d->KH, d->KW) > 0)
         return iiseg_launch_conv_taps(s, p, d->KH, d->KW, pick_bm(d->Cout), unpool);

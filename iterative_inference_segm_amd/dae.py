@@ -153,6 +153,27 @@ class StandardDAE:
         self.fold_border = os.environ.get('IISEG_DAE_BORDER_FOLD', '1') != '0'
         self._store = None
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
+        # DePool2D masks as bytes: where the encoder conv that pools and the decoder conv that
+        # unpools both run on halo kernels, the pre-pool map is never stored -- the encoder writes
+        # pool + one mask byte per pooled element, the decoder reads up + that byte (`_mask_levels`)
+        self.use_masks = os.environ.get('IISEG_DEPOOL_MASKS', '1') != '0'
+        self.keep_pre = False   # True: the pre-pool maps are needed afterwards (backward_y)
+
+    def _mask_levels(self, overridden):
+        """Levels (1-based) whose DePool2D mask travels as bytes in this call."""
+        if not self.use_masks or overridden or self.keep_pre or self.bn or self.trace is not None or \
+                self.unpool_type == 'standard' or self.dtype != torch.float32 or \
+                self.fuse_unpool is False:
+            return frozenset()
+        levels = set()
+        for L in range(1, self.total + 1):
+            enc = self.enc['conv%d_%d' % (L, self.conv_before_pool)]
+            fed_by_h = self.conv_before_pool == 1 and \
+                ('input' if L == 1 else 'pool%d' % (L - 1)) in self.concat_h
+            if not fed_by_h and enc.pool_fusable() and enc.mask_ok() and \
+                    self.dec['up_conv%d' % L].mask_ok():
+                levels.add(L)
+        return frozenset(levels)
 
     def new_session(self, h_list=None, y=None, tags=None):
         """State of one refinement loop (h fixed, y evolving): see `scores`.
@@ -204,6 +225,15 @@ class StandardDAE:
         # border and everything fed by h alone keep the values of the first step).  `session`
         # carries the full-size buffers; `dep` is the y-dependent region (y0, x0, h, w) of `t`.
         primed = session is not None and session.get('primed', False) and self.licm
+        will_override = mask_override is not None or (
+            self.emulate_noise and (self.noise > 0 or self.dropout > 0) and
+            self.unpool_type == 'trackind')
+        masked = self._mask_levels(will_override)
+        if session is not None:
+            if primed and session.get('masked', frozenset()) != masked:
+                primed = False               # buffers of the other form: compute everything again
+            session['masked'] = masked
+        masks = {}
         dep = (0, 0, y.shape[2], y.shape[3])
         ydep = dep    # the region y alone reaches: its origin parity anchors the Winograd tiles
 
@@ -273,11 +303,25 @@ class StandardDAE:
                                                    dtype=t.dtype, device=t.device)
                         fused_pool = pooled_t
                         kw['pool_out'] = pooled_t
-                    t = conv(t, **kw)
+                    if (p + 1) in masked:
+                        if pw_ is None:
+                            raise RuntimeError('internal: level %d was planned for byte masks but '
+                                               'its pool is not fused' % (p + 1))
+                        m = session['mask%d' % (p + 1)] if primed else \
+                            torch.empty(pooled_t.shape, dtype=torch.uint8, device=t.device)
+                        masks[p + 1] = m
+                        kw.update(mask_out=m, store_out=False)
+                        conv(t, **kw)
+                        # the pre-pool map is not stored: a shape-only stand-in from here on
+                        t = torch.empty((t.shape[0], conv.Cout, fh, fw), dtype=t.dtype, device='meta')
+                    else:
+                        t = conv(t, **kw)
                 if self.bn:
                     ops.bn_affine(t, self.enc_bn[name], window=dep if primed else None)
                 if session is not None and not primed:
                     session[name] = t
+                    if (p + 1) in masks and i == self.conv_before_pool:
+                        session['mask%d' % (p + 1)] = masks[p + 1]
                 self._count(name, conv, t, computed=(dep[2], dep[3]) if primed else None)
             pre[p + 1] = t
             ydep = (ydep[0] // 2, ydep[1] // 2,
@@ -376,6 +420,8 @@ class StandardDAE:
             kw = dict(pre=mpre, pooled=mpool, window=window, out=out,
                       place=None if full else (y0, x0),
                       anchor=(cy + win[p][0], cx + win[p][1]))
+            if p in masks:
+                kw.update(pre=None, pooled=None, mask_in=masks[p], unpool_hw=(ph, pw))
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
                 kw.update(add=other, add_off=(_center(other.shape[2], oh) + y0,
                                               _center(other.shape[3], ow) + x0))
@@ -423,6 +469,9 @@ class StandardDAE:
         Full maps (the decoder / encoder windows of the forward are not exploited here)."""
         bwd = self._bwd_convs()
         override, pre, pool = self._saved
+        if any(t.device.type == 'meta' for t in pre.values()):
+            raise RuntimeError('backward_y needs the pre-pool maps of the forward pass: set '
+                               'dae.keep_pre = True before calling scores()')
         B = g_score.shape[0]
         dev, dt = g_score.device, g_score.dtype
         g_pool = {}

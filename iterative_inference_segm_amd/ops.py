@@ -42,6 +42,7 @@ CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
 DEFAULT_MMA = os.environ.get('IISEG_MMA', 'f32')
 # bf16 mode: 3x3 layers at least this wide run on the bf16 Winograd kernels (conv_wino_bf16.hip)
 BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '128'))
+BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
 BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '128'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
 
@@ -216,7 +217,8 @@ class Conv:
         return plan
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
-                 window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None):
+                 window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None,
+                 mask_in=None, unpool_hw=None, mask_out=None, store_out=True):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
@@ -227,11 +229,34 @@ class Conv:
         row / column where the Winograd 2x2 tiles start (a per-layer constant for the caller:
         launches of one layer agree bit for bit only under the same anchor).  `pool_out`: the FULL
         pooled tensor (B, Cout, fullH//2, fullW//2) of this layer; the 2x2 max-pool of the computed
-        window is written into it by the conv's epilogue (see `pool_window`)."""
+        window is written into it by the conv's epilogue (see `pool_window`).
+
+        DePool2D masks as bytes (`mask_ok()` layers, include/iiseg.h iiseg_conv_mask_f32):
+        `mask_out` (uint8, pool_out's shape) receives, with the pool, one byte per pooled element
+        whose bit (y&1)*2+(x&1) says pre == pooled; `store_out=False` then skips the pre-pool map
+        itself (returns None; `out`, if given, only carries the placement geometry).  `mask_in`
+        (uint8, x1's shape) + `unpool_hw` = (H, W) replace `pre` / `pooled` for the unpooled
+        input."""
         dt = self.dtype
-        unpool = pre is not None
+        unpool = pre is not None or mask_in is not None
+        masked = mask_in is not None or mask_out is not None
         B, C1 = x1.shape[0], x1.shape[1]
-        if unpool:
+        if masked:
+            if not self.mask_ok():
+                raise RuntimeError('DePool2D byte masks need a halo-kernel layer (Conv.mask_ok)')
+            if mask_in is not None and (pre is not None or mask_in.dtype != torch.uint8 or
+                                        mask_in.shape != x1.shape or unpool_hw is None or
+                                        (unpool_hw[0] // 2, unpool_hw[1] // 2) != tuple(x1.shape[2:])):
+                raise RuntimeError('mask_in: uint8 of x1\'s shape %s with unpool_hw, without pre'
+                                   % (tuple(x1.shape),))
+            if mask_out is not None and (pool_out is None or mask_out.dtype != torch.uint8 or
+                                         mask_out.shape != pool_out.shape):
+                raise RuntimeError('mask_out: uint8 of pool_out\'s shape')
+        if not store_out and (mask_out is None or out_c0 is not None):
+            raise RuntimeError('store_out=False needs pool_out and mask_out')
+        if mask_in is not None:
+            H, W = int(unpool_hw[0]), int(unpool_hw[1])
+        elif unpool:
             H, W = pre.shape[2], pre.shape[3]
             if pooled.shape != x1.shape or pre.shape[:2] != x1.shape[:2] or \
                     (H // 2, W // 2) != tuple(x1.shape[2:]):
@@ -263,7 +288,9 @@ class Conv:
             pl = None if place is None else (out.shape[2], out.shape[3], int(place[0]), int(place[1]))
             d, wp, ktab = self._plan(B, C1, C2, H, W, window, add_geom, unpool, out_slice, pl,
                                      (int(anchor[0]) & 1, int(anchor[1]) & 1))
-        if place is not None:
+        if not store_out:
+            out = None                     # geometry taken above; nothing is written
+        elif place is not None:
             if self.via_im2col or out is None or out.shape[0] != B or out.dtype != dt or \
                     (out_c0 is None and out.shape[1] != self.Cout):
                 raise RuntimeError('bad placement target %s' % (None if out is None else tuple(out.shape),))
@@ -278,10 +305,15 @@ class Conv:
         # profiling: every launch is bracketed by events recorded IMMEDIATELY around the ctypes
         # call (after all planning / workspace work), so a bracket holds the kernel and nothing else
         prof = CONV_PROFILE
-        if pool_out is None and self.wino_bf16 and \
+        if not masked and pool_out is None and self.wino_bf16 and \
                 self.lib.iiseg_conv_wino_bf16_supported(C.byref(d)):
             return self._call_wino_bf16(d, x1, x2, pre, pooled, add, out, prof)
-        if self.halo_bf16 and self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
+        # (the DAE's last layer -- DePool2D input, <= 16 output channels: reading pre / pooled it is
+        # read-bound and faster on the 16-row fp32 kernel, 0.60 vs 0.74 ms at configs[1]; from mask
+        # bytes the bf16 kernel wins, 0.45 vs 0.58 ms)
+        if self.halo_bf16 and \
+                not (unpool and self.Cout <= 16 and mask_in is None and not BF16_UPCONV1) and \
+                self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
             if pool_out is not None:
                 fh, fw = self.out_hw(H, W)
                 if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2):
@@ -295,13 +327,30 @@ class Conv:
             ev0 = _ev() if prof is not None else None
             check(self.lib.iiseg_conv_halo_bf16(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
                                                 _ptr(pooled), _ptr(self._W16, torch.bfloat16),
-                                                _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out)),
+                                                _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out),
+                                                _ptr(mask_in, torch.uint8),
+                                                _ptr(mask_out, torch.uint8)),
                   'iiseg_conv_halo_bf16')
             if prof is not None:
                 prof.append(('conv_halo_bf16_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
             return out
-        if pool_out is None and self.wino and self.lib.iiseg_conv_wino_supported(C.byref(d)):
+        if not masked and pool_out is None and self.wino and \
+                self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
+        if masked:
+            if pool_out is not None:
+                fh, fw = self.out_hw(H, W)
+                if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2):
+                    raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
+            ev0 = _ev() if prof is not None else None
+            check(self.lib.iiseg_conv_mask_f32(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
+                                               _ptr(pooled), _ptr(mask_in, torch.uint8), _ptr(wp),
+                                               _ptr(ktab, torch.int32), _ptr(self.b), _ptr(add),
+                                               _ptr(out), _ptr(pool_out),
+                                               _ptr(mask_out, torch.uint8)), 'iiseg_conv_mask_f32')
+            if prof is not None:
+                prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
+            return out
         if pool_out is not None:
             fh, fw = self.out_hw(H, W)
             if dt != torch.float32 or tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2) or \
@@ -398,17 +447,28 @@ class Conv:
             prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
         return out
 
+    def pool_fusable(self):
+        """True if this layer runs on a halo kernel whose epilogue can do the 2x2 max-pool."""
+        if not POOL_FUSE or self.dtype != torch.float32:
+            return False
+        if self.mma == 'bf16':
+            return self.halo_bf16
+        return not (self.wino or self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256)
+
+    def mask_ok(self):
+        """True if this layer can take / produce DePool2D masks as bytes (halo kernels only, and
+        only where the byte form runs the very kernel the pre / pooled form runs)."""
+        if self.dtype != torch.float32 or (self.KH, self.KW) != (3, 3) or self.dil != 1 or \
+                self.transposed or self.kernel != 'conv_halo_f32_kernel' or self.wino_bf16:
+            return False
+        return not self.wino and (self.halo_bf16 or self.mma != 'bf16')
+
     def pool_window(self, H, W, region=None):
         """If the 2x2 max-pool that follows this layer can be fused into its epilogue: the conv
         window (y0, x0, h, w) to launch so that every pooling window touching `region` (of the
         conv output; None = the whole map) is whole -- even origin, even extent unless it ends at
         the map's last row / column.  None if the layer does not run on the halo kernel."""
-        if not POOL_FUSE or self.dtype != torch.float32:
-            return None
-        if self.mma == 'bf16':
-            if not self.halo_bf16:
-                return None
-        elif self.wino or self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256:
+        if not self.pool_fusable():
             return None
         fh, fw = self.out_hw(H, W)
         if region is None:

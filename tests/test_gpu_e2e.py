@@ -541,6 +541,7 @@ def test_true_gradient_mode(built_lib, dtype, tol, skip):
     dae = StandardDAE(dp, 11, dtype=dtype, **kw)
     yt = torch.from_numpy(y).to(dtype).cuda()
     ht = torch.from_numpy(h).to(dtype).cuda()
+    dae.keep_pre = True            # backward_y reads the pre-pool maps of this forward
     score = dae.scores([ht], yt)
     r = ops.crop_softmax(score, size[0], size[1], off=(0, 0))
     g_thr = dae.backward_y(ops.sqerr_softmax_bwd(score, yt, off=(0, 0)), yt.shape)
@@ -675,3 +676,53 @@ def test_graph_replay_is_bit_identical_to_the_eager_loop(built_lib, dtype, nf, s
     b = ii_e.refine([og[0].clone()], og[-1], 0.3, n_it, graph=False)
     for x, y_ in zip(a, b):
         assert np.array_equal(host(x), host(y_))
+
+
+@pytest.mark.parametrize('mma', ['f32', 'bf16'])
+@pytest.mark.parametrize('nf,size,div', [(16, (40, 52), 16), (64, (224, 224), 1)])
+def test_depool_byte_masks_are_bit_identical_to_the_stored_pre_pool_maps(built_lib, mma, nf, size, div,
+                                                                        monkeypatch):
+    """DePool2D (layers/mylayers.py:76-114) with its equality mask carried as one byte per pooled
+    element (the encoder's pre-pool maps of those levels are never written) against the form that
+    stores the maps and compares pre == pooled in the decoder: same refined maps, iteration counts,
+    norms and first reconstruction, bit for bit -- over three batches (the later ones run on the
+    reused border-folded session, i.e. windowed mask updates), eager and from the HIP graph, and for
+    a one-shot scores() call.  Also checks that the mode is really on (levels planned) and that
+    gradient mode, which needs the maps, still gets them.  (In bf16 mode the last decoder layer is
+    put on the bf16 kernel in both forms -- by default the pre / pooled form of that one layer runs
+    the fp32 16-row kernel, which is faster for it -- so that the same kernels are compared.)"""
+    from iterative_inference_segm_amd import ops as _ops
+    monkeypatch.setattr(_ops, 'BF16_UPCONV1', True)
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    concat_h = ['pool4']
+    fp = S.make_fcn8_params(width_div=div, fc_channels=4096 // div, seed=281)
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=nf, seed=282)
+    B = 2
+
+    def make(masks):
+        ii = IterativeInference(FCN8(fp, 11, layer=concat_h + ['probs_dimshuffle'], mma=mma),
+                                StandardDAE(dp, 11, concat_h=concat_h, n_filters=nf, mma=mma),
+                                11, [11])
+        ii.dae.use_masks = masks
+        ii.prepare(B, size[0], size[1])
+        return ii
+    ii_m, ii_p = make(True), make(False)
+    levels = ii_m.dae._mask_levels(False)
+    assert len(levels) >= 1 and not ii_p.dae._mask_levels(False), levels
+    for i in range(3):
+        X = S.make_images(B, size[0], size[1], seed=290 + i)
+        om, op = ii_m.pred_fcn_fn(X), ii_p.pred_fcn_fn(X)
+        for graph in (False, True):
+            rm = ii_m.refine(om[:-1], om[-1], 0.3, 5, eps=1e-3, graph=graph, first_reconstruction=True)
+            rp = ii_p.refine(op[:-1], op[-1], 0.3, 5, eps=1e-3, graph=graph, first_reconstruction=True)
+            for a, b in zip(rm, rp):
+                assert np.array_equal(host(a), host(b)), 'batch %d graph %s differs' % (i, graph)
+    sm = ii_m.dae.scores(list(om[:-1]), om[-1])
+    sp = ii_p.dae.scores(list(op[:-1]), op[-1])
+    assert np.array_equal(host(sm), host(sp))
+    if mma == 'f32':
+        gm = ii_m.refine(om[:-1], om[-1], 0.05, 2, mode='gradient')
+        gp = ii_p.refine(op[:-1], op[-1], 0.05, 2, mode='gradient')
+        assert np.array_equal(host(gm[0]), host(gp[0]))

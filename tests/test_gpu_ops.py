@@ -499,3 +499,97 @@ def test_abi_rejects_bad_arguments(ops):
     assert lib.iiseg_bn_stats_workspace_elems(16) == 16 * 64 * 2
     assert lib.iiseg_depool_bwd_f32(None, None, None, None, None, 1, 4, 4) == -1
     assert lib.iiseg_add_noise_f32(None, None, None, 0.1, None, 10) == -1
+
+
+def _eq_bits(pre, pooled):
+    """Byte form of the DePool2D mask (include/iiseg.h, iiseg_conv_mask_f32) from host arrays."""
+    B, Cc, H, W = pre.shape
+    h2, w2 = H // 2, W // 2
+    m = np.zeros((B, Cc, h2, w2), np.uint8)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            eq = pre[:, :, dy:2 * h2:2, dx:2 * w2:2] == pooled
+            m |= (eq.astype(np.uint8) << (dy * 2 + dx))
+    return m
+
+
+@pytest.mark.parametrize('mma', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 5, 21, 19, 40, 3), (1, 12, 16, 70, 100, 1), (2, 8, 9, 9, 64, 5)])
+def test_conv_pool_mask_bytes_are_exact(ops, case, mma):
+    """Encoder side of the byte-mask DePool2D: conv + pool + mask_out with the pre-pool map NOT
+    stored gives the same pool as the pool-fused conv and exactly the bytes of pre == pooled; a
+    window writes only its pooling windows (full map and LICM-style windows)."""
+    B, Cin, H, W, Cout, pad = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x, w, b = rnd(rng, B, Cin, H, W), rnd(rng, Cout, Cin, 3, 3) * 0.3, rnd(rng, Cout)
+    conv = ops.Conv(w, b, pad=pad, relu=True, mma=mma)
+    if not (conv.pool_fusable() and conv.mask_ok()):
+        pytest.skip('halo kernels switched off')
+    fh, fw = conv.out_hw(H, W)
+    pooled = torch.empty((B, Cout, fh // 2, fw // 2), device='cuda')
+    full = conv(dev(x), pool_out=pooled)
+    ref_mask = _eq_bits(host(full), host(pooled))
+    pool2 = torch.full_like(pooled, -3.0)
+    mask = torch.full(pooled.shape, 0xAA, dtype=torch.uint8, device='cuda')
+    assert conv(dev(x), pool_out=pool2, mask_out=mask, store_out=False) is None
+    assert np.array_equal(host(pool2), host(pooled))
+    assert np.array_equal(mask.cpu().numpy(), ref_mask)
+    # with the pre-pool map stored as well
+    mask.fill_(0x55)
+    out = conv(dev(x), pool_out=pool2, mask_out=mask)
+    assert np.array_equal(host(out), host(full)) and np.array_equal(mask.cpu().numpy(), ref_mask)
+    for region in [(3, 5, 4, 6), (0, 1, fh, 3), (fh - 3, fw - 4, 3, 4), (2, 2, 1, 1)]:
+        y0, x0, h, ww = win = conv.pool_window(H, W, region)
+        pool2 = torch.full_like(pooled, -3.0)
+        mask = torch.full(pooled.shape, 0xAA, dtype=torch.uint8, device='cuda')
+        shape_only = torch.empty(full.shape, device='meta')
+        conv(dev(x), window=win, out=shape_only, place=(y0, x0), pool_out=pool2, mask_out=mask,
+             store_out=False)
+        exp_p = np.full(pooled.shape, -3.0, np.float32)
+        exp_m = np.full(pooled.shape, 0xAA, np.uint8)
+        q = (slice(None), slice(None), slice(y0 // 2, (y0 + h) // 2), slice(x0 // 2, (x0 + ww) // 2))
+        exp_p[q], exp_m[q] = host(pooled)[q], ref_mask[q]
+        assert np.array_equal(host(pool2), exp_p), region
+        assert np.array_equal(mask.cpu().numpy(), exp_m), region
+
+
+@pytest.mark.parametrize('mma', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 24, 20, 26, 40), (1, 64, 33, 41, 21), (2, 16, 14, 15, 8),
+                                  (1, 40, 64, 70, 64)])
+def test_unpool_conv_from_mask_bytes_is_bit_identical(ops, case, mma):
+    """Decoder side: the conv over the DePool2D of `up` takes the mask as bytes (mask_in) and gives
+    bit for bit what it gives from pre / pooled -- 32-row, 16-row (<= 16 output channels) and bf16
+    halo kernels, full maps, decoder windows, with and without the skip add; ties and all-equal
+    windows (several bits set) included."""
+    B, Cc, H, W, Cout = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    pre = np.maximum(rnd(rng, B, Cc, H, W), 0)                  # post-ReLU map: many exact ties at 0
+    h2, w2 = H // 2, W // 2
+    pooled = pre[:, :, :2 * h2, :2 * w2].reshape(B, Cc, h2, 2, w2, 2).max(axis=(3, 5))
+    up = rnd(rng, B, Cc, h2, w2)
+    w, b = rnd(rng, Cout, Cc, 3, 3) * 0.3, rnd(rng, Cout)
+    conv = ops.Conv(w, b, pad=1, relu=False, mma=mma)
+    if not conv.mask_ok():
+        pytest.skip('halo kernels switched off')
+    mask = torch.from_numpy(_eq_bits(pre, pooled)).cuda()
+    assert int((mask.cpu().numpy() == 15).sum()) > 0             # all-zero windows: every bit set
+    ref = conv(dev(up), pre=dev(pre), pooled=dev(pooled))
+    got = conv(dev(up), mask_in=mask, unpool_hw=(H, W))
+    assert np.array_equal(host(got), host(ref))
+    add = rnd(rng, B, Cout, H + 3, W + 2)
+    for (y0, x0, h, ww) in [(1, 2, 9, 11), (0, 0, H, 5), (H - 4, W - 7, 4, 7), (3, 3, 1, 1)]:
+        kw = dict(window=(y0, x0, h, ww), add=dev(add), add_off=(y0 + 1, x0))
+        ref = conv(dev(up), pre=dev(pre), pooled=dev(pooled), **kw)
+        got = conv(dev(up), mask_in=mask, unpool_hw=(H, W), **kw)
+        assert np.array_equal(host(got), host(ref)), (y0, x0, h, ww)
+
+
+def test_mask_bytes_are_refused_off_the_halo_kernels(ops):
+    """Layers that do not run on a halo kernel (Winograd, >= 256 output channels) say so instead
+    of silently taking another path."""
+    rng = np.random.default_rng(3)
+    conv = ops.Conv(rnd(rng, 256, 32, 3, 3), rnd(rng, 256), pad=1, relu=False)
+    assert not conv.mask_ok()
+    up = dev(rnd(rng, 1, 32, 4, 4))
+    with pytest.raises(RuntimeError):
+        conv(up, mask_in=torch.zeros((1, 32, 4, 4), dtype=torch.uint8, device='cuda'), unpool_hw=(8, 8))
