@@ -86,6 +86,13 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     uint4 (*Ws)[WCH] = reinterpret_cast<uint4 (*)[WCH]>(smem);
     uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + 2 * WCH);
 
+    // (experiment) co-resident workgroups start in lock step and stay there -- their load, MFMA and
+    // store phases then add up instead of overlapping; a one-time stagger of the first wave of
+    // workgroups (later ones start whenever a slot frees, which keeps the offset)
+    if (const int stag = p.debug_nogather >> 8; stag && blockIdx.x < 768) {
+        const int n = (int)((blockIdx.x >> 8) % 3) * stag;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     int pt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
     const int m0 = mt * BM;

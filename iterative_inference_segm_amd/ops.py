@@ -42,6 +42,9 @@ CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
 DEFAULT_MMA = os.environ.get('IISEG_MMA', 'f32')
 # bf16 mode: 3x3 layers at least this wide run on the bf16 Winograd kernels (conv_wino_bf16.hip)
 BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '128'))
+# both 16-bit forms possible for a layer: time them once per geometry (0: Winograd whenever it applies)
+BF16_TUNE = os.environ.get('IISEG_BF16_TUNE', '1') != '0'
+BF16_PICKS = {}
 BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
 BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '128'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
@@ -305,8 +308,34 @@ class Conv:
         # profiling: every launch is bracketed by events recorded IMMEDIATELY around the ctypes
         # call (after all planning / workspace work), so a bracket holds the kernel and nothing else
         prof = CONV_PROFILE
-        if not masked and pool_out is None and self.wino_bf16 and \
-                self.lib.iiseg_conv_wino_bf16_supported(C.byref(d)):
+        wino16 = not masked and pool_out is None and self.wino_bf16 and \
+            bool(self.lib.iiseg_conv_wino_bf16_supported(C.byref(d)))
+        if wino16 and BF16_TUNE and self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
+            # both 16-bit forms can run this layer: which one is faster depends on how the window
+            # quantises into 32-pixel tiles and on the channel counts (measured), so the
+            # first call of a (layer geometry, window size) times both -- once per process, shared by
+            # every Conv of the same shape so that equal launches make equal choices whatever the
+            # batch size (an image gets the same result alone and in a batch).  A recomputed window
+            # of a loop-invariant map may thus come from the other form than its border: both are
+            # within the same bf16 error model; the bit-identity of the work eliminations is an
+            # fp32 / f64 property (and holds here under IISEG_BF16_TUNE=0).
+            key = (self.Cin, self.Cout, C1, C2, H, W, unpool, d.OH, d.OW)
+            pick = BF16_PICKS.get(key)
+            if pick is None and not torch.cuda.is_current_stream_capturing():
+                forms = (lambda: self._call_wino_bf16(d, x1, x2, pre, pooled, add, out, None),
+                         lambda: self._call_halo_bf16(d, x1, x2, pre, pooled, add, out, None, None,
+                                                      None, None, B, H, W))
+                ms = []
+                for f in forms:
+                    f()                                       # packs the weights, warms up
+                    e0 = _ev(); f(); f(); f(); e1 = _ev()
+                    e1.synchronize()
+                    ms.append(e0.elapsed_time(e1))
+                pick = BF16_PICKS[key] = 'wino' if ms[0] <= ms[1] else 'halo'
+            if pick == 'halo':
+                return self._call_halo_bf16(d, x1, x2, pre, pooled, add, out, None, None, None, prof,
+                                            B, H, W)
+        if wino16:
             return self._call_wino_bf16(d, x1, x2, pre, pooled, add, out, prof)
         # (the DAE's last layer -- DePool2D input, <= 16 output channels: reading pre / pooled it is
         # read-bound and faster on the 16-row fp32 kernel, 0.60 vs 0.74 ms at configs[1]; from mask
@@ -314,26 +343,8 @@ class Conv:
         if self.halo_bf16 and \
                 not (unpool and self.Cout <= 16 and mask_in is None and not BF16_UPCONV1) and \
                 self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
-            if pool_out is not None:
-                fh, fw = self.out_hw(H, W)
-                if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2):
-                    raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
-            if self._W16 is None:
-                self._W16 = torch.empty(self.lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(d)) // 2,
-                                        dtype=torch.bfloat16, device=self.W.device)
-                check(self.lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(d), _ptr(self.W), self.so,
-                                                         self.sc, _ptr(self._W16, torch.bfloat16)),
-                      'iiseg_conv_halo_bf16_pack')
-            ev0 = _ev() if prof is not None else None
-            check(self.lib.iiseg_conv_halo_bf16(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
-                                                _ptr(pooled), _ptr(self._W16, torch.bfloat16),
-                                                _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out),
-                                                _ptr(mask_in, torch.uint8),
-                                                _ptr(mask_out, torch.uint8)),
-                  'iiseg_conv_halo_bf16')
-            if prof is not None:
-                prof.append(('conv_halo_bf16_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
-            return out
+            return self._call_halo_bf16(d, x1, x2, pre, pooled, add, out, pool_out, mask_in,
+                                        mask_out, prof, B, H, W)
         if not masked and pool_out is None and self.wino and \
                 self.lib.iiseg_conv_wino_supported(C.byref(d)):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
@@ -480,6 +491,30 @@ class Conv:
         if region[1] + region[3] == fw:
             x1 = fw
         return (y0, x0, y1 - y0, x1 - x0)
+
+    def _call_halo_bf16(self, d, x1, x2, pre, pooled, add, out, pool_out, mask_in, mask_out, prof,
+                        B, H, W):
+        """Direct 3x3 form on the bf16 matrix pipe (include/iiseg.h, iiseg_conv_halo_bf16)."""
+        if pool_out is not None:
+            fh, fw = self.out_hw(H, W)
+            if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2):
+                raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
+        if self._W16 is None:
+            self._W16 = torch.empty(self.lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(d)) // 2,
+                                    dtype=torch.bfloat16, device=self.W.device)
+            check(self.lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(d), _ptr(self.W), self.so,
+                                                     self.sc, _ptr(self._W16, torch.bfloat16)),
+                  'iiseg_conv_halo_bf16_pack')
+        ev0 = _ev() if prof is not None else None
+        check(self.lib.iiseg_conv_halo_bf16(_stream(), C.byref(d), _ptr(x1), _ptr(x2), _ptr(pre),
+                                            _ptr(pooled), _ptr(self._W16, torch.bfloat16),
+                                            _ptr(self.b), _ptr(add), _ptr(out), _ptr(pool_out),
+                                            _ptr(mask_in, torch.uint8),
+                                            _ptr(mask_out, torch.uint8)),
+              'iiseg_conv_halo_bf16')
+        if prof is not None:
+            prof.append(('conv_halo_bf16_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
+        return out
 
     def _call_wino_bf16(self, d, x1, x2, pre, pooled, add, out, prof):
         """bf16-operand Winograd form (include/iiseg.h, iiseg_conv_wino_bf16): input transform ->

@@ -1,4 +1,4 @@
-"""Times one conv layer (HIP events, reps launches).  Usage: time_layer.py cin cout H mma [batch] [window]"""
+"""Times one conv layer (HIP events, reps launches).  Usage: time_layer.py cin cout H mma [batch] [window] [origin]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,8 @@ W = torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * (2.0 / (cin * 9))
 b = torch.randn(cout, device='cuda', generator=g) * 0.1
 x = torch.rand(B, cin, H, H, device='cuda', generator=g)
 conv = ops.Conv(W, b, pad=1, relu=True, mma=mma)
-kw = dict(window=((H - win) // 2, (H - win) // 2, win, win)) if win else {}
+org = int(sys.argv[7]) if len(sys.argv) > 7 else (H - win) // 2
+kw = dict(window=(org, org, win, win)) if win else {}
 out = conv(x, **kw)
 torch.cuda._sleep(int(3e8))
 ops.CONV_PROFILE = prof = []

@@ -27,6 +27,15 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
 
 
+@pytest.fixture(autouse=True)
+def _one_kernel_per_layer(request, monkeypatch):
+    """The tests named *wino* pin the Winograd form: with the per-geometry choice between the two
+    16-bit forms (ops.BF16_TUNE) a layer could run the direct kernel instead."""
+    if 'wino' in request.node.name:
+        from iterative_inference_segm_amd import ops as _ops
+        monkeypatch.setattr(_ops, 'BF16_TUNE', False)
+
+
 @pytest.fixture(scope='module')
 def ops(built_lib):
     from iterative_inference_segm_amd import ops as _ops
@@ -353,3 +362,23 @@ def test_config3_densenet_runs_in_bf16(built_lib):
     Yii, iters, norms = ii16.refine(o16[:-1], o16[-1], 0.1, 10, early_stop=False)
     a = host(Yii)
     assert list(host(iters)) == [10] * 32 and a.min() >= 0 and a.max() <= 1 and np.isfinite(a).all()
+
+
+def test_bf16_form_choice_is_shared_and_batch_independent(ops, monkeypatch):
+    """Where both 16-bit forms can run a layer, the faster one is chosen once per (layer geometry,
+    window size): two Conv objects of the same shape make the same choice (so two engines agree bit
+    for bit), and so does the same layer on another batch size (an image alone == in a batch)."""
+    monkeypatch.setattr(ops, 'BF16_TUNE', True)
+    rng = np.random.default_rng(5)
+    B, Cin, H, W, Cout = 6, 128, 30, 34, 128
+    x = rng.random((B, Cin, H, W)).astype(np.float32)
+    Wt = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    c1, c2 = (ops.Conv(Wt, b, pad=1, relu=True, mma='bf16') for _ in range(2))
+    a = host(c1(dev(x)))
+    key = (Cin, Cout, Cin, 0, H, W, False, H, W)
+    assert ops.BF16_PICKS.get(key) in ('wino', 'halo')
+    assert np.array_equal(host(c2(dev(x))), a)
+    assert np.array_equal(host(c2(dev(x[2:3]))), a[2:3])
+    ref = onn.conv2d(x[:1].astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), pad=1, relu=True)
+    assert rel_rms(a[:1], ref) <= 6e-3
