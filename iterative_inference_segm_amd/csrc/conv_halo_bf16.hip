@@ -12,10 +12,17 @@
 // bf16 weights Wp16[kt][tap][h][co][8] streamed global -> LDS by 16-byte LDS-DMA.
 // Activations stay fp32 NCHW in HBM; fusions as in conv_halo.hip (bias / skip-add with crop / ReLU /
 // window / placement / channel slice, 2x2 max-pool in the epilogue).  Statistical parity only.
+// Measured dead ends (round 2, 128 -> 128 channels on 119^2 windows, 0.57 ms): 16-row tiles at two
+// workgroups per CU 6 % slower; a one-time stagger of co-resident workgroups no change.  PMC on that
+// launch: matrix pipe 20 % busy, 53 % of wave time parked on s_waitcnt / barriers, L2 hit 77 %, mean
+// L2 latency 335 cycles -- a chain of short dependent phases per 16-channel k-tile, not a bandwidth
+// limit; LDS operand reads one tap ahead of the MFMAs and wave-uniform scalar offsets (no waterfall
+// loops around the patch loads) bought 4-13 %.
 // Same Lasagne Conv2DLayer call sites (models/fcn8.py:34-45, models/fcn_down.py:102-104,
 // models/fcn_up.py:83-86; FC-DenseNet's BN_ReLU_Conv convs, models/FCDenseNet.py:90).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include <stdlib.h>
 #include "iiseg.h"
 #include "common.h"
@@ -86,13 +93,6 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     uint4 (*Ws)[WCH] = reinterpret_cast<uint4 (*)[WCH]>(smem);
     uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + 2 * WCH);
 
-    // (experiment) co-resident workgroups start in lock step and stay there -- their load, MFMA and
-    // store phases then add up instead of overlapping; a one-time stagger of the first wave of
-    // workgroups (later ones start whenever a slot frees, which keeps the offset)
-    if (const int stag = p.debug_nogather >> 8; stag && blockIdx.x < 768) {
-        const int n = (int)((blockIdx.x >> 8) % 3) * stag;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     int pt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
     const int m0 = mt * BM;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     // ---- patch staging: chunk e = i*256 + tid -> (channel half h, patch y, patch x) -------------
     unsigned voff[NE], voff2[UNPOOL ? NE : 1];
     int bsel[UNPOOL ? NE : 1];
-    int ch0[NE];                                  // first channel of the chunk inside the k-tile
+    int hbits = 0;                                // bit i: chunk i holds channels 8..15 of the k-tile
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = i * 256 + tid;
@@ -120,12 +120,14 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         const int py = rr / PW, px = rr - py * PW;
         const int iy = iy0 + py, ix = ix0 + px;
         bool ok = e < NCHK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ch0[i] = 8 * h;
-        voff[i] = ok ? 4u * (unsigned)(iy * p.W + ix) : OOB;
+        hbits |= h << i;
+        // (the chunk's channel half goes into the PER-LANE offset: the scalar offset of a load is
+        // then wave-uniform -- a lane-dependent one makes hipcc wrap every load in a waterfall loop)
+        voff[i] = ok ? 4u * (unsigned)(iy * p.W + ix + 8 * h * HW) : OOB;
         if constexpr (UNPOOL) {
             // DePool2D (layers/mylayers.py:95-114): only the 2h x 2w region has pooling windows
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
-            voff2[i] = ok ? 4u * (unsigned)((iy >> 1) * p.w2 + (ix >> 1)) : OOB;
+            voff2[i] = ok ? 4u * (unsigned)((iy >> 1) * p.w2 + (ix >> 1) + 8 * h * hw2) : OOB;
             bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
@@ -162,12 +164,12 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
-                const bool cok = ch0[i] + j < crem && !(p.debug_nogather & 2);                     \
-                const unsigned so = (unsigned)((cb + ch0[i] + j) * HW) * 4u;                       \
+                const bool cok = (((hbits >> i) & 1) * 8 + j) < crem && !(p.debug_nogather & 2);   \
+                const unsigned so = (unsigned)((cb + j) * HW) * 4u;                                \
                 if constexpr (!MASKIN)                                                             \
                     xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
                 if constexpr (UNPOOL) {                                                            \
-                    const unsigned so2 = (unsigned)((cb + ch0[i] + j) * hw2) * 4u;                 \
+                    const unsigned so2 = (unsigned)((cb + j) * hw2) * 4u;                          \
                     const unsigned vo2 = cok ? voff2[i] : OOB;                                     \
                     if constexpr (MASKIN)                                                          \
                         xq[i][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8( \
@@ -221,23 +223,36 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             HBF_LOAD_X(kt + 1)
         }
         __builtin_amdgcn_sched_barrier(0);
+        // operands of tap t+1 are read from LDS while the MFMAs of tap t run (two register sets)
+        uint4 a[2][TM], bq[2][TN];
+        auto lds_operands = [&](auto TAP, auto SET) __attribute__((always_inline)) {
+            constexpr int tap = decltype(TAP)::value, set = decltype(SET)::value;
+            constexpr int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[set][i] = Ws[buf][(tap * 2 + lh) * BM + wm * WTM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bq[set][j] = Ps[0][(lh * PH + lrow + j + ky) * PW + l31 + kx];
+        };
+        lds_operands(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
             constexpr int tap = decltype(TAP)::value;
-            constexpr int ky = tap / 3, kx = tap % 3;
-            uint4 a[TM], bq[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ws[buf][(tap * 2 + lh) * BM + wm * WTM + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bq[j] = Ps[0][(lh * PH + lrow + j + ky) * PW + l31 + kx];
+            if constexpr (tap + 1 < 9)
+                lds_operands(std::integral_constant<int, tap + 1>{},
+                             std::integral_constant<int, (tap + 1) & 1>{});
             if (!(p.debug_nogather & 4)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, bq[j]), acc[i][j],
-                        0, 0, 0);
+                        __builtin_bit_cast(bf16x8, a[tap & 1][i]),
+                        __builtin_bit_cast(bf16x8, bq[tap & 1][j]), acc[i][j], 0, 0, 0);
             }
+            // keep that order: the next tap's reads, then this tap's MFMAs
+            if constexpr (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         });
         __builtin_amdgcn_sched_barrier(0);
         if (more) {

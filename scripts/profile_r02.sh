@@ -8,10 +8,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r02/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-cpu-baseline --no-full-recompute --no-strict-f64 --no-bf16 --steps 3 --warmup 1"
+# two warm-up batches: the first primes the border stores, the second meets the steady-state windows
+# (in bf16 mode: times the two 16-bit forms on them once); `make_profiles.py steady ... 6` drops both
+B="$R/bench.py --no-cpu-baseline --no-full-recompute --no-strict-f64 --no-bf16 --steps 3 --warmup 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/f32 --output-format csv -- python3 $B > $O/f32.json 2> $O/f32.err
 IISEG_MMA=bf16 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/bf16 --output-format csv -- python3 $B > $O/bf16.json 2> $O/bf16.err
-B1="$R/bench.py --no-cpu-baseline --no-full-recompute --no-strict-f64 --no-bf16 --no-roofline --steps 1 --warmup 1"
+B1="$R/bench.py --no-cpu-baseline --no-full-recompute --no-strict-f64 --no-bf16 --no-roofline --steps 1 --warmup 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $B1 > $O/fetch.json 2> $O/fetch.err
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $B1 > $O/write.json 2> $O/write.err
 IISEG_GRAPH=0 timeout -k 10 300 rocprofv3 --hip-trace -d $O/hip_eager --output-format csv -- python3 $B1 > $O/hip_eager.json 2> $O/hip_eager.err
