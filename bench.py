@@ -388,8 +388,14 @@ def worker(args):
                     'note': 'consistency metric (random weights), reduced over ranks'}
     X, T = Xs[0], Ts[0]
     if not args.no_roofline:
+        from iterative_inference_segm_amd import ops as _ops
+        # (IISEG_MMA=bf16 forces the 16-bit operand path onto this leg too -- the profiling runs of
+        # scripts/profile_r02.sh do: the leg then says so and is priced against the bf16 peak)
+        main_bf16 = _ops.DEFAULT_MMA == 'bf16'
+        if main_bf16:
+            line['dtype'] = 'bf16 operands, f32 accumulate (IISEG_MMA=bf16)'
         rl = conv_roofline(ii, X, T, args.num_iter, args.step_size, ms_per_step,
-                           PEAK_TFLOPS_F32_MFMA)
+                           PEAK_TFLOPS_BF16_MFMA if main_bf16 else PEAK_TFLOPS_F32_MFMA)
         line['roofline'] = rl
         line['executed_gflop_per_image'] = round(rl['all_conv_gflop_per_step'] / B, 1)
 

@@ -556,11 +556,14 @@ def test_conv_pool_mask_bytes_are_exact(ops, case, mma):
 @pytest.mark.parametrize('mma', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', [(2, 24, 20, 26, 40), (1, 64, 33, 41, 21), (2, 16, 14, 15, 8),
                                   (1, 40, 64, 70, 64)])
-def test_unpool_conv_from_mask_bytes_is_bit_identical(ops, case, mma):
+def test_unpool_conv_from_mask_bytes_is_bit_identical(ops, case, mma, monkeypatch):
     """Decoder side: the conv over the DePool2D of `up` takes the mask as bytes (mask_in) and gives
     bit for bit what it gives from pre / pooled -- 32-row, 16-row (<= 16 output channels) and bf16
     halo kernels, full maps, decoder windows, with and without the skip add; ties and all-equal
-    windows (several bits set) included."""
+    windows (several bits set) included.  (bf16 mode, <= 16 output channels: by default the pre /
+    pooled form of such a layer runs the fp32 16-row kernel and only the byte form the bf16 one --
+    ops.py; here both are put on the bf16 kernel so that one kernel is compared with itself.)"""
+    monkeypatch.setattr(ops, 'BF16_UPCONV1', True)
     B, Cc, H, W, Cout = case
     rng = np.random.default_rng(hash(case) % 2**32)
     pre = np.maximum(rnd(rng, B, Cc, H, W), 0)                  # post-ReLU map: many exact ties at 0
