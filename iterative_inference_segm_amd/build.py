@@ -30,9 +30,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST = {}      # what the latest build() did: {'compiled': [...], 'reused': [...], 'linked': bool}
+
+
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libiiseg_hip.so.  Returns the path."""
+    """Compile every HIP source for gfx950 and link libiiseg_hip.so.  Returns the path.  Objects
+    newer than their source and the headers are reused unless `force`; `LAST` says what happened."""
     hipcc = _hipcc()
+    LAST.clear()
+    LAST.update(compiled=[], reused=[], linked=False)
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'),
@@ -50,6 +56,9 @@ def build(force=False, verbose=False):
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr))
+            LAST['compiled'].append(src)
+        else:
+            LAST['reused'].append(src)
         return o
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
@@ -59,6 +68,7 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr)
+        LAST['linked'] = True
     return LIB
 
 

@@ -10,6 +10,7 @@ FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled; WRI
 import collections
 import csv
 import glob
+import os
 import re
 import sys
 
@@ -27,7 +28,8 @@ def find(d, pat):
     f = glob.glob(d + '/**/*' + pat, recursive=True)
     if not f:
         raise SystemExit('no %s under %s' % (pat, d))
-    return f[0]
+    # (gpurun merges every call's output into the same scratch tree: take the latest run's file)
+    return max(f, key=os.path.getmtime)
 
 
 def stats(d, out, steady=False, nconf=3):
