@@ -40,13 +40,15 @@ CONV_GEMM = os.environ.get('IISEG_CONV_GEMM', '1') != '0'
 # default: the path with tolerance claims) or 'bf16' (bf16 operands, fp32 accumulation -- statistical
 # parity only; BASELINE north_star's 16-bit MFMA target).  Per-Conv `mma=` overrides the default.
 DEFAULT_MMA = os.environ.get('IISEG_MMA', 'f32')
-# bf16 mode: 3x3 layers at least this wide run on the bf16 Winograd kernels (conv_wino_bf16.hip)
-BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '128'))
+# bf16 mode: 3x3 layers at least this wide (input AND output channels) are candidates for the bf16
+# Winograd kernels (conv_wino_bf16.hip); below, the direct bf16 kernel won every measured case
+#  and also fuses the pool and the DePool2D byte masks
+BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '256'))
 # both 16-bit forms possible for a layer: time them once per geometry (0: Winograd whenever it applies)
 BF16_TUNE = os.environ.get('IISEG_BF16_TUNE', '1') != '0'
 BF16_PICKS = {}
 BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
-BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '128'))
+BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '256'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
 
 
@@ -472,7 +474,7 @@ class Conv:
         if self.dtype != torch.float32 or (self.KH, self.KW) != (3, 3) or self.dil != 1 or \
                 self.transposed or self.kernel != 'conv_halo_f32_kernel' or self.wino_bf16:
             return False
-        return not self.wino and (self.halo_bf16 or self.mma != 'bf16')
+        return self.halo_bf16 if self.mma == 'bf16' else not self.wino
 
     def pool_window(self, H, W, region=None):
         """If the 2x2 max-pool that follows this layer can be fused into its epilogue: the conv

@@ -31,8 +31,12 @@ def dev(a):
 def _one_kernel_per_layer(request, monkeypatch):
     """The tests named *wino* pin the Winograd form: with the per-geometry choice between the two
     16-bit forms (ops.BF16_TUNE) a layer could run the direct kernel instead."""
+    from iterative_inference_segm_amd import ops as _ops
+    if 'wino' in request.node.name or 'form_choice' in request.node.name:
+        # (by default layers below 256 channels go straight to the direct kernel)
+        monkeypatch.setattr(_ops, 'BF16_WINO_MIN_CIN', 128)
+        monkeypatch.setattr(_ops, 'BF16_WINO_MIN_COUT', 128)
     if 'wino' in request.node.name:
-        from iterative_inference_segm_amd import ops as _ops
         monkeypatch.setattr(_ops, 'BF16_TUNE', False)
 
 
@@ -308,7 +312,7 @@ def test_bf16_mode_statistical_parity_64_images(built_lib):
             FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=dtype, mma=mma),
             StandardDAE(dp, 11, dtype=dtype, mma=mma), 11, [11], dtype=dtype)
     ii16, ii64 = make(torch.float32, 'bf16'), make(torch.float64)
-    assert ii16.dae.enc['conv3_1'].wino_bf16 and ii16.dae.enc['conv2_1'].halo_bf16
+    assert ii16.dae.enc['conv4_1'].wino_bf16 and ii16.dae.enc['conv2_1'].halo_bf16
     cm = {k: np.zeros((11, 12)) for k in ('bf16', 'f64')}
     agree_fcn, agree_ii = [], []
     for i in range(4):                                   # 4 batches of 16 = 64 images
