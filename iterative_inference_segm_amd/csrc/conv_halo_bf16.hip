@@ -35,6 +35,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access, 4-byte aligned
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int RSRC_W3 = 0x00027000;
 constexpr unsigned OOB = 0x80000000u;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         const int iy = iy0 + py, ix = ix0 + px;
         bool ok = e < NCHK && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         hbits |= h << i;
+        if (p.debug_nogather & 2) ok = false;
         // (the chunk's channel half goes into the PER-LANE offset: the scalar offset of a load is
         // then wave-uniform -- a lane-dependent one makes hipcc wrap every load in a waterfall loop)
         voff[i] = ok ? 4u * (unsigned)(iy * p.W + ix + 8 * h * HW) : OOB;
@@ -155,7 +157,15 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
 
     // channels [c0, c0+16) of the logical (concatenated) input; the source is tile-uniform
     // (C1 % 16 == 0 when there are two sources); channels beyond the layer's read as zero
+    // FULL: all 16 channels of the k-tile exist (every k-tile but a ragged last one): no per-channel
+    // validity select in front of the loads
 #define HBF_LOAD_X(KT)                                                                             \
+    {                                                                                              \
+        const int c0_ = (KT) * CPT;                                                                \
+        const bool s1_ = UNPOOL || c0_ < C1;                                                       \
+        if ((s1_ ? C1 : Ctot) - c0_ >= CPT) { HBF_LOAD_X_(KT, true) } else { HBF_LOAD_X_(KT, false) } \
+    }
+#define HBF_LOAD_X_(KT, FULL)                                                                      \
     {                                                                                              \
         const int c0 = (KT) * CPT;                                                                 \
         const bool s1 = UNPOOL || c0 < C1;                                                         \
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
-                const bool cok = (((hbits >> i) & 1) * 8 + j) < crem && !(p.debug_nogather & 2);   \
+                const bool cok = (FULL) || (((hbits >> i) & 1) * 8 + j) < crem;                    \
                 const unsigned so = (unsigned)((cb + j) * HW) * 4u;                                \
                 if constexpr (!MASKIN)                                                             \
                     xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         __syncthreads();
     }
 #undef HBF_LOAD_X
+#undef HBF_LOAD_X_
 #undef HBF_STORE_X
 #undef HBF_LOAD_W
 
@@ -276,80 +287,104 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     // store instructions, whole 128-byte lines wherever the row start allows.
     // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh
     static_assert(WM == 1, "the staging tile holds all rows of one 32-channel block");
+    static_assert(TH == 8, "the store / pool passes below map a wave to one channel of the staged tile");
+    // All epilogue traffic goes through buffer descriptors of image b with 32-bit offsets computed
+    // ONCE per thread (stamped in-kernel, the first version of this epilogue spent 35-40 % of a
+    // workgroup's cycles here, mostly on per-piece 64-bit address arithmetic and bounds branches):
+    // out-of-range pieces get the out-of-bounds offset instead of a branch.
     float* Cs = reinterpret_cast<float*>(smem);
-    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
     if ((p.debug_nogather & 8) && acc[0][0][0] != 12345.f) return;
     const bool pooling = p.pool != nullptr;
+    const __amdgpu_buffer_rsrc_t r_bias = mk_rsrc(p.bias, p.bias ? p.Cout * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_out =
+        mk_rsrc(p.out ? p.out + (size_t)b * p.out_ctot * OPL : nullptr, p.out ? p.out_ctot * OPL * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_add =
+        mk_rsrc(p.add ? p.add + (size_t)b * p.Cout * APL : nullptr, p.add ? p.Cout * APL * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_pool =
+        mk_rsrc(pooling ? p.pool + (size_t)b * p.Cout * PPL : nullptr, pooling ? p.Cout * PPL * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_mask =
+        mk_rsrc(p.mask_out ? p.mask_out + (size_t)b * p.Cout * PPL : nullptr, p.mask_out ? p.Cout * PPL : 0);
+    const bool relu1 = p.relu && !p.add, relu2 = p.relu && p.add;   // (with a skip-add the ReLU comes
+                                                                    //  after the sum)
+    // store pass: thread -> (channel cl = 4 k + wave of the 32-channel block, row, 4-pixel piece)
+    const int s_row = lane >> 3, s_x4 = (lane & 7) * 4;
+    const int s_wy = wy0 + s_row, s_wx = wx0 + s_x4;
+    const int s_nv = min(4, p.OW - s_wx);
+    const bool s_ok = s_wy < p.OH && s_nv > 0;
+    const unsigned s_out0 = 4u * (unsigned)((p.out_c0 + m0 + wave) * OPL + (p.out_y0 + s_wy) * p.out_W +
+                                            p.out_x0 + s_wx);
+    const unsigned s_add0 = 4u * (unsigned)((m0 + wave) * APL + (p.ay0 + s_wy) * p.AW + p.ax0 + s_wx);
+    // pool pass: thread -> (channel cl = 4 k + wave, pooled row, pooled column) of the staged tile
+    const int q_row = lane >> 4, q_col = lane & 15;
+    const int q_wy = wy0 + 2 * q_row, q_wx = wx0 + 2 * q_col;
+    const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
+    const bool q_ok = pooling && q_wy + 1 < p.OH && q_wx + 1 < p.OW && q_py < p.pool_H && q_px < p.pool_W;
+    const unsigned q_off0 = (unsigned)((m0 + wave) * PPL + q_py * p.pool_W + q_px);   // elements
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        // bias of the 16 channels this lane holds in the MFMA C/D layout (0 beyond Cout / without bias)
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bv[r] = buf_ld(r_bias, 4u * (unsigned)(m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh), 0);
         __syncthreads();                       // previous users of these LDS bytes are done
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int co = m0 + i * 32 + cl;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[min(co, p.Cout - 1)];
-                // (with a skip-add the ReLU comes after the sum: applied by the store pass)
-                if (p.relu && !p.add) v = fmaxf(v, 0.f);
+                float v = acc[i][j][r] + bv[r];
+                if (relu1) v = fmaxf(v, 0.f);
                 Cs[(cl * TH + lrow + j) * 32 + l31] = v;
             }
         __syncthreads();
-        // 32 channels x TH rows x 8 pieces of 4 pixels
-        constexpr int NPC = 32 * TH * 8;
+        // 32 channels x TH rows x 8 pieces of 4 pixels: 8 passes, pass k handles channels 4k..4k+3
 #pragma unroll
-        for (int k = 0; k < NPC / 256; ++k) {
-            const int idx = k * 256 + tid;
-            const int cl = idx / (TH * 8), rem = idx - cl * (TH * 8);
-            const int row = rem >> 3, x4 = (rem & 7) * 4;
-            const int co = m0 + i * 32 + cl;
-            const int wy = wy0 + row, wx = wx0 + x4;
-            if (co >= p.Cout || wy >= p.OH || wx >= p.OW || !p.out) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (cl * TH + row) * 32 + x4);
-            float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0 + co) * OPL +
-                          (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-            const int nv = min(4, p.OW - wx);
+        for (int k = 0; k < 8; ++k) {
+            const int cl = 4 * k + wave;
+            const bool ok = s_ok && m0 + i * 32 + cl < p.Cout;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (cl * TH + s_row) * 32 + s_x4);
+            const unsigned oo = s_out0 + 4u * (unsigned)((i * 32 + 4 * k) * OPL);
+            const unsigned ao = s_add0 + 4u * (unsigned)((i * 32 + 4 * k) * APL);
             if (p.add) {
-                const float* addp = p.add + ((size_t)b * p.Cout + co) * APL +
-                                    (size_t)(p.ay0 + wy) * p.AW + p.ax0 + wx;
-                if (nv == 4) {
-                    const f32x4u a4 = *reinterpret_cast<const f32x4u*>(addp);
-                    v[0] += a4[0]; v[1] += a4[1]; v[2] += a4[2]; v[3] += a4[3];
-                } else {
-                    for (int e = 0; e < nv; ++e) v[e] += addp[e];
-                }
-                if (p.relu) {
-                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-                    v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_add, (int)((ok && s_nv == 4) ? ao : OOB), 0, 0));
+                v += a4;
+            }
+            if (ok && s_nv < 4) {              // ragged right edge of the window: element by element
+                for (int e = 0; e < s_nv; ++e) {
+                    float t = v[e];
+                    if (p.add) t += buf_ld(r_add, ao + 4u * e, 0);
+                    if (relu2) t = fmaxf(t, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), r_out,
+                                                          (int)(oo + 4u * e), 0, 0);
                 }
             }
-            if (nv == 4) *reinterpret_cast<f32x4u*>(outp) = f32x4u{v[0], v[1], v[2], v[3]};
-            else for (int e = 0; e < nv; ++e) outp[e] = v[e];
+            if (relu2) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out,
+                                                   (int)((ok && s_nv == 4) ? oo : OOB), 0, 0);
         }
         if (pooling) {
             // fused 2x2 max-pool of this 32-channel block from the staged tile: window origin and TH
             // are even, so the pairs (2m, 2m+1) of rows / columns are whole inside the tile; a
             // trailing unpaired row / column of the map has no pooling window (ignore_border)
-            const size_t PPL = (size_t)p.pool_H * p.pool_W;
-            constexpr int NPP = 32 * (TH / 2) * 16;
 #pragma unroll
-            for (int k = 0; k < NPP / 256; ++k) {
-                const int idx = k * 256 + tid;
-                const int cl = idx / ((TH / 2) * 16), rem = idx - cl * ((TH / 2) * 16);
-                const int prow = rem >> 4, pcol = rem & 15;
-                const int co = m0 + i * 32 + cl;
-                const int wy = wy0 + 2 * prow, wx = wx0 + 2 * pcol;
-                if (co >= p.Cout || wy + 1 >= p.OH || wx + 1 >= p.OW) continue;
-                const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
-                if (py >= p.pool_H || px >= p.pool_W) continue;
-                const float* c0 = Cs + (cl * TH + 2 * prow) * 32 + 2 * pcol;
+            for (int k = 0; k < 8; ++k) {
+                const int cl = 4 * k + wave;
+                const bool ok = q_ok && m0 + i * 32 + cl < p.Cout;
+                const float* c0 = Cs + (cl * TH + 2 * q_row) * 32 + 2 * q_col;
                 const float m = fmaxf(fmaxf(c0[0], c0[1]), fmaxf(c0[32], c0[33]));
-                p.pool[((size_t)b * p.Cout + co) * PPL + (size_t)py * p.pool_W + px] = m;
-                if (p.mask_out)      // bit (row & 1) * 2 + (col & 1): pre == pooled
-                    p.mask_out[((size_t)b * p.Cout + co) * PPL + (size_t)py * p.pool_W + px] =
-                        (unsigned char)((c0[0] == m ? 1u : 0u) | (c0[1] == m ? 2u : 0u) |
-                                        (c0[32] == m ? 4u : 0u) | (c0[33] == m ? 8u : 0u));
+                const unsigned po = q_off0 + (unsigned)((i * 32 + 4 * k) * PPL);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, m), r_pool,
+                                                      (int)(ok ? 4u * po : OOB), 0, 0);
+                // bit (row & 1) * 2 + (col & 1): pre == pooled  (no descriptor records without mask_out)
+                const unsigned bits = (c0[0] == m ? 1u : 0u) | (c0[1] == m ? 2u : 0u) |
+                                      (c0[32] == m ? 4u : 0u) | (c0[33] == m ? 8u : 0u);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, r_mask, (int)(ok ? po : OOB), 0, 0);
             }
         }
     }
@@ -396,6 +431,11 @@ int halo_bf16_check(const iiseg_conv_desc* d) {
     const int nkt = (d->C1 + d->C2 + CPT - 1) / CPT;
     const int bm = halo_bf16_bm(d->Cout), mpad = (d->Cout + bm - 1) / bm * bm;
     if ((int64_t)nkt * 18 * mpad * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    // the epilogue addresses one image's output / skip-add / pooled planes with 32-bit byte offsets
+    const int64_t octot = d->out_ctot ? d->out_ctot : d->Cout;
+    const int64_t opl = d->out_H ? (int64_t)d->out_H * d->out_W : (int64_t)d->OH * d->OW;
+    if ((octot + 64) * opl * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if (((int64_t)d->Cout + 64) * d->AH * d->AW * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     if ((int64_t)d->B * ((d->OH + 3) / 4) * ((d->OW + 31) / 32) * (mpad / 32) >= (1ll << 31))
         return IISEG_ERR_UNSUPPORTED;
     return IISEG_OK;
