@@ -28,6 +28,8 @@ namespace {
 
 constexpr int RSRC_W3 = 0x00027000;
 constexpr unsigned OOB = 0x80000000u;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const float* base, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
@@ -235,91 +237,131 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
 #undef HALO_W_DMA
 #undef HALO_W_ON
 
-    // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store ---------------------------
-    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh
-    const int wx = wx0 + l31;
-    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
-    if (p.pool) {
-        // fused 2x2 max-pool: a wave owns the row pairs (2m, 2m+1) of its rows (window origin and
-        // RW are even), the column pair is the neighbouring lane.  No lane leaves early here: the
-        // cross-lane max needs every lane; stores are predicated.
-        static_assert(TN % 2 == 0, "row pairs");
-        const size_t PPL = (size_t)p.pool_H * p.pool_W;
+    // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store, fused pool / mask bytes ----
+    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel x), row = (r&3) + 8*(r>>2) + 4*lh.
+    // Stored as it stands every store instruction writes 4 bytes per lane into two planes; stamped
+    // in-kernel that epilogue was 16-35 % of a workgroup's cycles (64 stores per thread with 64-bit
+    // address arithmetic and bounds branches each).  So the tile takes one trip through LDS (the
+    // weight ring's bytes, CHR channels at a time): Cs[c][row][x] <- acc (conflict-free: lanes are
+    // consecutive x), then every thread moves 16-byte pieces of whole rows through buffer descriptors
+    // of image b with 32-bit offsets computed once per thread; out-of-range pieces get the
+    // out-of-bounds offset instead of a branch.  Same values in the same order of operations.
+    constexpr int WSB = 2 * BK * BM * 4;                          // bytes of the weight ring
+    constexpr int CHR = WSB >= 32 * TH * 128 ? 32 : (WSB >= 16 * TH * 128 ? 16 : 8);
+    static_assert(CHR * TH * 128 <= WSB && 256 % (TH * 8) == 0, "staging tile must fit the weight ring");
+    constexpr int CPP = 256 / (TH * 8);                           // channels per store pass
+    constexpr int NSP = CHR / CPP;                                // store passes per round
+    constexpr int QPP = 256 / ((TH / 2) * 16);                    // channels per pool pass
+    constexpr int NQP = CHR / QPP;
+    float* Cs = &Ws[0][0][0];
+    const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
+    const bool pooling = p.pool != nullptr;
+    const __amdgpu_buffer_rsrc_t r_bias = mk_rsrc(p.bias, p.bias ? p.Cout * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_out =
+        mk_rsrc(p.out ? p.out + (size_t)b * p.out_ctot * OPL : nullptr, p.out ? p.out_ctot * OPL * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_add =
+        mk_rsrc(p.add ? p.add + (size_t)b * p.Cout * APL : nullptr, p.add ? p.Cout * APL * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_pool =
+        mk_rsrc(pooling ? p.pool + (size_t)b * p.Cout * PPL : nullptr, pooling ? p.Cout * PPL * 4 : 0);
+    const __amdgpu_buffer_rsrc_t r_mask = mk_rsrc_b(
+        p.mask_out ? p.mask_out + (size_t)b * p.Cout * PPL : nullptr, p.mask_out ? p.Cout * PPL : 0);
+    const bool relu1 = p.relu && !p.add, relu2 = p.relu && p.add;   // (with a skip-add the ReLU comes
+                                                                    //  after the sum)
+    // store pass: thread -> (channel s_c of the pass, row, 4-pixel piece)
+    const int s_c = tid / (TH * 8), s_rem = tid % (TH * 8);
+    const int s_row = s_rem >> 3, s_x4 = (s_rem & 7) * 4;
+    const int s_wy = wy0 + s_row, s_wx = wx0 + s_x4;
+    const int s_nv = min(4, p.OW - s_wx);
+    const bool s_ok = s_wy < p.OH && s_nv > 0;
+    const unsigned s_out0 = 4u * (unsigned)((p.out_c0 + m0 + s_c) * OPL + (p.out_y0 + s_wy) * p.out_W +
+                                            p.out_x0 + s_wx);
+    const unsigned s_add0 = 4u * (unsigned)((m0 + s_c) * APL + (p.ay0 + s_wy) * p.AW + p.ax0 + s_wx);
+    // pool pass: thread -> (channel q_c of the pass, pooled row, pooled column) of the staged tile
+    const int q_c = tid / ((TH / 2) * 16), q_rem = tid % ((TH / 2) * 16);
+    const int q_row = q_rem >> 4, q_col = q_rem & 15;
+    const int q_wy = wy0 + 2 * q_row, q_wx = wx0 + 2 * q_col;
+    const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
+    const bool q_ok = pooling && q_wy + 1 < p.OH && q_wx + 1 < p.OW && q_py < p.pool_H && q_px < p.pool_W;
+    const unsigned q_off0 = (unsigned)((m0 + q_c) * PPL + q_py * p.pool_W + q_px);   // elements
+    const int lrow = wn * RW;
 #pragma unroll
-        for (int j = 0; j < TN; j += 2) {
-            const int wy = wy0 + wn * RW + j;
-            const bool ok0 = wy < p.OH && wx < p.OW, ok1 = wy + 1 < p.OH && wx < p.OW;
-            float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
-                          (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-            const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
-            const bool okp = ok1 && wx + 1 < p.OW && !(l31 & 1) && py < p.pool_H && px < p.pool_W;
-            float* poolp = p.pool + (size_t)b * p.Cout * PPL + (size_t)py * p.pool_W + px;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float bias = p.bias ? p.bias[min(co, p.Cout - 1)] : 0.f;
-                    float v0 = acc[i][j][r] + bias, v1 = acc[i][j + 1][r] + bias;
-                    if (p.relu) {
-                        v0 = fmaxf(v0, 0.f);
-                        v1 = fmaxf(v1, 0.f);
-                    }
-                    const bool cv = co < p.Cout;
-                    if (p.out) {
-                        if (cv && ok0) outp[(size_t)co * OPL] = v0;
-                        if (cv && ok1) outp[(size_t)co * OPL + p.out_W] = v1;
-                    }
-                    float m = fmaxf(v0, v1);
-                    m = fmaxf(m, __shfl_xor(m, 1));
-                    if (cv && okp) poolp[(size_t)co * PPL] = m;
-                    if (p.mask_out) {
-                        // bit (row & 1) * 2 + (col & 1) of the window's byte: pre == pooled
-                        unsigned bits = (v0 == m ? (l31 & 1 ? 2u : 1u) : 0u) |
-                                        (v1 == m ? (l31 & 1 ? 8u : 4u) : 0u);
-                        bits |= __shfl_xor(bits, 1);
-                        if (cv && okp)
-                            p.mask_out[(size_t)b * p.Cout * PPL + (size_t)co * PPL +
-                                       (size_t)py * p.pool_W + px] = (unsigned char)bits;
-                    }
-                }
-        }
-        return;
-    }
-    if (wx >= p.OW) return;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int wy = wy0 + wn * RW + j;
-        if (wy >= p.OH) continue;
-        float* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
-                      (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
-        // skip-add / bias values first, all loads in flight together (unconditional, channel index
-        // clamped), then the stores: out and add may alias as far as the compiler knows, so loads
-        // interleaved with stores would serialise into one round trip each
-        float addv[TM][16];
-        if (p.add) {
-            const float* addp = p.add + (size_t)b * p.Cout * APL + (size_t)(p.ay0 + wy) * p.AW +
-                                p.ax0 + wx;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    addv[i][r] = addp[(size_t)min(co, p.Cout - 1) * APL];
-                }
-        }
+    for (int wmr = 0; wmr < WM; ++wmr)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[min(co, p.Cout - 1)];
-                if (p.add) v += addv[i][r];
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (co < p.Cout) outp[(size_t)co * OPL] = v;
+            for (int h = 0; h < 32 / CHR; ++h) {
+                // channels [cb, cb + CHR) of the workgroup's BM: registers r with 8*(r>>2) in the part
+                const int cb = wmr * WTM + i * 32 + h * CHR;
+                constexpr int RN = CHR / 2;                       // registers per part (CHR=8: 4, 16: 8, 32: 16)
+                float bv[RN];
+#pragma unroll
+                for (int rr = 0; rr < RN; ++rr) {
+                    const int r = h * RN + rr;
+                    bv[rr] = buf_ld(r_bias, 4u * (unsigned)(m0 + wmr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh), 0);
+                }
+                __syncthreads();                   // previous users of these LDS bytes are done
+                if (wm == wmr) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < RN; ++rr) {
+                            const int r = h * RN + rr;
+                            const int c = (r & 3) + 8 * (r >> 2) + 4 * lh - h * CHR;   // inside the part
+                            float v = acc[i][j][r] + bv[rr];
+                            if (relu1) v = fmaxf(v, 0.f);
+                            Cs[(c * TH + lrow + j) * 32 + l31] = v;
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < NSP; ++k) {
+                    const int c = CPP * k + s_c;
+                    const bool ok = s_ok && m0 + cb + c < p.Cout;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (c * TH + s_row) * 32 + s_x4);
+                    const unsigned oo = s_out0 + 4u * (unsigned)((cb + CPP * k) * OPL);
+                    const unsigned ao = s_add0 + 4u * (unsigned)((cb + CPP * k) * APL);
+                    if (p.add) {
+                        const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            r_add, (int)((ok && s_nv == 4) ? ao : OOB), 0, 0));
+                        v += a4;
+                    }
+                    if (ok && s_nv < 4) {          // ragged right edge of the window: element by element
+                        for (int e = 0; e < s_nv; ++e) {
+                            float t = v[e];
+                            if (p.add) t += buf_ld(r_add, ao + 4u * e, 0);
+                            if (relu2) t = fmaxf(t, 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t), r_out,
+                                                                  (int)(oo + 4u * e), 0, 0);
+                        }
+                    }
+                    if (relu2) {
+                        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+                        v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r_out,
+                                                           (int)((ok && s_nv == 4) ? oo : OOB), 0, 0);
+                }
+                if (pooling) {
+                    // fused 2x2 max-pool of these channels from the staged tile: window origin and TH
+                    // are even, so the pairs (2m, 2m+1) of rows / columns are whole inside the tile; a
+                    // trailing unpaired row / column of the map has no pooling window (ignore_border)
+#pragma unroll
+                    for (int k = 0; k < NQP; ++k) {
+                        const int c = QPP * k + q_c;
+                        const bool ok = q_ok && m0 + cb + c < p.Cout;
+                        const float* c0 = Cs + (c * TH + 2 * q_row) * 32 + 2 * q_col;
+                        const float m = fmaxf(fmaxf(c0[0], c0[1]), fmaxf(c0[32], c0[33]));
+                        const unsigned po = q_off0 + (unsigned)((cb + QPP * k) * PPL);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, m), r_pool,
+                                                              (int)(ok ? 4u * po : OOB), 0, 0);
+                        // bit (row & 1) * 2 + (col & 1): pre == pooled  (no records without mask_out)
+                        const unsigned bits = (c0[0] == m ? 1u : 0u) | (c0[1] == m ? 2u : 0u) |
+                                              (c0[32] == m ? 4u : 0u) | (c0[33] == m ? 8u : 0u);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, r_mask,
+                                                             (int)(ok ? po : OOB), 0, 0);
+                    }
+                }
             }
-    }
 }
 
 template <int BM, int TH, int WM, int WN>
@@ -346,7 +388,6 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
 // x 4 k), so a layer with 11 or 16 output channels fills 11/16 or 16/16 of the MFMA rows instead of
 // 11/32 or 16/32.  Lane = (pixel n = lane & 15, k sub-step kq = lane >> 4); the accumulation over k
 // is still sequential in k (4 at a time), results agree with the 32-row kernels to fp32 rounding.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int TH, bool UNPOOL, int DIL, bool BNRELU = false, bool MASKIN = false>
 __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParams p, const int tiles_y,
@@ -604,6 +645,9 @@ bool iiseg_conv_halo_ok(const ConvParams& p, int KH, int KW) {
     const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;
     if (cmax * p.H * p.W * 4 >= (1ll << 31)) return false;  // per-image 32-bit byte offsets
     if ((int64_t)p.B * ((p.OH + 3) / 4) * ((p.OW + 31) / 32) * (p.Mpad / 32) >= (1ll << 31)) return false;
+    // the epilogue addresses one image's output / skip-add planes with 32-bit byte offsets
+    if (((int64_t)p.out_ctot + 128) * p.out_H * p.out_W * 4 >= (1ll << 31)) return false;
+    if (p.add && ((int64_t)p.Cout + 128) * p.AH * p.AW * 4 >= (1ll << 31)) return false;
     return true;
 }
 
