@@ -153,28 +153,25 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     float xv[NE][8];
     float xq[UNPOOL ? NE : 1][8], xu[UNPOOL ? NE : 1][8];
     const int nkt = p.Kpad;                        // bf16 plan: Kpad holds the number of k-tiles
-    const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, nkt * 9 * 2 * p.Mpad * 16);
+    static_assert(WCH % 64 == 0, "a wave's DMA piece is whole");
+    const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, (p.debug_nogather & 1) ? 0 : nkt * 9 * 2 * p.Mpad * 16);
 
     // channels [c0, c0+16) of the logical (concatenated) input; the source is tile-uniform
     // (C1 % 16 == 0 when there are two sources); channels beyond the layer's read as zero
-    // FULL: all 16 channels of the k-tile exist (every k-tile but a ragged last one): no per-channel
-    // validity select in front of the loads
-#define HBF_LOAD_X(KT)                                                                             \
-    {                                                                                              \
-        const int c0_ = (KT) * CPT;                                                                \
-        const bool s1_ = UNPOOL || c0_ < C1;                                                       \
-        if ((s1_ ? C1 : Ctot) - c0_ >= CPT) { HBF_LOAD_X_(KT, true) } else { HBF_LOAD_X_(KT, false) } \
-    }
-#define HBF_LOAD_X_(KT, FULL)                                                                      \
+    // Branch-free on purpose, also past the last k-tile (every channel out of range: the loads return
+    // zeros without memory traffic).  HBF_LOAD_X_SLICE issues the loads n = 8 i + j of one slice
+    // [N0, N1): the main loop spreads the next k-tile's loads over the taps, between the MFMAs.
+#define HBF_LOAD_X(KT) HBF_LOAD_X_SLICE(KT, 0, NE * 8)
+#define HBF_LOAD_X_SLICE(KT, N0, N1)                                                               \
     {                                                                                              \
         const int c0 = (KT) * CPT;                                                                 \
         const bool s1 = UNPOOL || c0 < C1;                                                         \
         const int crem = (s1 ? C1 : Ctot) - c0;                                                    \
         const int cb = s1 ? c0 : c0 - C1;                                                          \
-        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
-            constexpr int i = decltype(I)::value;                                                  \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                        \
-                const bool cok = (FULL) || (((hbits >> i) & 1) * 8 + j) < crem;                    \
+        static_for<(N0), ((N1) < NE * 8 ? (N1) : NE * 8)>([&](auto N) __attribute__((always_inline)) { \
+            constexpr int i = decltype(N)::value / 8, j = decltype(N)::value % 8;                  \
+            {                                                                                      \
+                const bool cok = (((hbits >> i) & 1) * 8 + j) < crem;                              \
                 const unsigned so = (unsigned)((cb + j) * HW) * 4u;                                \
                 if constexpr (!MASKIN)                                                             \
                     xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
@@ -207,12 +204,15 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
                                                 pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));     \
     });
     // weights of k-tile KT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
+    // (the last, partial piece first and alone behind its wave-uniform test; the full pieces are
+    // unconditional so that they share a basic block with the patch loads and the MFMAs.  Past the
+    // last k-tile the offsets are out of the descriptor's range: zeros land in the idle ring half.)
 #define HBF_LOAD_W(KT, BUF)                                                                        \
     static_for<0, WPT>([&](auto J) __attribute__((always_inline)) {                                \
-        constexpr int j = decltype(J)::value;                                                      \
+        constexpr int j = WPT - 1 - decltype(J)::value;                                            \
         const int f = j * 256 + tid;                                                               \
         const int row = f / BM, col = f % BM;                                                      \
-        if (!(p.debug_nogather & 1) && ((j + 1) * 256 <= WCH || f < WCH))                          \
+        if ((j + 1) * 256 <= WCH || j * 256 + wave * 64 < WCH)                                     \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                              \
                 wrsrc, (__attribute__((address_space(3))) void*)(&Ws[BUF][0] + j * 256 + wave * 64), \
                 16, (int)(16u * (unsigned)(((KT) * 18 + row) * p.Mpad + m0 + col)), 0, 0, 0);      \
@@ -228,11 +228,10 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) {
-            HBF_LOAD_W(kt + 1, buf ^ 1)
-            HBF_LOAD_X(kt + 1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // The next k-tile's loads are spread over the nine taps, a slice between the LDS reads and
+        // the MFMAs of each (issued back to back in front of the MFMAs they took 2-4 thousand cycles
+        // per k-tile, stamped in-kernel -- longer than the MFMAs themselves), the weight DMA last:
+        // hipcc drains the DMA queue in front of any later LDS read, and after tap 8 there is none.
         // operands of tap t+1 are read from LDS while the MFMAs of tap t run (two register sets)
         uint4 a[2][TM], bq[2][TN];
         auto lds_operands = [&](auto TAP, auto SET) __attribute__((always_inline)) {
@@ -248,9 +247,12 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         lds_operands(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
             constexpr int tap = decltype(TAP)::value;
+            constexpr int NPT = (NE * 8 + 7) / 8;          // patch loads (i, j) per tap, taps 0..7
             if constexpr (tap + 1 < 9)
                 lds_operands(std::integral_constant<int, tap + 1>{},
                              std::integral_constant<int, (tap + 1) & 1>{});
+            if constexpr (tap < 8) HBF_LOAD_X_SLICE(kt + 1, tap * NPT, (tap + 1) * NPT)
+            if constexpr (tap == 8) HBF_LOAD_W(kt + 1, buf ^ 1)
             if (!(p.debug_nogather & 4)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -260,9 +262,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
                         __builtin_bit_cast(bf16x8, a[tap & 1][i]),
                         __builtin_bit_cast(bf16x8, bq[tap & 1][j]), acc[i][j], 0, 0, 0);
             }
-            // keep that order: the next tap's reads, then this tap's MFMAs
-            if constexpr (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            __builtin_amdgcn_sched_barrier(0);             // keep that order tap by tap
         });
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         __syncthreads();
     }
 #undef HBF_LOAD_X
-#undef HBF_LOAD_X_
+#undef HBF_LOAD_X_SLICE
 #undef HBF_STORE_X
 #undef HBF_LOAD_W
 
