@@ -73,11 +73,17 @@ __global__ void halo_pack_bf16_kernel(const float* __restrict__ w, int64_t so, i
 
 // MASKIN (with UNPOOL): DePool2D mask from bytes (ConvParams::mask_in) instead of pre == pooled
 template <int BM, int TH, int WM, int WN, bool UNPOOL, bool MASKIN = false>
-__global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(const ConvParams p, const int tiles_y,
+__global__ __launch_bounds__(256, (UNPOOL && !MASKIN) ? 2 : 3) void conv_halo_bf16_kernel(const ConvParams p, const int tiles_y,
                                                                 const int tiles_x) {
     constexpr int TW = 32, PH = TH + 2, PW = TW + 2, PP = PH * PW;
     constexpr int NCHK = 2 * PP;                  // patch chunks per k-tile
     constexpr int NE = (NCHK + 255) / 256;        // ... per thread
+    // MASKIN: a thread stages one POOLED position (8 channels of `up` + their 8 mask bytes, 16 loads)
+    // and writes the up to four patch chunks of its 2x2 block -- a third of the loads of the
+    // per-pixel form, which fetched every `up` value and mask byte once per pixel of the block
+    constexpr int QH = PH / 2 + 1, QW = PW / 2 + 1, QP = QH * QW;
+    static_assert(!MASKIN || 2 * QP <= 256, "one pooled position per thread");
+    constexpr int NL = MASKIN ? 1 : NE;           // (chunk, channel) load slots per thread / 8
     constexpr int WTM = BM / WM, TM = WTM / 32;
     constexpr int RW = TH / WN, TN = RW;          // output rows per wave = 32-pixel MFMA column tiles
     constexpr int WCH = 9 * 2 * BM;               // weight chunks per k-tile
@@ -133,6 +139,24 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
+    unsigned q_voff = OOB;
+    int q_slot[4] = {-1, -1, -1, -1}, q_h = 0;
+    if constexpr (MASKIN) {
+        q_h = tid / QP;
+        const int qr = tid - q_h * QP, qy = qr / QW, qx = qr - qy * QW;
+        const int Y2 = (iy0 >> 1) + qy, X2 = (ix0 >> 1) + qx;       // (arithmetic shifts: floor)
+        const bool qin = tid < 2 * QP;
+        // DePool2D (layers/mylayers.py:95-114): outside the h2 x w2 pooled map there is no window
+        // (padding, the odd trailing row / column): the chunks written there are zero
+        if (qin && (unsigned)Y2 < (unsigned)p.h2 && (unsigned)X2 < (unsigned)p.w2 && !(p.debug_nogather & 2))
+            q_voff = 4u * (unsigned)(Y2 * p.w2 + X2 + 8 * q_h * hw2);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int py = 2 * Y2 + (sl >> 1) - iy0, px = 2 * X2 + (sl & 1) - ix0;
+            if (qin && (unsigned)py < (unsigned)PH && (unsigned)px < (unsigned)PW)
+                q_slot[sl] = (q_h * PH + py) * PW + px;
+        }
+    }
     const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
     // one image per tile: descriptors start at image b of each source
     const float* base1 = (UNPOOL && !MASKIN) ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
@@ -151,7 +175,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float xv[NE][8];
-    float xq[UNPOOL ? NE : 1][8], xu[UNPOOL ? NE : 1][8];
+    float xq[UNPOOL ? NL : 1][8], xu[UNPOOL ? NL : 1][8];
     const int nkt = p.Kpad;                        // bf16 plan: Kpad holds the number of k-tiles
     static_assert(WCH % 64 == 0, "a wave's DMA piece is whole");
     const __amdgpu_buffer_rsrc_t wrsrc = mk_rsrc(p.wp, (p.debug_nogather & 1) ? 0 : nkt * 9 * 2 * p.Mpad * 16);
@@ -161,23 +185,23 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
     // Branch-free on purpose, also past the last k-tile (every channel out of range: the loads return
     // zeros without memory traffic).  HBF_LOAD_X_SLICE issues the loads n = 8 i + j of one slice
     // [N0, N1): the main loop spreads the next k-tile's loads over the taps, between the MFMAs.
-#define HBF_LOAD_X(KT) HBF_LOAD_X_SLICE(KT, 0, NE * 8)
+#define HBF_LOAD_X(KT) HBF_LOAD_X_SLICE(KT, 0, NL * 8)
 #define HBF_LOAD_X_SLICE(KT, N0, N1)                                                               \
     {                                                                                              \
         const int c0 = (KT) * CPT;                                                                 \
         const bool s1 = UNPOOL || c0 < C1;                                                         \
         const int crem = (s1 ? C1 : Ctot) - c0;                                                    \
         const int cb = s1 ? c0 : c0 - C1;                                                          \
-        static_for<(N0), ((N1) < NE * 8 ? (N1) : NE * 8)>([&](auto N) __attribute__((always_inline)) { \
+        static_for<((N0) < NL * 8 ? (N0) : NL * 8), ((N1) < NL * 8 ? (N1) : NL * 8)>([&](auto N) __attribute__((always_inline)) { \
             constexpr int i = decltype(N)::value / 8, j = decltype(N)::value % 8;                  \
             {                                                                                      \
-                const bool cok = (((hbits >> i) & 1) * 8 + j) < crem;                              \
+                const bool cok = ((MASKIN ? q_h : ((hbits >> i) & 1)) * 8 + j) < crem;             \
                 const unsigned so = (unsigned)((cb + j) * HW) * 4u;                                \
                 if constexpr (!MASKIN)                                                             \
                     xv[i][j] = buf_ld(mk_rsrc(s1 ? base1 : base2, s1 ? n1 : n2), cok ? voff[i] : OOB, so); \
                 if constexpr (UNPOOL) {                                                            \
                     const unsigned so2 = (unsigned)((cb + j) * hw2) * 4u;                          \
-                    const unsigned vo2 = cok ? voff2[i] : OOB;                                     \
+                    const unsigned vo2 = cok ? (MASKIN ? q_voff : voff2[i]) : OOB;                 \
                     if constexpr (MASKIN)                                                          \
                         xq[i][j] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b8( \
                             mk_rsrc(basem, nq >> 2), (int)(vo2 == OOB ? OOB : vo2 >> 2), (int)(so2 >> 2), 0)); \
@@ -189,6 +213,17 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         });                                                                                        \
     }
 #define HBF_STORE_X(BUF)                                                                           \
+    if constexpr (MASKIN) {                                                                        \
+        _Pragma("unroll") for (int sl = 0; sl < 4; ++sl) {                                         \
+            /* bit (row & 1) * 2 + (col & 1) of the window's byte: pre == pooled */                \
+            float v[8];                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                          \
+                v[j] = ((__builtin_bit_cast(unsigned, xq[0][j]) >> sl) & 1u) ? xu[0][j] : 0.f;     \
+            if (q_slot[sl] >= 0)                                                                   \
+                Ps[BUF][q_slot[sl]] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),     \
+                                                 pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));    \
+        }                                                                                          \
+    } else                                                                                         \
     static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
         constexpr int i = decltype(I)::value;                                                      \
         float v[8];                                                                                \
@@ -247,7 +282,7 @@ __global__ __launch_bounds__(256, UNPOOL ? 2 : 3) void conv_halo_bf16_kernel(con
         lds_operands(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
             constexpr int tap = decltype(TAP)::value;
-            constexpr int NPT = (NE * 8 + 7) / 8;          // patch loads (i, j) per tap, taps 0..7
+            constexpr int NPT = (NL * 8 + 7) / 8;          // patch loads (i, j) per tap, taps 0..7
             if constexpr (tap + 1 < 9)
                 lds_operands(std::integral_constant<int, tap + 1>{},
                              std::integral_constant<int, (tap + 1) & 1>{});
