@@ -58,6 +58,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
     constexpr int RW = TH / WN, TN = RW;      // output rows per wave = 32-pixel MFMA column tiles
     constexpr int WVEC = BK * BM / 4, WPT = (WVEC + 255) / 256;
     static_assert(WM * WN == 4 && TH % WN == 0 && BM % (WM * 32) == 0 && WPT <= 5, "tile config");
+    // MASKIN: a thread stages POOLED positions (`up` value + mask byte, 2 loads) and writes the up
+    // to four patch elements of the 2x2 block -- a third of the loads of the per-pixel form
+    constexpr int QH = PH / 2 + 1, QW = PW / 2 + 1, QP = QH * QW, QE = CPT * QP;
+    constexpr int NQ = (QE + 255) / 256;
+    static_assert(NQ <= NE, "staging registers");
 
     __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Ps[2][NE * 256];
@@ -97,6 +102,29 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
             bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
+    unsigned qv[MASKIN ? NQ : 1];
+    int qs[MASKIN ? NQ : 1][4], qc[MASKIN ? NQ : 1];
+    if constexpr (MASKIN) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = i * 256 + tid;
+            const int c = e / QP, r = e - c * QP;
+            const int qy = r / QW, qx = r - qy * QW;
+            const int Y2 = (iy0 >> 1) + qy, X2 = (ix0 >> 1) + qx;       // (arithmetic shifts: floor)
+            const bool in = e < QE;
+            qc[i] = c;
+            // DePool2D (layers/mylayers.py:95-114): outside the h2 x w2 pooled map there is no
+            // window (padding, the odd trailing row / column): the elements written there are zero
+            qv[i] = (in && (unsigned)Y2 < (unsigned)p.h2 && (unsigned)X2 < (unsigned)p.w2)
+                        ? 4u * (unsigned)(c * hw2 + Y2 * p.w2 + X2) : OOB;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int py = 2 * Y2 + (sl >> 1) - iy0, px = 2 * X2 + (sl & 1) - ix0;
+                qs[i][sl] = (in && (unsigned)py < (unsigned)PH && (unsigned)px < (unsigned)PW)
+                                ? c * PP + py * PW + px : -1;
+            }
+        }
+    }
     // one image per tile: descriptors start at image b of each source
     const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
     const float* base1 = (UNPOOL && !MASKIN) ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
@@ -124,7 +152,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
 #define HALO_LOAD_X(KT, BUF)                                                                       \
     {                                                                                              \
         const int c0 = (KT) * CPT;                                                                 \
-        if constexpr (UNPOOL) {                                                                    \
+        if constexpr (MASKIN) {                                                                    \
+            const int crem = C1 - c0;                                                              \
+            static_for<0, NQ>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const unsigned vo2 = qc[i] < crem ? qv[i] : OOB;                                   \
+                xq[i] = __builtin_bit_cast(float, buf_ld_u8(mk_rsrc_b(basem, nq >> 2),             \
+                                                            vo2 == OOB ? OOB : vo2 >> 2,           \
+                                                            (unsigned)(c0 * hw2)));                \
+                xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+            });                                                                                    \
+        } else if constexpr (UNPOOL) {                                                             \
             const int crem = C1 - c0;                                                              \
             static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
                 constexpr int i = decltype(I)::value;                                              \
@@ -155,7 +193,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
         }                                                                                          \
     }
 #define HALO_STORE_X(BUF)                                                                          \
-    if constexpr (UNPOOL) {                                                                        \
+    if constexpr (MASKIN) {                                                                        \
+        static_for<0, NQ>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            /* bit (row & 1) * 2 + (col & 1) of the window's byte: pre == pooled */                \
+            _Pragma("unroll") for (int sl = 0; sl < 4; ++sl)                                       \
+                if (qs[i][sl] >= 0)                                                                \
+                    Ps[BUF][qs[i][sl]] =                                                           \
+                        ((__builtin_bit_cast(unsigned, xq[i]) >> sl) & 1u) ? xu[i] : 0.f;          \
+        });                                                                                        \
+    } else if constexpr (UNPOOL) {                                                                 \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             /* padding / odd trailing row+col read 0 == 0 -> up, which is also 0 there */          \
