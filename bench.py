@@ -246,10 +246,15 @@ def launch_workers(args, argv):
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
     line = None
     for out in proc.stdout:
-        sys.stdout.write(out)
-        sys.stdout.flush()
+        # stdout carries ONE line, the result; whatever else the workers or their libraries print
+        # there (e.g. gloo's connection notes) goes to stderr
         if out.lstrip().startswith('{"metric"'):
             line = out
+            sys.stdout.write(out)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(out)
+            sys.stderr.flush()
     rc = proc.wait()
     if rc == 0 and line is None:
         sys.stderr.write('bench.py: workers exited without a result line\n')
