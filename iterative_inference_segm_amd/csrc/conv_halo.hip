@@ -451,6 +451,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
     constexpr int RW = TH / 4, TN = 2 * RW;     // 16-pixel column tiles per wave
     constexpr int WVEC = BK * BM / 4;           // 144 float4 per weight tile
     static_assert(TH % 4 == 0 && WVEC <= 256, "tile config");
+    // MASKIN: pooled-position staging as in conv_halo_f32_kernel (2 loads per 2x2 block, not 8)
+    constexpr int QH = PH / 2 + 1, QW = PW / 2 + 1, QP = QH * QW, QE = CPT * QP;
+    constexpr int NQ = (QE + 255) / 256;
+    static_assert(!MASKIN || (NQ <= NE && DIL == 1), "staging registers");
 
     __shared__ __attribute__((aligned(16))) float Ws[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Ps[2][NE * 256];
@@ -487,6 +491,27 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
             bsel[i] = ((iy & 1) << 1) | (ix & 1);
         }
     }
+    unsigned qv[MASKIN ? NQ : 1];
+    int qs[MASKIN ? NQ : 1][4], qc[MASKIN ? NQ : 1];
+    if constexpr (MASKIN) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = i * 256 + tid;
+            const int c = e / QP, r = e - c * QP;
+            const int qy = r / QW, qx = r - qy * QW;
+            const int Y2 = (iy0 >> 1) + qy, X2 = (ix0 >> 1) + qx;       // (arithmetic shifts: floor)
+            const bool in = e < QE;
+            qc[i] = c;
+            qv[i] = (in && (unsigned)Y2 < (unsigned)p.h2 && (unsigned)X2 < (unsigned)p.w2)
+                        ? 4u * (unsigned)(c * hw2 + Y2 * p.w2 + X2) : OOB;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int py = 2 * Y2 + (sl >> 1) - iy0, px = 2 * X2 + (sl & 1) - ix0;
+                qs[i][sl] = (in && (unsigned)py < (unsigned)PH && (unsigned)px < (unsigned)PW)
+                                ? c * PP + py * PW + px : -1;
+            }
+        }
+    }
     const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
     const float* base1 = (UNPOOL && !MASKIN) ? p.pre + (size_t)b * C1 * HW
                                 : p.x1 + (size_t)b * (p.in_bstride ? (size_t)p.in_bstride : (size_t)C1 * HW);
@@ -510,7 +535,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
 #define H16_LOAD_X(KT, BUF)                                                                        \
     {                                                                                              \
         const int c0 = (KT) * CPT;                                                                 \
-        if constexpr (UNPOOL) {                                                                    \
+        if constexpr (MASKIN) {                                                                    \
+            const int crem = C1 - c0;                                                              \
+            static_for<0, NQ>([&](auto I) __attribute__((always_inline)) {                         \
+                constexpr int i = decltype(I)::value;                                              \
+                const unsigned vo2 = qc[i] < crem ? qv[i] : OOB;                                   \
+                xq[i] = __builtin_bit_cast(float, buf_ld_u8(mk_rsrc_b(basem, nq >> 2),             \
+                                                            vo2 == OOB ? OOB : vo2 >> 2,           \
+                                                            (unsigned)(c0 * hw2)));                \
+                xu[i] = buf_ld(mk_rsrc(baseu, nq), vo2, (unsigned)(c0 * hw2) * 4u);                \
+            });                                                                                    \
+        } else if constexpr (UNPOOL) {                                                             \
             const int crem = C1 - c0;                                                              \
             static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                         \
                 constexpr int i = decltype(I)::value;                                              \
@@ -560,7 +595,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
             Ps[BUF][i * 256 + tid] = (cbn[i] >= 0 && v > 0.f) ? v : 0.f;                           \
         });                                                                                        \
     }                                                                                              \
-    if constexpr (UNPOOL) {                                                                        \
+    if constexpr (MASKIN) {                                                                        \
+        static_for<0, NQ>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            _Pragma("unroll") for (int sl = 0; sl < 4; ++sl)                                       \
+                if (qs[i][sl] >= 0)                                                                \
+                    Ps[BUF][qs[i][sl]] =                                                           \
+                        ((__builtin_bit_cast(unsigned, xq[i]) >> sl) & 1u) ? xu[i] : 0.f;          \
+        });                                                                                        \
+    } else if constexpr (UNPOOL) {                                                                 \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             if constexpr (MASKIN)                                                                  \
