@@ -596,7 +596,11 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const Wi
     }
 #undef WINO_STAGE
 
-    // epilogue: rows of the C/D layout are channels, columns (lane & 31) are tiles
+    // epilogue: rows of the C/D layout are channels, columns (lane & 31) are tiles.  A tile's two
+    // pixels of a row go out as ONE 8-byte store (lanes are consecutive tiles: 256 contiguous bytes
+    // per 32 lanes) wherever both columns are inside the window; the channel offsets are formed once
+    // per (i, r) from 32-bit products.
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
     const int ntt = p.nty * p.ntx;
     const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
 #pragma unroll
@@ -607,10 +611,9 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const Wi
         const int rr = t - b * ntt;
         const int tyl = rr / p.ntx, txl = rr - tyl * p.ntx;
         const int wy = p.ty0 + 2 * tyl - p.oy0, wx = p.tx0 + 2 * txl - p.ox0;
-        const bool ok[4] = {(unsigned)wy < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
-                            (unsigned)wy < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW,
-                            (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)wx < (unsigned)p.OW,
-                            (unsigned)(wy + 1) < (unsigned)p.OH && (unsigned)(wx + 1) < (unsigned)p.OW};
+        const bool rok[2] = {(unsigned)wy < (unsigned)p.OH, (unsigned)(wy + 1) < (unsigned)p.OH};
+        const bool cok[2] = {(unsigned)wx < (unsigned)p.OW, (unsigned)(wx + 1) < (unsigned)p.OW};
+        const bool pair = cok[0] && cok[1];
         float* ob = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
                     (ptrdiff_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
         const float* ab = p.add ? p.add + (size_t)b * p.Cout * APL +
@@ -623,13 +626,35 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const Wi
                 const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Cout) continue;
                 const float bias = p.bias ? p.bias[co] : 0.f;
+                float* oc = ob + (size_t)co * OPL;
+                const float* ac = ab ? ab + (size_t)co * APL : nullptr;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!ok[q]) continue;
-                    float v = Y[q][i][j][r] + bias;
-                    if (ab) v += ab[(size_t)co * APL + (q >> 1) * p.AW + (q & 1)];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    ob[(size_t)co * OPL + (size_t)(q >> 1) * p.out_W + (q & 1)] = v;
+                for (int a = 0; a < 2; ++a) {
+                    if (!rok[a]) continue;
+                    float v0 = Y[2 * a][i][j][r] + bias, v1 = Y[2 * a + 1][i][j][r] + bias;
+                    if (pair) {
+                        if (ac) {
+                            const f32x2u a2 = *reinterpret_cast<const f32x2u*>(ac + a * p.AW);
+                            v0 += a2[0];
+                            v1 += a2[1];
+                        }
+                        if (p.relu) {
+                            v0 = fmaxf(v0, 0.f);
+                            v1 = fmaxf(v1, 0.f);
+                        }
+                        *reinterpret_cast<f32x2u*>(oc + (size_t)a * p.out_W) = f32x2u{v0, v1};
+                    } else {
+                        if (cok[0]) {
+                            if (ac) v0 += ac[a * p.AW];
+                            if (p.relu) v0 = fmaxf(v0, 0.f);
+                            oc[(size_t)a * p.out_W] = v0;
+                        }
+                        if (cok[1]) {
+                            if (ac) v1 += ac[a * p.AW + 1];
+                            if (p.relu) v1 = fmaxf(v1, 0.f);
+                            oc[(size_t)a * p.out_W + 1] = v1;
+                        }
+                    }
                 }
             }
     }
