@@ -251,15 +251,19 @@ __global__ __launch_bounds__(NT) void wino_input_lds_kernel(const WinoParams p, 
             const float* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
             const float* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
             const float* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
+            // all three loads of every staged element unconditionally (offsets of elements outside
+            // the 2h x 2w region clamped to 0 and masked afterwards): one batch in flight instead
+            // of a dependent branch per element
+            float pv[ILDS_E], pq[ILDS_E], uq[ILDS_E];
 #pragma unroll
             for (int i = 0; i < ILDS_E; ++i) {
-                float r = 0.f;
-                if (qoff[i] >= 0) {
-                    const float pv = prep[goff[i]], pq = poolp[qoff[i]], uq = upp[qoff[i]];
-                    r = pv == pq ? uq : 0.f;
-                }
-                v[i] = r;
+                const int go = qoff[i] >= 0 ? goff[i] : 0, qo = qoff[i] >= 0 ? qoff[i] : 0;
+                pv[i] = prep[go];
+                pq[i] = poolp[qo];
+                uq[i] = upp[qo];
             }
+#pragma unroll
+            for (int i = 0; i < ILDS_E; ++i) v[i] = (qoff[i] >= 0 && pv[i] == pq[i]) ? uq[i] : 0.f;
         } else {
             const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
                                         : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
