@@ -169,6 +169,8 @@ class IterativeInference:
         """
         H_in = list(H) if isinstance(H, (list, tuple)) else [H]
         want_graph = GRAPH_MODE if graph is None else ('1' if graph else '0')
+        if inplace:
+            want_graph = '0'    # the graph path works on its own static copy of y
         if want_graph != '0' and mode == 'residual' and per_iter_target is None and \
                 hasattr(self.dae, 'new_session') and int(num_iter) >= 3 and torch.cuda.is_available():
             # 'auto': a capture costs about as much as the launches it saves in one short loop, so
@@ -258,9 +260,9 @@ class IterativeInference:
         for dst, src in zip(H, H_src):
             dst.copy_(src)
         st.reset()
+        if hasattr(self.dae, 'keep_pre'):
+            self.dae.keep_pre = False        # (a gradient-mode call before this one leaves it set)
         sess = self.dae.new_session(H, y, tags=tags)
-        if sess is None or ctx['sess'] is not sess:   # another session: its buffers are other memory
-            ctx['graph'], ctx['sess'] = None, sess
         dae_scores = (lambda: self.dae.scores(H, y, session=sess)) if sess is not None else \
             (lambda: self.dae.scores(H, y))
 
@@ -271,6 +273,12 @@ class IterativeInference:
             return score
 
         score = dae_scores()                                     # step 0, eager
+        # The captured step is valid only for the launch structure and the buffers it was captured
+        # on.  Step 0 has just run on the CURRENT ones (it re-primes the session when the masked-level
+        # set, trace / keep_pre, ... changed since the last call), so the fingerprint is taken here.
+        fp = (id(sess), self._launch_fingerprint(sess))
+        if ctx.get('fingerprint') != fp:
+            ctx['graph'], ctx['fingerprint'] = None, fp
         r0 = _ops.crop_softmax(score, y.shape[2], y.shape[3], off=(0, 0)) if first_reconstruction \
             else None
         _ops.refine_update(score, y, st, step, off=(0, 0))
@@ -288,15 +296,33 @@ class IterativeInference:
                 _ops.CONV_PROFILE = prof
                 ctx['graph'] = g
                 # scratch the captured launches point at must outlive the graph
-                ctx['keep'] = (_ops._wino_ws.get(y.device),)
+                ctx['keep'] = (_ops._wino_ws.get(y.device), sess)
         g = ctx['graph']
         while it < num_iter:
             g.replay()
             it += 1
+            # per-image early stop (iterative_inference.py:275-277): once every image is frozen the
+            # remaining replays would change nothing.  One 4-byte read every 4th replay, only when
+            # the stop test is on.
+            if eps_eff >= 0 and it < num_iter and (it & 3) == 0 and not bool(st.active.any()):
+                break
         res = (y.clone(), st.iters.clone(), st.last_norm.clone())
         if first_reconstruction:
             res = res + (r0,)
         return res
+
+    def _launch_fingerprint(self, sess):
+        """What a captured refinement step depends on besides shapes: the DAE's launch-structure
+        switches and the identity of the session buffers the launches point into."""
+        dae = self.dae
+        knobs = tuple(getattr(dae, k, None) for k in
+                      ('dce', 'licm', 'fold_border', 'fuse_unpool', 'use_masks', 'keep_pre',
+                       'emulate_noise', 'mma')) + (getattr(dae, 'trace', None) is not None,)
+        if not isinstance(sess, dict):
+            return knobs
+        bufs = tuple(sorted((k, v.data_ptr()) for k, v in sess.items()
+                            if isinstance(v, torch.Tensor) and v.device.type != 'meta'))
+        return knobs + (sess.get('masked'), sess.get('gen'), bufs)
 
     def _dev(self, a):
         if isinstance(a, torch.Tensor):

@@ -3,6 +3,7 @@
 `python -m iterative_inference_segm_amd.build` or `__graft_entry__.build()`.  hipcc
 cross-compiles without a GPU; the .so is git-ignored but travels with the tree.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -23,19 +24,50 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(paths, extra=()):
+    """Content key of a build product: sha256 over the bytes of its inputs (NOT their mtimes: a
+    checkout or a copy to the GPU box does not preserve those), the flags and the compiler version."""
+    h = hashlib.sha256()
+    for e in extra:
+        h.update(str(e).encode() + b'\0')
+    for q in paths:
+        with open(q, 'rb') as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    return h.hexdigest()
+
+
+def _stale(target, key):
+    """True unless `target` exists and the key stored next to it equals `key`."""
+    try:
+        with open(target + '.key') as f:
+            return not os.path.exists(target) or f.read().strip() != key
+    except OSError:
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _stamp(target, key):
+    with open(target + '.key', 'w') as f:
+        f.write(key + '\n')
+
+
+_HIPCC_VERSION = {}
+
+
+def _hipcc_version(hipcc):
+    if hipcc not in _HIPCC_VERSION:
+        r = subprocess.run([hipcc, '--version'], capture_output=True, text=True)
+        _HIPCC_VERSION[hipcc] = r.stdout.strip()
+    return _HIPCC_VERSION[hipcc]
 
 
 LAST = {}      # what the latest build() did: {'compiled': [...], 'reused': [...], 'linked': bool}
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link libiiseg_hip.so.  Returns the path.  Objects
-    newer than their source and the headers are reused unless `force`; `LAST` says what happened."""
+    """Compile every HIP source for gfx950 and link libiiseg_hip.so.  Returns the path.  An object
+    is reused (unless `force`) only when the content key stored next to it -- source + headers +
+    flags + hipcc version -- matches; the library only when its key over the objects' keys does.
+    `LAST` says what happened."""
     hipcc = _hipcc()
     LAST.clear()
     LAST.update(compiled=[], reused=[], linked=False)
@@ -46,16 +78,21 @@ def build(force=False, verbose=False):
     flags = ['-O3', '--offload-arch=' + ARCH, '-fPIC', '-std=c++17', '-I' + INCLUDE, '-I' + CSRC,
              '-Wall', '-Wno-unused-function']
 
+    version = _hipcc_version(hipcc)
+    keys = {}
+
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
-        if force or _stale(o, [s] + headers):
+        key = keys[src] = _digest([s] + headers, extra=flags + [version])
+        if force or _stale(o, key):
             cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr))
+            _stamp(o, key)
             LAST['compiled'].append(src)
         else:
             LAST['reused'].append(src)
@@ -63,11 +100,13 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _stale(LIB, objs):
+    lib_key = hashlib.sha256('\n'.join(keys[s] for s in SOURCES).encode()).hexdigest()
+    if force or LAST['compiled'] or _stale(LIB, lib_key):
         cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('link failed:\n' + r.stderr)
+        _stamp(LIB, lib_key)
         LAST['linked'] = True
     return LIB
 

@@ -311,6 +311,11 @@ __global__ __launch_bounds__(256, (UNPOOL && !MASKIN) ? 2 : 3) void conv_halo_bf
 #undef HBF_LOAD_X_SLICE
 #undef HBF_STORE_X
 #undef HBF_LOAD_W
+    // The last k-tile still issued its (out-of-range: zeros) patch loads and the weight DMA into the
+    // idle ring half, and nothing waited for them (`more` was false).  The staging tile Cs below
+    // overlays those LDS bytes, and a barrier does not drain ANOTHER wave's in-flight LDS-DMA: every
+    // wave retires its own vector-memory queue before the first epilogue barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: bias, skip add (center-cropped), ReLU, NCHW store ---------------------------
     // The MFMA C/D layout gives a lane one pixel of 16 different channels: stored as it stands,

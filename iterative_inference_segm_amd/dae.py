@@ -233,6 +233,10 @@ class StandardDAE:
             if primed and session.get('masked', frozenset()) != masked:
                 primed = False               # buffers of the other form: compute everything again
             session['masked'] = masked
+            if not primed:
+                # the session's buffers are (re)allocated by this call: anything that captured
+                # pointers into the previous ones (api._refine_graph) must notice
+                session['gen'] = session.get('gen', 0) + 1
         masks = {}
         dep = (0, 0, y.shape[2], y.shape[3])
         ydep = dep    # the region y alone reaches: its origin parity anchors the Winograd tiles

@@ -44,9 +44,44 @@ DEFAULT_MMA = os.environ.get('IISEG_MMA', 'f32')
 # Winograd kernels (conv_wino_bf16.hip); below, the direct bf16 kernel won every measured case
 #  and also fuses the pool and the DePool2D byte masks
 BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '256'))
-# both 16-bit forms possible for a layer: time them once per geometry (0: Winograd whenever it applies)
-BF16_TUNE = os.environ.get('IISEG_BF16_TUNE', '1') != '0'
-BF16_PICKS = {}
+# Both 16-bit forms possible for a layer (Winograd / direct): the choice is DETERMINISTIC -- a committed
+# table of measured winners per launch geometry (bf16_picks.json, written by scripts/tune_bf16.py on an
+# MI355X; keys without the batch size) and, for a geometry the table does not hold, a static rule on
+# the geometry alone (`_bf16_static_pick`).  Two processes, two ranks, two runs make the same choices,
+# so bf16 outputs are reproducible and identical across the ranks of a data-parallel evaluation, and a
+# loop-invariant border and its recomputed window come from the same form.  IISEG_BF16_TUNE=1 (the
+# generating script only) times both forms for keys the table lacks and records them in BF16_PICKS.
+BF16_TUNE = os.environ.get('IISEG_BF16_TUNE', '0') == '1'
+# 'wino' / 'halo': force one form wherever both apply (tests, A/B timing); '' = table, then rule
+BF16_FORCE = os.environ.get('IISEG_BF16_FORM', '')
+BF16_PICKS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bf16_picks.json')
+
+
+def _bf16_key(Cin, Cout, C1, C2, unpool, OH, OW):
+    return '%d,%d,%d,%d,%d,%d,%d' % (Cin, Cout, C1, C2, 1 if unpool else 0, OH, OW)
+
+
+def _load_bf16_picks():
+    import json
+    try:
+        with open(BF16_PICKS_FILE) as f:
+            return {k: v for k, v in json.load(f).get('picks', {}).items() if v in ('wino', 'halo')}
+    except OSError:
+        return {}
+
+
+BF16_PICKS = _load_bf16_picks()
+BF16_TIMES = {}      # key -> [ms Winograd, ms direct] of the keys timed in this process (tuning runs)
+
+
+def _bf16_static_pick(Cin, OW):
+    """Rule for geometries outside the table, from the round-2 measurements: the
+    direct kernel's 32-pixel column tiles waste (1 - OW / (32 ceil(OW / 32))) of its MFMAs, and from
+    1024 input channels the long-K Winograd GEMM wins on any window."""
+    fill = OW / (32.0 * ((OW + 31) // 32))
+    return 'wino' if (Cin >= 1024 or fill < 0.7) else 'halo'
+
+
 BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
 BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '256'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
@@ -312,18 +347,13 @@ class Conv:
         prof = CONV_PROFILE
         wino16 = not masked and pool_out is None and self.wino_bf16 and \
             bool(self.lib.iiseg_conv_wino_bf16_supported(C.byref(d)))
-        if wino16 and BF16_TUNE and self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
-            # both 16-bit forms can run this layer: which one is faster depends on how the window
-            # quantises into 32-pixel tiles and on the channel counts (measured), so the
-            # first call of a (layer geometry, window size) times both -- once per process, shared by
-            # every Conv of the same shape so that equal launches make equal choices whatever the
-            # batch size (an image gets the same result alone and in a batch).  A recomputed window
-            # of a loop-invariant map may thus come from the other form than its border: both are
-            # within the same bf16 error model; the bit-identity of the work eliminations is an
-            # fp32 / f64 property (and holds here under IISEG_BF16_TUNE=0).
-            key = (self.Cin, self.Cout, C1, C2, H, W, unpool, d.OH, d.OW)
-            pick = BF16_PICKS.get(key)
-            if pick is None and not torch.cuda.is_current_stream_capturing():
+        if wino16 and self.lib.iiseg_conv_halo_bf16_supported(C.byref(d)):
+            # both 16-bit forms can run this layer: table of measured winners, else the static rule
+            # (see BF16_PICKS above).  The key carries no batch size: an image gets the same form
+            # alone and in a batch.
+            key = _bf16_key(self.Cin, self.Cout, C1, C2, unpool, d.OH, d.OW)
+            pick = BF16_FORCE or BF16_PICKS.get(key)
+            if not pick and BF16_TUNE and not torch.cuda.is_current_stream_capturing():
                 forms = (lambda: self._call_wino_bf16(d, x1, x2, pre, pooled, add, out, None),
                          lambda: self._call_halo_bf16(d, x1, x2, pre, pooled, add, out, None, None,
                                                       None, None, B, H, W))
@@ -334,6 +364,9 @@ class Conv:
                     e1.synchronize()
                     ms.append(e0.elapsed_time(e1))
                 pick = BF16_PICKS[key] = 'wino' if ms[0] <= ms[1] else 'halo'
+                BF16_TIMES[key] = ms
+            if not pick:
+                pick = _bf16_static_pick(self.Cin, d.OW)
             if pick == 'halo':
                 return self._call_halo_bf16(d, x1, x2, pre, pooled, add, out, None, None, None, prof,
                                             B, H, W)

@@ -1,6 +1,7 @@
 """How fast the free-running refinement loop amplifies a perturbation of y0 (float64 HIP path =
 the reference's numerics), and how far the fp32 path drifts from it, per number of steps.
-Usage: python scripts/sensitivity.py [c2|c3|c5] """
+Usage: python scripts/sensitivity.py [c2|c2d|c3|c5]   (c2d: configs[1] on the DAMPED synthetic set,
+synthetic.DAMPED -- there the perturbation decays) """
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -24,7 +25,11 @@ else:
         kw = dict(concat_h=ch, pad_multi_concat=True); B, steps = 2, [1, 2, 5, 10, 20, 50]
     else:
         ch = ['pool4']; dp = S.make_dae_params(); kw = {}; B, steps = 2, [1, 2, 5, 10]
-    mk = lambda dt: IterativeInference(FCN8(fp, 11, layer=ch + ['probs_dimshuffle'], dtype=dt),
+    temp = 1.0
+    if which == 'c2d':
+        fp, dp, temp = S.make_damped_set()
+    mk = lambda dt: IterativeInference(FCN8(fp, 11, layer=ch + ['probs_dimshuffle'], dtype=dt,
+                                            temperature=temp),
                                        StandardDAE(dp, 11, dtype=dt, **kw), 11, [11], dtype=dt)
 X = S.make_images(B, 224, 224, seed=1234)
 ii64, ii32 = mk(F64), mk(F32)

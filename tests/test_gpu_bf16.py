@@ -30,14 +30,14 @@ def dev(a):
 @pytest.fixture(autouse=True)
 def _one_kernel_per_layer(request, monkeypatch):
     """The tests named *wino* pin the Winograd form: with the per-geometry choice between the two
-    16-bit forms (ops.BF16_TUNE) a layer could run the direct kernel instead."""
+    16-bit forms (ops.BF16_PICKS / the static rule) a layer could run the direct kernel instead."""
     from iterative_inference_segm_amd import ops as _ops
     if 'wino' in request.node.name or 'form_choice' in request.node.name:
         # (by default layers below 256 channels go straight to the direct kernel)
         monkeypatch.setattr(_ops, 'BF16_WINO_MIN_CIN', 128)
         monkeypatch.setattr(_ops, 'BF16_WINO_MIN_COUT', 128)
     if 'wino' in request.node.name:
-        monkeypatch.setattr(_ops, 'BF16_TUNE', False)
+        monkeypatch.setattr(_ops, 'BF16_FORCE', 'wino')
 
 
 @pytest.fixture(scope='module')
@@ -369,20 +369,31 @@ def test_config3_densenet_runs_in_bf16(built_lib):
 
 
 def test_bf16_form_choice_is_shared_and_batch_independent(ops, monkeypatch):
-    """Where both 16-bit forms can run a layer, the faster one is chosen once per (layer geometry,
-    window size): two Conv objects of the same shape make the same choice (so two engines agree bit
-    for bit), and so does the same layer on another batch size (an image alone == in a batch)."""
-    monkeypatch.setattr(ops, 'BF16_TUNE', True)
+    """Where both 16-bit forms can run a layer the choice is a function of the launch geometry alone
+    (committed table ops.BF16_PICKS, else the static rule): two Conv objects of the same shape make
+    the same choice (two engines, two ranks, two runs agree bit for bit), and so does the same layer
+    on another batch size (an image alone == in a batch).  Nothing is timed at run time: the table
+    is not written to.  Both forms are reachable (forced) and differ in their bits, i.e. the
+    agreement above is not an accident of a single code path."""
     rng = np.random.default_rng(5)
     B, Cin, H, W, Cout = 6, 128, 30, 34, 128
     x = rng.random((B, Cin, H, W)).astype(np.float32)
     Wt = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
     b = (0.1 * rng.standard_normal(Cout)).astype(np.float32)
+    before = dict(ops.BF16_PICKS)
+    assert not ops.BF16_TUNE
     c1, c2 = (ops.Conv(Wt, b, pad=1, relu=True, mma='bf16') for _ in range(2))
     a = host(c1(dev(x)))
-    key = (Cin, Cout, Cin, 0, H, W, False, H, W)
-    assert ops.BF16_PICKS.get(key) in ('wino', 'halo')
+    assert ops.BF16_PICKS == before
     assert np.array_equal(host(c2(dev(x))), a)
     assert np.array_equal(host(c2(dev(x[2:3]))), a[2:3])
     ref = onn.conv2d(x[:1].astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), pad=1, relu=True)
     assert rel_rms(a[:1], ref) <= 6e-3
+    forced = {}
+    for form in ('wino', 'halo'):
+        monkeypatch.setattr(ops, 'BF16_FORCE', form)
+        forced[form] = host(ops.Conv(Wt, b, pad=1, relu=True, mma='bf16')(dev(x)))
+        assert rel_rms(forced[form][:1], ref) <= 6e-3
+    assert not np.array_equal(forced['wino'], forced['halo'])
+    pick = before.get(ops._bf16_key(Cin, Cout, Cin, 0, False, H, W)) or ops._bf16_static_pick(Cin, W)
+    assert np.array_equal(forced[pick], a)

@@ -678,6 +678,61 @@ def test_graph_replay_is_bit_identical_to_the_eager_loop(built_lib, dtype, nf, s
         assert np.array_equal(host(x), host(y_))
 
 
+@pytest.mark.parametrize('nf,size,div', [(16, (40, 52), 16), (64, (224, 224), 1)])
+def test_captured_graph_is_dropped_when_the_launch_structure_changes(built_lib, nf, size, div):
+    """A captured refinement step points into the DAE session's buffers and encodes its launch
+    structure (byte masks or stored pre-pool maps, decoder windows, ...).  ONE engine, persistent
+    session: residual loop from the graph, then a gradient-mode loop (it needs the pre-pool maps:
+    `keep_pre`, the session is re-primed on other buffers), then the residual loop again -- and the
+    same with `dce` / `use_masks` toggled in between.  Every graph-mode result must be bit for bit
+    that of a fresh engine running the eager loop; a stale replay would give other numbers (or
+    touch freed memory).  Also: early stopping ends the replays once every image is frozen."""
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    concat_h = ['pool4']
+    fp = S.make_fcn8_params(width_div=div, fc_channels=4096 // div, seed=381)
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=nf, seed=382)
+    B = 2
+
+    def make():
+        ii = IterativeInference(FCN8(fp, 11, layer=concat_h + ['probs_dimshuffle']),
+                                StandardDAE(dp, 11, concat_h=concat_h, n_filters=nf), 11, [11])
+        ii.prepare(B, size[0], size[1])
+        return ii
+    ii_g = make()
+
+    def check(i, **knobs):
+        X = S.make_images(B, size[0], size[1], seed=390 + i)
+        ii_e = make()
+        for k, v in knobs.items():
+            setattr(ii_g.dae, k, v)
+            setattr(ii_e.dae, k, v)
+        og, oe = ii_g.pred_fcn_fn(X), ii_e.pred_fcn_fn(X)
+        rg = ii_g.refine(og[:-1], og[-1], 0.3, 6, eps=1e-4, graph=True)
+        re = ii_e.refine(oe[:-1], oe[-1], 0.3, 6, eps=1e-4, graph=False)
+        for a, b in zip(rg, re):
+            assert np.array_equal(host(a), host(b)), (i, knobs)
+        return og
+
+    check(0)
+    og = check(1)
+    assert next(iter(ii_g._graphs.values()))['graph'] is not None
+    ii_g.refine(og[:-1], og[-1], 0.05, 2, mode='gradient')          # keep_pre = True, re-primes
+    assert ii_g.dae.keep_pre
+    check(2)
+    assert not ii_g.dae.keep_pre
+    check(3, dce=False)
+    check(4, dce=True, use_masks=False)
+    check(5, use_masks=True)
+    # early stop on the graph path: a huge eps freezes every image after the first step; the loop
+    # must not replay all 40 steps (iteration counts as the eager loop reports them)
+    X = S.make_images(B, size[0], size[1], seed=399)
+    og = ii_g.pred_fcn_fn(X)
+    rg = ii_g.refine(og[:-1], og[-1], 0.3, 40, eps=1e3, graph=True)
+    assert host(rg[1]).tolist() == [1] * B
+
+
 @pytest.mark.parametrize('mma', ['f32', 'bf16'])
 @pytest.mark.parametrize('nf,size,div', [(16, (40, 52), 16), (64, (224, 224), 1)])
 def test_depool_byte_masks_are_bit_identical_to_the_stored_pre_pool_maps(built_lib, mma, nf, size, div,
