@@ -234,6 +234,40 @@ int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1
                          const float* add, float* out, float* pool_out, const uint8_t* mask_in,
                          uint8_t* mask_out);
 
+/* bf16 "C8" activations: the 16-bit MFMA path with the tensors BETWEEN layers already in the matrix
+ * pipe's operand format.  A C8 tensor of C channels is (B, ceil(C/8), H, W, 8) bf16 -- the 8 channels
+ * a lane feeds to one MFMA are 16 contiguous bytes -- with zero channels beyond C.  Same Lasagne
+ * Conv2DLayer(3x3, stride 1) call sites as iiseg_conv_halo_bf16 (models/fcn8.py:34-71,
+ * models/fcn_down.py:102-104, models/fcn_up.py:83-86); descriptor semantics as iiseg_conv_f32 with
+ * d->C1 / d->C2 = the PHYSICAL channel counts of the C8 inputs (multiples of 16; d->C2 > 0 = channel
+ * concat, x1 first) and weights packed by iiseg_conv_halo_bf16_pack for a descriptor with those
+ * counts (rows of channels the reference layer does not have are zero).
+ *   x1, x2      C8 inputs; with IISEG_CONV_UNPOOL x1 = `up` (B, C1/8, H/2, W/2, 8) and mask_in =
+ *               (B, C1/8, H/2, W/2, 8) bytes, bit (y & 1) * 2 + (x & 1) of byte j: pre == pooled for
+ *               channel 8 c8 + j at pixel (y, x) (DePool2D, layers/mylayers.py:88-115)
+ *   add         NULL (add_kind 0), C8 bf16 (1) or C8 fp32 (2: (B, Cout/8, AH, AW, 8) floats)
+ *   out         out_kind 0: not stored (pool_out given), 1: C8 bf16, 2: C8 fp32, 3: NCHW fp32
+ *               (B, out_ctot, out_H, out_W), Cout <= 32, no add / pool -- the class-score layer
+ *   pool_out    C8 bf16 (B, Cout/8, fullH/2, fullW/2, 8): 2x2 max-pool of the fp32 results, rules as
+ *               iiseg_conv_pool_f32; mask_out: the DePool2D mask bytes of those windows, taken from
+ *               the fp32 results before rounding (same decisions as the fp32-activation form)
+ * iiseg_conv_c8_is_flat: 1 if the launch uses the flat pixel tiling (256 consecutive window pixels of
+ * the whole batch per workgroup: small windows); pool_out is then not available -- store the map and
+ * call iiseg_pool_mask_c8.
+ * iiseg_nchw_to_c8 / iiseg_c8_to_nchw: layout converters (fp32 NCHW <-> C8 bf16, C8n chunks/image).
+ * iiseg_pool_mask_c8: 2x2 max-pool (+ mask bytes, may be NULL) of the pooled-coordinate window
+ * (y0, x0, wh, ww) from a stored piece `pre` (BC8 = B * chunks, PH, PW, 8) whose corner is at
+ * (py0, px0) of the (H, W) map, into the full (BC8, H/2, W/2, 8) pooled / mask tensors. */
+int iiseg_conv_c8_supported(const iiseg_conv_desc* d);
+int iiseg_conv_c8_is_flat(const iiseg_conv_desc* d);
+int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const void* x2,
+                  const uint8_t* mask_in, const void* wp16, const float* bias, const void* add,
+                  int add_kind, void* out, int out_kind, void* pool_out, uint8_t* mask_out);
+int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
+int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8n);
+int iiseg_pool_mask_c8(void* stream, const void* pre, void* pooled, uint8_t* mask, int BC8, int PH,
+                       int PW, int py0, int px0, int H, int W, int y0, int x0, int wh, int ww);
+
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,
  * d->Mpad from iiseg_conv_plan), the gather-free MFMA GEMM kernel of the Winograd path, partial

@@ -1,0 +1,790 @@
+// Direct 3x3 convolution on bf16 "C8" activations (gfx950, v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+// the 16-bit MFMA path with the activations BETWEEN layers already in the matrix pipe's operand
+// format.  A C8 tensor is (B, C/8, H, W, 8) bf16: the 8 channels one lane feeds to an MFMA are 16
+// contiguous bytes ("k8 chunk"), so
+//   * an input patch is staged global -> LDS by 16-byte LDS-DMA, one chunk per lane -- no VGPR pass,
+//     no conversion, half the bytes of the fp32 NCHW form (conv_halo_bf16.hip spent most of a
+//     k-tile issuing 24 dword loads + converts per thread: DESIGN 3.4 item 5);
+//   * the MFMA B operand of tap (ky, kx) is one ds_read_b128 at patch[(y + ky) * PW + x + kx];
+//   * the epilogue stores straight from the accumulators: in the 32x32 C/D layout a lane holds 4
+//     consecutive channels of one pixel = 8 bytes of that pixel's chunk, lanes are consecutive
+//     pixels, so one store instruction writes 512 contiguous bytes -- no LDS staging trip.
+// Fusions (same call sites as conv_halo_bf16.hip: Conv2DLayer 3x3 of models/fcn8.py:34-71,
+// models/fcn_down.py:102-104, models/fcn_up.py:83-86): bias, skip-add with crop (ElemwiseSumLayer),
+// ReLU, output window / placement, 2x2 max-pool + DePool2D equality-mask BYTES taken from the fp32
+// accumulators (layers/mylayers.py:111-114: same decisions as the fp32-activation form), DePool2D as
+// the input staging of the decoder convs (up chunk + 8 mask bytes per patch element), the loop-
+// invariant h half as an fp32 C8 addend, NCHW fp32 output for the class-score layer.
+// Two pixel tilings: RECT (8 x 32 pixels of one image; fused pool) and FLAT (256 consecutive pixels
+// of the window list of the whole batch: the 10^2..24^2 windows of the deep layers fill a tile that
+// a 32-column tiling would leave 40-70 % empty).
+// Pipeline: patch and weights double-buffered in ONE LDS array, both by LDS-DMA, one barrier per
+// 16-channel k-tile (wait own DMA -> barrier -> issue next k-tile's DMA -> 36 MFMAs per wave).
+// Numerics: statistical parity (8 significant bits per operand), like mma='bf16'; activations are
+// rounded once, where an operand would be rounded anyway.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int RSRC_W3 = 0x00027000;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, RSRC_W3);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+// lane ^ 1 of a 32-bit value (DPP quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor as four scalar words (for the inline-asm LDS-DMA below): base, stride 0,
+// num_records = bytes, raw 32-bit data format.  Every word is made wave-uniform explicitly.
+__device__ __forceinline__ i32x4 mk_srsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = RSRC_W3;
+    return r;
+}
+// One LDS-DMA piece: every lane fetches the 16 bytes at (descriptor base + voff + soff) and the wave's
+// 64 pieces land contiguously at LDS byte address `lds` (wave-uniform).  Written as inline asm ON
+// PURPOSE: beside a `__builtin_amdgcn_raw_ptr_buffer_load_lds` hipcc puts `s_waitcnt vmcnt(0)` in
+// front of every later LDS read it cannot prove disjoint (all of them, with a runtime ring index),
+// which serialises the prefetch with the MFMAs it should run under (checked in the .s).  An asm DMA
+// is outside hipcc's bookkeeping: it is retired by the explicit `s_waitcnt vmcnt(0)` + barrier at the
+// top of the k-loop and nothing else.  M0 (the DMA's LDS base) is saved and restored in the same
+// statement (the compiler does not expect it to change).
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+struct C8Params {
+    const void* x1;               // C8 input (B, C1/8, H, W, 8); UNPOOL: `up` (B, C1/8, h2, w2, 8)
+    const void* x2;               // second source of a channel concat (RECT only) or NULL
+    const unsigned char* mask_in; // UNPOOL: (B, C1/8, h2, w2, 8) mask bytes
+    const void* wp;               // Wp16[kt][tap][h][co][8] (iiseg_conv_halo_bf16_pack)
+    const float* bias;
+    const void* add;              // add_kind 1: C8 bf16 (B, Cout/8, AH, AW, 8); 2: C8 fp32
+    void* out;                    // out_kind 0: none, 1: C8 bf16, 2: C8 fp32; OUTF32: float NCHW
+    void* pool;                   // C8 bf16 (B, Cout/8, pool_H, pool_W, 8) or NULL
+    unsigned char* mask_out;      // (B, Cout/8, pool_H, pool_W, 8) bytes or NULL
+    int add_kind, out_kind;
+    int B, C1, C2, H, W, h2, w2;
+    int Cout, OH, OW, oy0, ox0, pad;
+    int AH, AW, ay0, ax0;
+    int nkt, Mpad;
+    int out_ctot, out_c0, out_H, out_W, out_y0, out_x0;
+    int pool_H, pool_W;
+    int relu;
+    int n_ptiles, n_mtiles, tiles_y, tiles_x;
+    int N;                        // FLAT: B * OH * OW
+    int PR, PWs;                  // FLAT: patch rows (capacity of a launch), patch row stride OW + 2
+    int debug;
+};
+
+// BM: output channels per workgroup (64; 32 for the class-score layer).  4 waves, each BM x 64 pixels.
+template <int BM, bool FLAT, bool UNPOOL, bool OUTF32>
+__global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
+    constexpr int TH = 8, TW = 32;
+    constexpr int PCAP = FLAT ? 480 : (TH + 2) * (TW + 2);   // patch chunks per 8-channel half
+    // (buffer size = whole 256-chunk DMA rounds: every wave issues all NE pieces, lanes past the patch
+    // write zeros into the unused tail)
+    constexpr int NE = (2 * PCAP + 255) / 256;
+    constexpr int NCHK = NE * 256;
+    constexpr int TM = BM / 32, TN = 2;
+    constexpr int WCH = 18 * BM;                             // weight chunks per k-tile
+    constexpr int WPT = (WCH + 255) / 256;
+    static_assert(WCH % 64 == 0, "a wave's DMA piece is whole");
+
+    // ONE LDS array: weight ring Ws[2][WCH], patch ring Ps[2][NCHK]
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * WCH + 2 * NCHK];
+    uint4 (*Ws)[WCH] = reinterpret_cast<uint4 (*)[WCH]>(smem);
+    uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + 2 * WCH);
+
+    int pt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
+    const int m0 = mt * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int HW = p.H * p.W, hw2 = p.h2 * p.w2;
+    const int OHW = p.OH * p.OW;
+    const int CC1 = p.C1 >> 3;                               // chunks per image of source 1
+
+    // ---- tile geometry -----------------------------------------------------------------------
+    int tb = 0, wy0 = 0, wx0 = 0;     // RECT: image, tile origin in window coordinates
+    int n0 = 0, vmin = 0;             // FLAT: first pixel of the tile, its virtual row
+    int PWs, half;
+    if constexpr (FLAT) {
+        // The windows of all images stacked: virtual output row u = b * (OH + 2) + y (two unused
+        // rows per image keep the 3-row halo of neighbouring images apart); the patch holds the
+        // virtual INPUT rows [vmin, vmin + PR) x (OW + 2) columns.
+        n0 = pt * 256;
+        const int b0 = n0 / OHW, r0 = n0 - b0 * OHW;
+        vmin = b0 * (p.OH + 2) + r0 / p.OW;
+        PWs = p.PWs;
+        half = p.PR * PWs;
+    } else {
+        const int tpi = p.tiles_y * p.tiles_x;
+        tb = pt / tpi;
+        const int tr = pt - tb * tpi;
+        const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+        wy0 = ty * TH; wx0 = tx * TW;
+        PWs = TW + 2;
+        half = PCAP;
+    }
+
+    // ---- patch staging offsets: chunk e = i * 256 + tid -> (half h, patch row, patch column) ----
+    unsigned voff[NE];                 // byte offset of the chunk in its source (k-tile 0), or OOB
+    unsigned voffm[UNPOOL ? NE : 1];   // UNPOOL: byte offset of its 8 mask bytes
+    int bsel[UNPOOL ? NE : 1];         // UNPOOL: bit (y & 1) * 2 + (x & 1) of the mask byte
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = i * 256 + tid;
+        const int h = e >= half ? 1 : 0;
+        const int rr = e - h * half;
+        const int prow = rr / PWs, pcol = rr - prow * PWs;
+        bool ok = e < 2 * half;
+        int b, iy;
+        if constexpr (FLAT) {
+            const int V = vmin + prow;
+            b = V / (p.OH + 2);
+            iy = p.oy0 - p.pad + (V - b * (p.OH + 2));
+            ok = ok && b < p.B;
+        } else {
+            b = 0;                                            // per-image descriptors
+            iy = p.oy0 + wy0 - p.pad + prow;
+        }
+        const int ix = p.ox0 + (FLAT ? 0 : wx0) - p.pad + pcol;
+        ok = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        if constexpr (UNPOOL) {
+            // DePool2D (layers/mylayers.py:95-114): only the 2 h2 x 2 w2 region has pooling windows
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
+            const unsigned idx = (unsigned)((b * CC1 + h) * hw2 + (iy >> 1) * p.w2 + (ix >> 1));
+            voff[i] = ok ? idx * 16u : OOB;
+            voffm[i] = ok ? idx * 8u : OOB;
+            bsel[i] = ((iy & 1) << 1) | (ix & 1);
+        } else {
+            voff[i] = ok ? (unsigned)((b * CC1 + h) * HW + iy * p.W + ix) * 16u : OOB;
+        }
+    }
+    // sources: RECT = image tb of each tensor (32-bit offsets inside one image), FLAT = whole tensor
+    const int plane = UNPOOL ? hw2 : HW;
+    const char* base1 = (const char*)p.x1 + (FLAT ? (size_t)0 : (size_t)tb * CC1 * plane * 16);
+    const unsigned n1 = (unsigned)((FLAT ? p.B : 1) * CC1 * plane) * 16u;
+    const char* base2 = p.C2 > 0 ? (const char*)p.x2 + (size_t)tb * (p.C2 >> 3) * plane * 16 : base1;
+    const unsigned n2 = p.C2 > 0 ? (unsigned)((p.C2 >> 3) * plane) * 16u : n1;
+    const __amdgpu_buffer_rsrc_t r_x1 = mk_rsrc(base1, (p.debug & 2) ? 0u : n1);
+    const i32x4 s_x1 = mk_srsrc(base1, (p.debug & 2) ? 0u : n1);
+    const i32x4 s_x2 = mk_srsrc(base2, (p.debug & 2) ? 0u : n2);
+    const __amdgpu_buffer_rsrc_t r_m =
+        mk_rsrc(UNPOOL ? p.mask_in + (FLAT ? (size_t)0 : (size_t)tb * CC1 * hw2 * 8) : nullptr,
+                UNPOOL ? n1 / 2 : 0u);
+    const i32x4 s_w = mk_srsrc(p.wp, (p.debug & 1) ? 0u : (unsigned)(p.nkt * 18 * p.Mpad) * 16u);
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr(&Ws[0][0]) + (unsigned)wave * 1024u);
+    const unsigned lds_p = __builtin_amdgcn_readfirstlane(lds_addr(&Ps[0][0]) + (unsigned)wave * 1024u);
+
+    // ---- MFMA B-operand positions of this lane's two 32-pixel columns -----------------------------
+    int bpos[TN];
+    int eb[TN], ey[TN], ex[TN];        // epilogue: image, window row, window column of the lane's pixel
+    bool eok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if constexpr (FLAT) {
+            const int n = n0 + wave * 64 + j * 32 + l31;
+            eok[j] = n < p.N;
+            const int nn = eok[j] ? n : p.N - 1;
+            eb[j] = nn / OHW;
+            const int r = nn - eb[j] * OHW;
+            ey[j] = r / p.OW; ex[j] = r - ey[j] * p.OW;
+            bpos[j] = (eb[j] * (p.OH + 2) + ey[j] - vmin) * PWs + ex[j];
+        } else {
+            eb[j] = 0;
+            ey[j] = wy0 + wave * 2 + j; ex[j] = wx0 + l31;
+            eok[j] = ey[j] < p.OH && ex[j] < p.OW;
+            bpos[j] = (wave * 2 + j) * PWs + l31;
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // k-tile KT = channels [16 KT, 16 KT + 16) of the logical (concatenated) input; its source is
+    // tile-uniform (C1 % 16 == 0)
+#define C8_SRC(KT)                                                                                 \
+    const bool s1 = UNPOOL || (KT) * 2 < CC1;                                                      \
+    const unsigned so = (unsigned)(((KT) * 2 - (s1 ? 0 : CC1)) * plane) * 16u;
+    // patch of k-tile KT by LDS-DMA: lane -> one chunk, a wave's 64 chunks land contiguously
+#define C8_DMA_X(KT, BUF)                                                                          \
+    {                                                                                              \
+        C8_SRC(KT)                                                                                 \
+        const unsigned so_u = __builtin_amdgcn_readfirstlane(so);                                  \
+        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            dma16(s1 ? s_x1 : s_x2, lds_p + (unsigned)((BUF) * NCHK + i * 256) * 16u, voff[i], so_u); \
+        });                                                                                        \
+    }
+    // weights of k-tile KT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
+    unsigned woff[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int f = j * 256 + tid;
+        woff[j] = f < WCH ? 16u * (unsigned)((f / BM) * p.Mpad + m0 + f % BM) : OOB;
+    }
+#define C8_DMA_W(KT, BUF)                                                                          \
+    {                                                                                              \
+        const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((KT) * 18 * p.Mpad) * 16u); \
+        static_for<0, WPT>([&](auto J) __attribute__((always_inline)) {                            \
+            constexpr int j = decltype(J)::value;                                                  \
+            if ((j + 1) * 256 <= WCH || j * 256 + wave * 64 < WCH)                                 \
+                dma16(s_w, lds_w + (unsigned)((BUF) * WCH + j * 256) * 16u, woff[j], so_w);        \
+        });                                                                                        \
+    }
+    // UNPOOL: up chunk + mask bytes into registers, selected and written to LDS later
+    u32x4 xu[UNPOOL ? NE : 1];
+    u32x2 xm[UNPOOL ? NE : 1];
+#define C8_LOAD_U(KT)                                                                              \
+    {                                                                                              \
+        const unsigned so = (unsigned)((KT) * 2 * hw2) * 16u;                                      \
+        static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(               \
+                r_x1, (int)voff[i], (int)so, 0));                                                  \
+            xm[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                \
+                r_m, (int)voffm[i], (int)(so >> 1), 0));                                           \
+        });                                                                                        \
+    }
+#define C8_STORE_U(BUF)                                                                            \
+    static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
+        constexpr int i = decltype(I)::value;                                                      \
+        /* byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j */         \
+        const unsigned t0 = (xm[i][0] >> bsel[i]) & 0x01010101u;                                   \
+        const unsigned t1 = (xm[i][1] >> bsel[i]) & 0x01010101u;                                   \
+        uint4 v;                                                                                   \
+        v.x = xu[i][0] & (((t0 & 1u) * 0xffffu) | (((t0 >> 8) & 1u) * 0xffff0000u));               \
+        v.y = xu[i][1] & ((((t0 >> 16) & 1u) * 0xffffu) | (((t0 >> 24) & 1u) * 0xffff0000u));      \
+        v.z = xu[i][2] & (((t1 & 1u) * 0xffffu) | (((t1 >> 8) & 1u) * 0xffff0000u));               \
+        v.w = xu[i][3] & ((((t1 >> 16) & 1u) * 0xffffu) | (((t1 >> 24) & 1u) * 0xffff0000u));      \
+        if (i * 256 + tid < 2 * half) Ps[BUF][i * 256 + tid] = v;                                  \
+    });
+
+    const int nkt = p.nkt;
+    if constexpr (UNPOOL) {
+        C8_LOAD_U(0)
+        C8_DMA_W(0, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C8_STORE_U(0)
+    } else {
+        C8_DMA_X(0, 0)
+        C8_DMA_W(0, 0)
+    }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        // k-tile kt has landed: every wave retires its own DMA pieces (and, UNPOOL, its LDS writes),
+        // then the barrier publishes them -- and tells that every wave is done READING buffer
+        // buf ^ 1 (k-tile kt - 1), which the next k-tile's DMA overwrites from here on
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (!UNPOOL) {
+            if (more) {
+                C8_DMA_X(kt + 1, buf ^ 1)
+                C8_DMA_W(kt + 1, buf ^ 1)
+            }
+        } else {
+            if (more) {
+                C8_LOAD_U(kt + 1)
+                C8_DMA_W(kt + 1, buf ^ 1)
+            }
+        }
+        // operands of tap t+1 are read from LDS while the MFMAs of tap t run (two register sets)
+        uint4 a[2][TM], bq[2][TN];
+        auto lds_operands = [&](auto TAP, auto SET) __attribute__((always_inline)) {
+            constexpr int tap = decltype(TAP)::value, set = decltype(SET)::value;
+            constexpr int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[set][i] = Ws[buf][(tap * 2 + lh) * BM + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bq[set][j] = Ps[buf][lh * half + bpos[j] + ky * PWs + kx];
+        };
+        lds_operands(ic<0>{}, ic<0>{});
+        static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
+            constexpr int tap = decltype(TAP)::value;
+            if constexpr (tap + 1 < 9) lds_operands(ic<tap + 1>{}, ic<(tap + 1) & 1>{});
+            {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[tap & 1][i]),
+                            __builtin_bit_cast(bf16x8, bq[tap & 1][j]), acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // keep that order tap by tap
+        });
+        if constexpr (UNPOOL) {
+            if (more) {
+                // buffer buf ^ 1 is free since the barrier above (k-tile kt - 1 was read before it)
+                C8_STORE_U(buf ^ 1)
+            }
+        }
+    }
+#undef C8_SRC
+#undef C8_DMA_X
+#undef C8_DMA_W
+#undef C8_LOAD_U
+#undef C8_STORE_U
+
+    // ---- epilogue, straight from the accumulators ------------------------------------------------
+    // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * lh:
+    // register group g = r >> 2 holds channels 8 g + 4 lh + (0..3) = one half of chunk g.
+    if ((p.debug & 8) && acc[0][0][0] != 12345.f) return;
+    const __amdgpu_buffer_rsrc_t r_bias = mk_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
+    const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
+    const int ib = FLAT ? 0 : tb;                 // image folded into the descriptor base (RECT)
+    if constexpr (OUTF32) {
+        // class-score layer: NCHW fp32, Cout <= 32
+        static_assert(TM == 1, "NCHW output: one 32-channel block");
+        const __amdgpu_buffer_rsrc_t r_out =
+            mk_rsrc((const char*)p.out + (size_t)ib * p.out_ctot * OPL * 4,
+                    (unsigned)((FLAT ? p.B : 1) * p.out_ctot * OPL) * 4u);
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                r_bias, (int)(4u * (unsigned)(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh)), 0, 0));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned o0 = (unsigned)((eb[j] * p.out_ctot + p.out_c0) * OPL +
+                                           (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[0][j][r] + bv[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(int, v), r_out,
+                    (int)((eok[j] && co < p.Cout) ? 4u * (o0 + (unsigned)(co * OPL)) : OOB), 0, 0);
+            }
+        }
+    } else {
+        // chunks of the Cout output channels: whole 16-channel groups (the layout every C8 consumer
+        // expects); channels past Cout come out as exact zeros (zero weight rows, no bias)
+        const int oct8 = p.out_ctot >> 3, co8 = ((p.Cout + 15) >> 4) << 1;
+        const unsigned osz = p.out_kind == 2 ? 32u : 16u;     // bytes per output chunk
+        const __amdgpu_buffer_rsrc_t r_out =
+            mk_rsrc(p.out ? (const char*)p.out + (size_t)ib * oct8 * OPL * osz : nullptr,
+                    p.out ? (unsigned)((FLAT ? p.B : 1) * oct8 * OPL) * osz : 0u);
+        const unsigned asz = p.add_kind == 2 ? 32u : 16u;
+        const __amdgpu_buffer_rsrc_t r_add =
+            mk_rsrc(p.add ? (const char*)p.add + (size_t)ib * co8 * APL * asz : nullptr,
+                    p.add ? (unsigned)((FLAT ? p.B : 1) * co8 * APL) * asz : 0u);
+        const bool pooling = !FLAT && p.pool != nullptr;
+        const __amdgpu_buffer_rsrc_t r_pool =
+            mk_rsrc(pooling ? (const char*)p.pool + (size_t)ib * co8 * PPL * 16 : nullptr,
+                    pooling ? (unsigned)(co8 * PPL) * 16u : 0u);
+        const __amdgpu_buffer_rsrc_t r_mask =
+            mk_rsrc(pooling && p.mask_out ? p.mask_out + (size_t)ib * co8 * PPL * 8 : nullptr,
+                    pooling && p.mask_out ? (unsigned)(co8 * PPL) * 8u : 0u);
+        // element offsets (chunks) of the lane's pixels inside chunk plane 0 of their image
+        unsigned opix[TN], apix[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            opix[j] = (unsigned)(eb[j] * oct8 * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
+            apix[j] = (unsigned)(eb[j] * co8 * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+        }
+        // fused pool (RECT): the wave's two rows are one row pair, lane ^ 1 is the column partner
+        const int q_wy = wy0 + wave * 2, q_wx = wx0 + l31;
+        const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
+        const bool q_ok = pooling && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
+                          q_py < p.pool_H && q_px < p.pool_W;
+        const unsigned q_pix = (unsigned)(q_py * p.pool_W + q_px);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c8 = ((m0 + i * 32) >> 3) + g;            // chunk of the output channels
+                const bool cok = c8 < co8;
+                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_bias, (int)(4u * (unsigned)(c8 * 8 + 4 * lh)), 0, 0));
+                f32x4 v[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[j][q] = acc[i][j][g * 4 + q] + bv[q];
+                    if (p.add_kind == 1) {
+                        const u32x2 a2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 16u + 8u * lh : OOB), 0, 0));
+                        v[j][0] += bf_lo(a2[0]); v[j][1] += bf_hi(a2[0]);
+                        v[j][2] += bf_lo(a2[1]); v[j][3] += bf_hi(a2[1]);
+                    } else if (p.add_kind == 2) {
+                        v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 32u + 16u * lh : OOB), 0, 0));
+                    }
+                    if (p.relu) {
+                        v[j][0] = fmaxf(v[j][0], 0.f); v[j][1] = fmaxf(v[j][1], 0.f);
+                        v[j][2] = fmaxf(v[j][2], 0.f); v[j][3] = fmaxf(v[j][3], 0.f);
+                    }
+                    const unsigned oo = opix[j] + (unsigned)(((p.out_c0 >> 3) + c8) * OPL);
+                    const bool ok = eok[j] && cok;
+                    if (p.out_kind == 1) {
+                        u32x2 w2;
+                        w2[0] = pack_bf16(v[j][0], v[j][1]); w2[1] = pack_bf16(v[j][2], v[j][3]);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)(ok ? oo * 16u + 8u * lh : OOB), 0, 0);
+                    } else if (p.out_kind == 2) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), r_out,
+                                                               (int)(ok ? oo * 32u + 16u * lh : OOB), 0, 0);
+                    }
+                }
+                if constexpr (!FLAT) {
+                    if (pooling) {
+                        // 2x2 max-pool of fp32 values + DePool2D mask bits (y & 1) * 2 + (x & 1):
+                        // pre == pooled (layers/mylayers.py:111-114), window = rows (j = 0, 1) x
+                        // columns (lane, lane ^ 1); the even lane stores
+                        f32x4 m;
+                        unsigned bits[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float a0 = v[0][q], a1 = v[1][q];
+                            const float b0 = dpp_xor1(a0), b1 = dpp_xor1(a1);
+                            m[q] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
+                            const unsigned c = (unsigned)(l31 & 1);
+                            const unsigned own = ((a0 == m[q] ? 1u : 0u) << c) | ((a1 == m[q] ? 1u : 0u) << (2 + c));
+                            bits[q] = own | dpp_xor1(own);
+                        }
+                        const unsigned po = q_pix + (unsigned)(c8 * PPL);
+                        u32x2 w2;
+                        w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)((q_ok && cok) ? po * 16u + 8u * lh : OOB), 0, 0);
+                        const unsigned mb = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
+                        __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)((q_ok && cok) ? po * 8u + 4u * lh : OOB), 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// x (B, C, H, W) fp32 -> C8 (B, C8n, H, W, 8) bf16, channels >= C zero
+__global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ x, uint4* __restrict__ out,
+                                                         int C, int HW, int C8n, int64_t total) {
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int pix = (int)(t % HW);
+        const int64_t r = t / HW;
+        const int c8 = (int)(r % C8n);
+        const int64_t b = r / C8n;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c8 * 8 + j;
+            v[j] = c < C ? x[(b * C + c) * HW + pix] : 0.f;
+        }
+        out[t] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
+                            pack_bf16(v[6], v[7]));
+    }
+}
+
+// C8 (B, C8n, H, W, 8) bf16 -> (B, C, H, W) fp32 (first C channels)
+__global__ __launch_bounds__(256) void c8_to_nchw_kernel(const uint4* __restrict__ x, float* __restrict__ out,
+                                                         int C, int HW, int C8n, int64_t total) {
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int pix = (int)(t % HW);
+        const int64_t r = t / HW;
+        const int c8 = (int)(r % C8n);
+        const int64_t b = r / C8n;
+        const uint4 u = x[t];
+        const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y),
+                            bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c8 * 8 + j;
+            if (c < C) out[(b * C + c) * HW + pix] = v[j];
+        }
+    }
+}
+
+// 2x2 max-pool (ignore_border) of the window (y0, x0, wh, ww) -- pooled coordinates -- of a C8 map
+// `pre` (B, C8n, PH, PW, 8), whose top-left corner sits at (py0, px0) of the full (H, W) map:
+// pooled (B, C8n, H/2, W/2, 8) and, if mask != NULL, the DePool2D mask bytes.
+__global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restrict__ pre, uint4* __restrict__ pooled,
+                                                           uint2* __restrict__ mask, int C8n, int PH, int PW,
+                                                           int py0, int px0, int h2, int w2, int y0, int x0,
+                                                           int wh, int ww, int64_t total) {
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int qx = (int)(t % ww);
+        int64_t r = t / ww;
+        const int qy = (int)(r % wh);
+        r /= wh;                                    // b * C8n + c8
+        const int Y = y0 + qy, X = x0 + qx;
+        const uint4* s = pre + (r * PH + (2 * Y - py0)) * PW + (2 * X - px0);
+        const uint4 u[4] = {s[0], s[1], s[PW], s[PW + 1]};
+        float v[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k][0] = bf_lo(u[k].x); v[k][1] = bf_hi(u[k].x); v[k][2] = bf_lo(u[k].y); v[k][3] = bf_hi(u[k].y);
+            v[k][4] = bf_lo(u[k].z); v[k][5] = bf_hi(u[k].z); v[k][6] = bf_lo(u[k].w); v[k][7] = bf_hi(u[k].w);
+        }
+        float m[8];
+        unsigned bits[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m[j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
+            bits[j] = (v[0][j] == m[j] ? 1u : 0u) | (v[1][j] == m[j] ? 2u : 0u) |
+                      (v[2][j] == m[j] ? 4u : 0u) | (v[3][j] == m[j] ? 8u : 0u);
+        }
+        const int64_t o = (r * h2 + Y) * w2 + X;
+        pooled[o] = make_uint4(pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3]), pack_bf16(m[4], m[5]),
+                               pack_bf16(m[6], m[7]));
+        if (mask)
+            mask[o] = make_uint2(bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24),
+                                 bits[4] | (bits[5] << 8) | (bits[6] << 16) | (bits[7] << 24));
+    }
+}
+
+constexpr int FLAT_PCAP = 480;
+
+// FLAT tiling: patch rows a 256-pixel tile can need (worst case over tile positions)
+int flat_patch_rows(int B, int OH, int OW) {
+    const int64_t N = (int64_t)B * OH * OW;
+    const int npt = (int)((N + 255) / 256);
+    int worst = 0;
+    for (int t = 0; t < npt; ++t) {
+        const int64_t n0 = (int64_t)t * 256, n1 = (n0 + 255 < N - 1) ? n0 + 255 : N - 1;
+        const int b0 = (int)(n0 / (OH * OW)), r0 = (int)(n0 % (OH * OW));
+        const int b1 = (int)(n1 / (OH * OW)), r1 = (int)(n1 % (OH * OW));
+        const int v0 = b0 * (OH + 2) + r0 / OW, v1 = b1 * (OH + 2) + r1 / OW;
+        if (v1 - v0 + 3 > worst) worst = v1 - v0 + 3;
+        if (t > 4096) break;                       // the pattern repeats with the image period
+    }
+    return worst;
+}
+
+struct C8Plan {
+    bool flat;
+    int PR;
+};
+
+int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2))
+        return IISEG_ERR_UNSUPPORTED;
+    if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
+        d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
+        return IISEG_ERR_SHAPE;
+    if (d->C1 % 16 || d->C2 % 16) return IISEG_ERR_UNSUPPORTED;     // whole k-tiles per source
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
+    if ((d->flags & IISEG_CONV_UNPOOL) && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
+    if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot)) return IISEG_ERR_SHAPE;
+    if (d->out_H != 0 && (d->out_y0 < 0 || d->out_x0 < 0 || d->out_y0 + d->OH > d->out_H ||
+                          d->out_x0 + d->OW > d->out_W))
+        return IISEG_ERR_SHAPE;
+    const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+    // RECT: one image of every tensor is addressed with 32-bit byte offsets
+    if (cmax * d->H * d->W * 2 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    const int64_t octot = d->out_ctot ? d->out_ctot : d->Cout;
+    const int64_t opl = d->out_H ? (int64_t)d->out_H * d->out_W : (int64_t)d->OH * d->OW;
+    if ((octot + 64) * opl * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if (((int64_t)d->Cout + 64) * d->AH * d->AW * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    const int bm = d->Cout > 32 ? 64 : 32, mpad = (d->Cout + bm - 1) / bm * bm;
+    const int nkt = (d->C1 + d->C2) / 16;
+    if ((int64_t)nkt * 18 * mpad * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if (plan) {
+        // FLAT where a 32-column tiling would leave more than a quarter of its MFMAs on padding and
+        // the whole tensors fit 32-bit offsets; needs a single source
+        const int ty = (d->OH + 7) / 8, tx = (d->OW + 31) / 32;
+        const double fill = (double)d->OH * d->OW / ((double)ty * 8 * tx * 32);
+        plan->flat = false;
+        plan->PR = 0;
+        static const int force = getenv("IISEG_C8_TILING") ? atoi(getenv("IISEG_C8_TILING")) : 0;  // 1 rect, 2 flat
+        if ((fill < 0.75 || force == 2) && force != 1 && d->C2 == 0 &&
+            (int64_t)d->B * cmax * d->H * d->W * 2 < (1ll << 31) &&
+            (int64_t)d->B * (octot + 64) * opl * 4 < (1ll << 31) &&
+            (int64_t)d->B * ((int64_t)d->Cout + 64) * d->AH * d->AW * 4 < (1ll << 31)) {
+            const int pr = flat_patch_rows(d->B, d->OH, d->OW);
+            if (pr * (d->OW + 2) <= FLAT_PCAP) {
+                plan->flat = true;
+                plan->PR = pr;
+            }
+        }
+    }
+    return IISEG_OK;
+}
+
+template <int BM, bool OUTF32>
+int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
+    p.n_mtiles = p.Mpad / BM;
+    if (plan.flat) {
+        p.N = p.B * p.OH * p.OW;
+        p.PR = plan.PR;
+        p.PWs = p.OW + 2;
+        p.n_ptiles = (p.N + 255) / 256;
+    } else {
+        p.tiles_y = (p.OH + 7) / 8;
+        p.tiles_x = (p.OW + 31) / 32;
+        p.n_ptiles = p.B * p.tiles_y * p.tiles_x;
+    }
+    const int grid = p.n_ptiles * p.n_mtiles;
+#define C8_LAUNCH(FL, UN) \
+    hipLaunchKernelGGL((conv_c8_kernel<BM, FL, UN, OUTF32>), dim3(grid), dim3(256), 0, s, p)
+    if (plan.flat) {
+        if (unpool) C8_LAUNCH(true, true); else C8_LAUNCH(true, false);
+    } else {
+        if (unpool) C8_LAUNCH(false, true); else C8_LAUNCH(false, false);
+    }
+#undef C8_LAUNCH
+    return iiseg_check_launch();
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_c8_supported(const iiseg_conv_desc* d) {
+    return c8_check(d, nullptr) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int iiseg_conv_c8_is_flat(const iiseg_conv_desc* d) {
+    C8Plan plan;
+    if (c8_check(d, &plan) != IISEG_OK) return 0;
+    return plan.flat ? 1 : 0;
+}
+
+extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const void* x2,
+                             const uint8_t* mask_in, const void* wp16, const float* bias,
+                             const void* add, int add_kind, void* out, int out_kind, void* pool_out,
+                             uint8_t* mask_out) {
+    C8Plan plan;
+    const int st = c8_check(d, &plan);
+    if (st) return st;
+    if (!x1 || !wp16) return IISEG_ERR_NULL;
+    if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool != (mask_in != nullptr)) return IISEG_ERR_NULL;
+    if ((uintptr_t)wp16 & 15) return IISEG_ERR_ALIGN;
+    if (out_kind < 0 || out_kind > 3 || add_kind < 0 || add_kind > 2) return IISEG_ERR_UNSUPPORTED;
+    if ((out_kind != 0) != (out != nullptr)) return IISEG_ERR_NULL;
+    if ((add_kind != 0) != (add != nullptr)) return IISEG_ERR_NULL;
+    if (!out && !pool_out) return IISEG_ERR_NULL;
+    if (mask_out && !pool_out) return IISEG_ERR_UNSUPPORTED;
+    if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
+        return IISEG_ERR_SHAPE;
+    const int octot = d->out_ctot ? d->out_ctot : d->Cout;
+    if (out_kind == 3) {                          // NCHW fp32: the class-score layer
+        if (d->Cout > 32 || add || pool_out) return IISEG_ERR_UNSUPPORTED;
+    } else if (d->out_ctot != 0 && (octot % 16 || d->out_c0 % 16)) {
+        return IISEG_ERR_UNSUPPORTED;
+    }
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (pool_out) {
+        // fused pool: RECT tiling, whole pooling windows (even origin, even extent unless the window
+        // ends at the map's last, unpaired row / column), no skip-add
+        if (plan.flat || add || ((d->oy0 | d->ox0) & 1) || ((d->OH & 1) && d->oy0 + d->OH != fullH) ||
+            ((d->OW & 1) && d->ox0 + d->OW != fullW))
+            return IISEG_ERR_UNSUPPORTED;
+    }
+    C8Params p = {};
+    p.x1 = x1; p.x2 = x2; p.mask_in = mask_in; p.wp = wp16; p.bias = bias;
+    p.add = add; p.add_kind = add_kind; p.out = out; p.out_kind = out_kind;
+    p.pool = pool_out; p.mask_out = mask_out;
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0; p.pad = d->pad;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    p.nkt = (d->C1 + d->C2) / 16;
+    const int bm = d->Cout > 32 ? 64 : 32;
+    p.Mpad = (d->Cout + bm - 1) / bm * bm;
+    // dense C8 output: the Cout channels padded to whole 16-channel groups
+    p.out_ctot = (out_kind == 3 || d->out_ctot) ? octot : (d->Cout + 15) / 16 * 16;
+    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
+    p.out_H = d->out_H ? d->out_H : d->OH;
+    p.out_W = d->out_H ? d->out_W : d->OW;
+    p.out_y0 = d->out_H ? d->out_y0 : 0;
+    p.out_x0 = d->out_H ? d->out_x0 : 0;
+    p.pool_H = fullH / 2; p.pool_W = fullW / 2;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    static const int dbg = getenv("IISEG_BF16_DEBUG") ? atoi(getenv("IISEG_BF16_DEBUG")) : 0;
+    p.debug = dbg;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_kind == 3) return launch_c8<32, true>(s, p, plan, unpool);
+    if (bm == 64) return launch_c8<64, false>(s, p, plan, unpool);
+    return launch_c8<32, false>(s, p, plan, unpool);
+}
+
+extern "C" int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, int C, int H, int W,
+                                int C8n) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)B * C8n * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint4*)out,
+                       C, H * W, C8n, total);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W,
+                                int C8n) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)B * C8n * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, out, C, H * W, C8n, total);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, void* pooled, uint8_t* mask, int BC8,
+                                  int PH, int PW, int py0, int px0, int H, int W, int y0, int x0,
+                                  int wh, int ww) {
+    if (!pre || !pooled) return IISEG_ERR_NULL;
+    if (BC8 <= 0 || wh <= 0 || ww <= 0) return IISEG_ERR_SHAPE;
+    // every 2x2 window of the pooled region must lie inside the stored piece of the pre-pool map
+    if (y0 < 0 || x0 < 0 || y0 + wh > H / 2 || x0 + ww > W / 2 || 2 * y0 < py0 || 2 * x0 < px0 ||
+        2 * (y0 + wh) > py0 + PH || 2 * (x0 + ww) > px0 + PW)
+        return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)BC8 * wh * ww;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(pool_mask_c8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)pre, (uint4*)pooled, (uint2*)mask, 0, PH, PW, py0, px0, H / 2, W / 2,
+                       y0, x0, wh, ww, total);
+    return iiseg_check_launch();
+}

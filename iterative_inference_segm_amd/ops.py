@@ -140,8 +140,13 @@ class Conv:
         precision on the matrix pipe (float32 tensors only; None: ops.DEFAULT_MMA)."""
         self.lib = _lib.load()
         self.mma = (mma or DEFAULT_MMA) if dtype == torch.float32 else 'f32'
-        if self.mma not in ('f32', 'bf16'):
-            raise ValueError("mma must be 'f32' or 'bf16'")
+        if self.mma not in ('f32', 'bf16', 'bf16c8'):
+            raise ValueError("mma must be 'f32', 'bf16' or 'bf16c8'")
+        # 'bf16c8': bf16 MFMA operands AND bf16 C8 activations between the 3x3 layers (conv_c8_bf16.hip);
+        # a layer takes that form when it is handed a C8 tensor, any other call is the 'bf16' mode
+        self.c8 = self.mma == 'bf16c8'
+        if self.c8:
+            self.mma = 'bf16'
         self.transposed = bool(transposed)
         self.dtype = dtype
         self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
@@ -185,9 +190,11 @@ class Conv:
         # bf16 mode: every other plain 3x3 layer on the bf16 halo kernel (conv_halo_bf16.hip)
         self.halo_bf16 = (self.mma == 'bf16' and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
                           not self.transposed and not self.wino_bf16)
+        self.c8 = self.c8 and (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed
         self._U = None
         self._U16 = None
         self._W16 = None
+        self._W16c8 = None
         self._plans = {}
         self._packs = {}
 
@@ -258,7 +265,7 @@ class Conv:
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
                  window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None,
-                 mask_in=None, unpool_hw=None, mask_out=None, store_out=True):
+                 mask_in=None, unpool_hw=None, mask_out=None, store_out=True, out_format=None):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
@@ -277,6 +284,9 @@ class Conv:
         itself (returns None; `out`, if given, only carries the placement geometry).  `mask_in`
         (uint8, x1's shape) + `unpool_hw` = (H, W) replace `pre` / `pooled` for the unpooled
         input."""
+        if is_c8(x1):
+            return self._call_c8(x1, x2, add, add_off, window, out, place, pool_out, mask_in,
+                                 unpool_hw, mask_out, store_out, out_format)
         dt = self.dtype
         unpool = pre is not None or mask_in is not None
         masked = mask_in is not None or mask_out is not None
@@ -497,6 +507,8 @@ class Conv:
         """True if this layer runs on a halo kernel whose epilogue can do the 2x2 max-pool."""
         if not POOL_FUSE or self.dtype != torch.float32:
             return False
+        if self.c8:
+            return True
         if self.mma == 'bf16':
             return self.halo_bf16
         return not (self.wino or self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256)
@@ -504,6 +516,8 @@ class Conv:
     def mask_ok(self):
         """True if this layer can take / produce DePool2D masks as bytes (halo kernels only, and
         only where the byte form runs the very kernel the pre / pooled form runs)."""
+        if self.c8:
+            return True
         if self.dtype != torch.float32 or (self.KH, self.KW) != (3, 3) or self.dil != 1 or \
                 self.transposed or self.kernel != 'conv_halo_f32_kernel' or self.wino_bf16:
             return False
@@ -526,6 +540,125 @@ class Conv:
         if region[1] + region[3] == fw:
             x1 = fw
         return (y0, x0, y1 - y0, x1 - x0)
+
+    def _call_c8(self, x1, x2, add, add_off, window, out, place, pool_out, mask_in, unpool_hw,
+                 mask_out, store_out, out_format):
+        """The layer on bf16 C8 activations (include/iiseg.h, iiseg_conv_c8).  x1 / x2 / pool_out:
+        C8 tensors (`is_c8`); add: C8 bf16 or C8 fp32 (float32, same 5-D shape); mask_in / mask_out:
+        uint8 (B, C/8, h, w, 8).  out_format: 'c8' (default), 'c8f32', or 'nchw' (fp32 NCHW, the
+        class-score layer: default when Cout is not a multiple of 8).  Returns the output tensor
+        (None with store_out=False)."""
+        lib = self.lib
+        if not self.c8:
+            raise RuntimeError("C8 input needs a 3x3 layer built with mma='bf16c8'")
+        unpool = mask_in is not None
+        B, CC1 = x1.shape[0], x1.shape[1]
+        if unpool:
+            if unpool_hw is None or not is_c8_mask(mask_in) or mask_in.shape != x1.shape or \
+                    (unpool_hw[0] // 2, unpool_hw[1] // 2) != tuple(x1.shape[2:4]) or x2 is not None:
+                raise RuntimeError('C8 DePool2D input: up %s, mask %s, unpool_hw %s'
+                                   % (tuple(x1.shape), tuple(mask_in.shape), unpool_hw))
+            H, W = int(unpool_hw[0]), int(unpool_hw[1])
+        else:
+            H, W = x1.shape[2], x1.shape[3]
+        CC2 = 0
+        if x2 is not None:
+            if not is_c8(x2) or x2.shape[0] != B or tuple(x2.shape[2:4]) != (H, W):
+                raise RuntimeError('concat shapes %s vs %s' % (tuple(x1.shape), tuple(x2.shape)))
+            CC2 = x2.shape[1]
+            if CC1 * 8 + CC2 * 8 != self.Cin:
+                raise RuntimeError('C8 concat needs unpadded sources')
+        if (CC1 + CC2) * 8 < self.Cin or (CC1 % 2) or (CC2 % 2):
+            raise RuntimeError('conv expects %d input channels in whole 16-channel groups, got '
+                               '%d + %d chunks' % (self.Cin, CC1, CC2))
+        fullH, fullW = self.out_hw(H, W)
+        oy0, ox0, OH, OW = window if window is not None else (0, 0, fullH, fullW)
+        fmt = out_format or ('c8' if self.Cout % 8 == 0 else 'nchw')
+        kind = {'c8': 1, 'c8f32': 2, 'nchw': 3}[fmt]
+        d = ConvDesc()
+        d.B, d.C1, d.C2, d.H, d.W = B, CC1 * 8, CC2 * 8, H, W
+        d.Cout, d.KH, d.KW, d.pad, d.dil = self.Cout, 3, 3, self.pad, 1
+        d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
+        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0)
+        add_kind = 0
+        if add is not None:
+            add_kind = 1 if is_c8(add) else 2
+            if add.dim() != 5 or add.shape[0] != B or add.shape[1] * 8 != self.Cout or \
+                    add.dtype not in (torch.bfloat16, torch.float32):
+                raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
+            d.AH, d.AW, d.ay0, d.ax0 = add.shape[2], add.shape[3], add_off[0], add_off[1]
+        oc8 = (self.Cout + 15) // 16 * 2
+        if place is not None:
+            if out is None:
+                raise RuntimeError('placement needs a target')
+            d.out_H, d.out_W, d.out_y0, d.out_x0 = out.shape[2], out.shape[3], int(place[0]), int(place[1])
+        if not store_out:
+            if pool_out is None:
+                raise RuntimeError('store_out=False needs pool_out')
+            out, kind = None, 0
+        elif out is None:
+            if fmt == 'nchw':
+                out = torch.empty((B, self.Cout, OH, OW), dtype=torch.float32, device=x1.device)
+            else:
+                out = torch.empty((B, oc8, OH, OW, 8), device=x1.device,
+                                  dtype=torch.bfloat16 if fmt == 'c8' else torch.float32)
+        if out is not None:
+            ok = (out.dim() == 4 and out.dtype == torch.float32 and out.shape[1] == self.Cout) \
+                if fmt == 'nchw' else \
+                (out.dim() == 5 and out.shape[1] == oc8 and
+                 out.dtype == (torch.bfloat16 if fmt == 'c8' else torch.float32))
+            if not ok or out.shape[0] != B or (place is None and tuple(out.shape[2:4]) != (OH, OW)):
+                raise RuntimeError('bad C8 output target %s' % (tuple(out.shape),))
+        if pool_out is not None:
+            if not is_c8(pool_out) or tuple(pool_out.shape) != (B, oc8, fullH // 2, fullW // 2, 8):
+                raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
+            if mask_out is not None and (not is_c8_mask(mask_out) or mask_out.shape != pool_out.shape):
+                raise RuntimeError('mask_out: uint8 of pool_out\'s shape')
+        elif mask_out is not None:
+            raise RuntimeError('mask_out needs pool_out')
+        if self._W16c8 is None:
+            # packed for the REAL channel count: the rows of padding channels are zero
+            dp = ConvDesc()
+            dp.B, dp.C1, dp.C2, dp.H, dp.W = 1, self.Cin, 0, 8, 8
+            dp.Cout, dp.KH, dp.KW, dp.pad, dp.dil = self.Cout, 3, 3, 1, 1
+            dp.OH, dp.OW = 8, 8
+            self._W16c8 = torch.empty(lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(dp)) // 2,
+                                      dtype=torch.bfloat16, device=self.W.device)
+            check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(self.W), self.so, self.sc,
+                                                _ptr(self._W16c8, torch.bfloat16)),
+                  'iiseg_conv_halo_bf16_pack')
+        dtp = lambda t: None if t is None else _ptr(t, t.dtype)
+        flat_pool = pool_out is not None and bool(lib.iiseg_conv_c8_is_flat(C.byref(d)))
+        tmp = None
+        if flat_pool:
+            # flat pixel tiling (small windows): the conv stores its window, a second kernel pools it
+            if not store_out:
+                tmp = torch.empty((B, oc8, OH, OW, 8), dtype=torch.bfloat16, device=x1.device)
+                d.out_H = d.out_W = d.out_y0 = d.out_x0 = 0
+            conv_out, conv_kind, conv_pool, conv_mask = (tmp if tmp is not None else out), 1, None, None
+            if tmp is None and fmt != 'c8':
+                raise RuntimeError('pooling a C8 layer needs a bf16 C8 output')
+        else:
+            conv_out, conv_kind, conv_pool, conv_mask = out, kind, pool_out, mask_out
+        prof = CONV_PROFILE
+        ev0 = _ev() if prof is not None else None
+        check(lib.iiseg_conv_c8(_stream(), C.byref(d), dtp(x1), dtp(x2), dtp(mask_in),
+                                dtp(self._W16c8), _ptr(self.b), dtp(add), add_kind, dtp(conv_out),
+                                conv_kind, dtp(conv_pool), dtp(conv_mask)), 'iiseg_conv_c8')
+        if prof is not None:
+            prof.append(('conv_c8_kernel', self.flops(B, OH, OW), ev0, _ev()))
+        if flat_pool:
+            src = tmp if tmp is not None else out
+            if tmp is not None:
+                ph_, pw_, py0, px0 = OH, OW, oy0, ox0
+            else:
+                ph_, pw_ = out.shape[2], out.shape[3]
+                py0 = oy0 - (int(place[0]) if place is not None else 0)
+                px0 = ox0 - (int(place[1]) if place is not None else 0)
+            pool_mask_c8(src, pool_out, mask_out, (py0, px0), (fullH, fullW),
+                         (oy0 // 2, ox0 // 2, min((oy0 + OH) // 2, fullH // 2) - oy0 // 2,
+                          min((ox0 + OW) // 2, fullW // 2) - ox0 // 2))
+        return out
 
     def _call_halo_bf16(self, d, x1, x2, pre, pooled, add, out, pool_out, mask_in, mask_out, prof,
                         B, H, W):
@@ -648,6 +781,63 @@ class Deconv:
         check(_fn('deconv', dt)(_stream(), C.byref(d), _ptr(x, dt), _ptr(self.W, dt),
                                 _ptr(self.b, dt), _ptr(add, dt), _ptr(out, dt)), 'iiseg_deconv')
         return out
+
+
+def is_c8(t):
+    """True for a bf16 C8 activation tensor: (B, C/8, H, W, 8) bfloat16 (include/iiseg.h)."""
+    return isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16 and t.dim() == 5 and \
+        t.shape[-1] == 8
+
+
+def is_c8_mask(t):
+    return isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and t.dim() == 5 and t.shape[-1] == 8
+
+
+def c8_chunks(channels):
+    """Chunks of a C8 tensor holding `channels` channels: whole 16-channel k-tiles."""
+    return (int(channels) + 15) // 16 * 2
+
+
+def empty_c8(B, channels, H, W, device, dtype=torch.bfloat16):
+    return torch.empty((B, c8_chunks(channels), H, W, 8), dtype=dtype, device=device)
+
+
+def nchw_to_c8(x, out=None):
+    """fp32 NCHW -> bf16 C8 (channels padded with zeros to a whole 16-channel group)."""
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = empty_c8(B, Cc, H, W, x.device)
+    check(_lib.load().iiseg_nchw_to_c8(_stream(), _ptr(x), C.c_void_p(out.data_ptr()), B, Cc, H, W,
+                                       out.shape[1]), 'iiseg_nchw_to_c8')
+    return out
+
+
+def c8_to_nchw(x8, channels, out=None):
+    """bf16 C8 -> fp32 NCHW (first `channels` channels)."""
+    if not is_c8(x8) or not x8.is_contiguous():
+        raise RuntimeError('c8_to_nchw needs a contiguous C8 tensor')
+    B, C8n, H, W, _ = x8.shape
+    if out is None:
+        out = torch.empty((B, int(channels), H, W), dtype=torch.float32, device=x8.device)
+    check(_lib.load().iiseg_c8_to_nchw(_stream(), C.c_void_p(x8.data_ptr()), _ptr(out), B,
+                                       int(channels), H, W, C8n), 'iiseg_c8_to_nchw')
+    return out
+
+
+def pool_mask_c8(pre, pooled, mask, origin, full_hw, window):
+    """2x2 max-pool (+ DePool2D mask bytes, `mask` may be None) of the pooled-coordinate `window`
+    (y0, x0, h, w) from the stored piece `pre` (C8) whose corner sits at `origin` of the `full_hw`
+    map, into the full-size `pooled` / `mask` tensors."""
+    B, C8n, PH, PW, _ = pre.shape
+    y0, x0, wh, ww = window
+    if wh <= 0 or ww <= 0:
+        return pooled
+    check(_lib.load().iiseg_pool_mask_c8(
+        _stream(), C.c_void_p(pre.data_ptr()), C.c_void_p(pooled.data_ptr()),
+        None if mask is None else C.c_void_p(mask.data_ptr()), B * C8n, PH, PW, int(origin[0]),
+        int(origin[1]), int(full_hw[0]), int(full_hw[1]), int(y0), int(x0), int(wh), int(ww)),
+        'iiseg_pool_mask_c8')
+    return pooled
 
 
 def maxpool2x2(x, out=None, window=None):

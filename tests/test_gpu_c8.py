@@ -1,0 +1,214 @@
+"""bf16 C8 activations (csrc/conv_c8_bf16.hip, include/iiseg.h iiseg_conv_c8): the direct 3x3 kernel,
+the layout converters and the pool + mask kernel against the float64 oracle.  On small-integer data
+every bf16 rounding is exact, so results must agree BIT FOR BIT -- that pins every index of the chunk
+layout, both pixel tilings (RECT 8 x 32 tiles, FLAT 256-pixel runs over the batch), the LDS-DMA
+staging incl. zero padding, the DePool2D input from mask bytes (layers/mylayers.py:88-115), the
+fused pool / mask-byte epilogue, skip-add, windows and placement."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops(built_lib):
+    from iterative_inference_segm_amd import ops as _ops
+    return _ops
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.float().cpu().numpy() if t.dtype == torch.bfloat16 else t.cpu().numpy()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def from_c8(t, C):
+    """(B, C8, H, W, 8) -> (B, C, H, W) float64 on the host."""
+    a = host(t).astype(np.float64)
+    B, C8, H, W, _ = a.shape
+    return a.transpose(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)[:, :C]
+
+
+def ints(rng, *shape, lo=-3, hi=4):
+    return rng.integers(lo, hi, size=shape).astype(np.float64)
+
+
+def layer(ops, rng, Cin, Cout, pad=1, relu=True):
+    # (sums must stay below 256 in magnitude to be exact in bf16: narrower weights for deep layers)
+    W = ints(rng, Cout, Cin, 3, 3, lo=-2, hi=3) if Cin < 32 else ints(rng, Cout, Cin, 3, 3, lo=-1, hi=2)
+    b = ints(rng, Cout)
+    return W, b, ops.Conv(W, b, pad=pad, relu=relu, mma='bf16c8')
+
+
+def test_converters_round_trip(ops):
+    rng = np.random.default_rng(0)
+    x = ints(rng, 3, 11, 9, 13, lo=-100, hi=100)
+    x8 = ops.nchw_to_c8(dev(x))
+    assert tuple(x8.shape) == (3, 2, 9, 13, 8) and ops.is_c8(x8)
+    full = from_c8(x8, 16)
+    assert np.array_equal(full[:, :11], x) and not full[:, 11:].any()
+    assert np.array_equal(host(ops.c8_to_nchw(x8, 11)), x.astype(np.float32))
+
+
+CASES = [  # B, Cin, H, W, Cout, pad, relu, window
+    (2, 16, 20, 45, 64, 1, True, None),            # RECT, ragged tiles
+    (1, 48, 9, 70, 72, 1, False, None),            # channel tails, three column tiles
+    (2, 32, 12, 12, 64, 5, True, None),            # wide zero padding (the pad-100 rule, scaled)
+    (3, 64, 40, 40, 128, 1, True, (6, 10, 21, 27)),  # window of a larger map
+    (5, 32, 13, 13, 64, 1, True, None),            # FLAT: tiles run across images
+    (7, 64, 22, 22, 96, 1, False, (5, 6, 10, 10)),   # FLAT window
+    (2, 128, 17, 19, 64, 1, True, None),           # FLAT, 8 k-tiles
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv_c8_exact_on_integer_data(ops, case):
+    B, Cin, H, W, Cout, pad, relu, window = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x = ints(rng, B, Cin, H, W) if Cin < 32 else ints(rng, B, Cin, H, W, lo=-2, hi=3)
+    if Cin >= 128:
+        x = ints(rng, B, Cin, H, W, lo=-1, hi=2)
+    Wt, b, conv = layer(ops, rng, Cin, Cout, pad, relu)
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+    got8 = conv(ops.nchw_to_c8(dev(x)), window=window)
+    if window is not None:
+        y0, x0, h, w = window
+        ref = ref[:, :, y0:y0 + h, x0:x0 + w]
+    assert ops.is_c8(got8) and got8.shape[1] == ops.c8_chunks(Cout)
+    got = from_c8(got8, got8.shape[1] * 8)
+    assert np.abs(ref).max() <= 256                   # every value bf16-exact
+    assert np.array_equal(got[:, :Cout], ref), np.abs(got[:, :Cout] - ref).max()
+    assert not got[:, Cout:].any()                    # padding channels stay zero
+
+
+@pytest.mark.parametrize('tiling', ['1', '2'])
+def test_conv_c8_tilings_agree(ops, tiling, monkeypatch):
+    """The same launch forced onto the RECT and the FLAT tiling (IISEG_C8_TILING is read once per
+    process, so the comparison is against the oracle for whichever the environment selects; the
+    default choice is covered by the cases above)."""
+    rng = np.random.default_rng(77)
+    x = ints(rng, 3, 32, 24, 24)
+    Wt, b, conv = layer(ops, rng, 32, 64)
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=True)
+    assert np.array_equal(from_c8(conv(ops.nchw_to_c8(dev(x))), 64), ref)
+
+
+def test_conv_c8_placement_and_skip_add(ops):
+    rng = np.random.default_rng(5)
+    B, Cin, Cout, H, W = 2, 32, 64, 30, 41
+    x = ints(rng, B, Cin, H, W)
+    Wt, b, conv = layer(ops, rng, Cin, Cout, relu=False)
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=False)
+    for add_fmt in ('c8', 'c8f32'):
+        skip = ints(rng, B, Cout, H + 4, W + 6)
+        s8 = ops.nchw_to_c8(dev(skip))
+        if add_fmt == 'c8f32':
+            s8 = s8.float()
+        y0, x0, h, w = 4, 8, 19, 30
+        out = torch.full((B, ops.c8_chunks(Cout), H, W, 8), 7.0, dtype=torch.bfloat16, device='cuda')
+        conv(ops.nchw_to_c8(dev(x)), add=s8, add_off=(2 + y0, 3 + x0), window=(y0, x0, h, w), out=out,
+             place=(y0, x0))
+        got = from_c8(out, Cout)
+        want = np.full_like(ref, 7.0)
+        want[:, :, y0:y0 + h, x0:x0 + w] = (ref + skip[:, :, 2:2 + H, 3:3 + W])[:, :, y0:y0 + h, x0:x0 + w]
+        assert np.array_equal(got, want)
+    # fp32 C8 output (the loop-invariant h half), dense
+    o32 = conv(ops.nchw_to_c8(dev(x)), out_format='c8f32')
+    a = host(o32).astype(np.float64).transpose(0, 1, 4, 2, 3).reshape(B, -1, H, W)[:, :Cout]
+    assert np.array_equal(a, ref)
+
+
+def test_conv_c8_class_score_layer_nchw_output(ops):
+    rng = np.random.default_rng(6)
+    B, Cin, H, W = 2, 64, 21, 37
+    x = ints(rng, B, Cin, H, W, lo=-2, hi=3)
+    Wt = ints(rng, 11, Cin, 3, 3, lo=-1, hi=2)
+    b = ints(rng, 11)
+    conv = ops.Conv(Wt, b, pad=1, relu=False, mma='bf16c8')
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=False)
+    got = conv(ops.nchw_to_c8(dev(x)), window=(3, 5, 16, 30))
+    assert got.dtype == torch.float32 and tuple(got.shape) == (B, 11, 16, 30)
+    assert np.array_equal(host(got), ref[:, :, 3:19, 5:35].astype(np.float32))
+
+
+def _masks(pre):
+    """oracle: pooled map and mask bytes (bit (y & 1) * 2 + (x & 1): pre == pooled) of `pre`."""
+    pooled = onn.maxpool2(pre)
+    h, w = pooled.shape[2], pooled.shape[3]
+    rep = np.repeat(np.repeat(pooled, 2, 2), 2, 3)
+    eq = (pre[:, :, :2 * h, :2 * w] == rep)
+    bits = (eq[:, :, 0::2, 0::2] * 1 + eq[:, :, 0::2, 1::2] * 2 + eq[:, :, 1::2, 0::2] * 4 +
+            eq[:, :, 1::2, 1::2] * 8)
+    return pooled, bits.astype(np.uint8)
+
+
+def mask_from_c8(m):
+    a = host(m)
+    B, C8, H, W, _ = a.shape
+    return a.transpose(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 38, 45, 64), (4, 32, 15, 15, 64)])   # RECT fused / FLAT + pool kernel
+def test_conv_c8_pool_and_mask_bytes(ops, shape):
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(H)
+    x = ints(rng, B, Cin, H, W, lo=-2, hi=3)
+    Wt, b, conv = layer(ops, rng, Cin, Cout)
+    pre = onn.conv2d(x, Wt, b, pad=1, relu=True)
+    pooled, bits = _masks(pre)
+    p8 = ops.empty_c8(B, Cout, H // 2, W // 2, 'cuda')
+    m8 = torch.zeros(p8.shape, dtype=torch.uint8, device='cuda')
+    assert conv(ops.nchw_to_c8(dev(x)), pool_out=p8, mask_out=m8, store_out=False) is None
+    assert np.array_equal(from_c8(p8, Cout), pooled)
+    assert np.array_equal(mask_from_c8(m8)[:, :Cout], bits)
+    # a window of whole pooling windows leaves the rest of the pooled / mask tensors untouched
+    p8.fill_(3.0); m8.fill_(255)
+    win = conv.pool_window(H, W, (5, 9, 7, 12))
+    conv(ops.nchw_to_c8(dev(x)), pool_out=p8, mask_out=m8, store_out=False, window=win)
+    y0, x0, h, w = win[0] // 2, win[1] // 2, win[2] // 2, win[3] // 2
+    want_p = np.full_like(pooled, 3.0); want_m = np.full_like(bits, 255)
+    want_p[:, :, y0:y0 + h, x0:x0 + w] = pooled[:, :, y0:y0 + h, x0:x0 + w]
+    want_m[:, :, y0:y0 + h, x0:x0 + w] = bits[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.array_equal(from_c8(p8, Cout), want_p)
+    assert np.array_equal(mask_from_c8(m8)[:, :Cout], want_m)
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 37, 44, 64), (6, 64, 13, 13, 32)])   # RECT / FLAT
+def test_conv_c8_depool_input_from_mask_bytes(ops, shape):
+    """DePool2D (layers/mylayers.py:88-115) as the conv's input staging: up (C8) + mask bytes."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(W)
+    pre = ints(rng, B, Cin, H, W, lo=0, hi=3)          # many ties
+    pooled, bits = _masks(pre)
+    up = ints(rng, B, Cin, H // 2, W // 2)
+    unp = onn.depool_eqmask(up, pre, pooled)
+    Wt, b, conv = layer(ops, rng, Cin, Cout, relu=False)
+    ref = onn.conv2d(unp, Wt, b, pad=1, relu=False)
+    m = np.zeros((B, ops.c8_chunks(Cin), H // 2, W // 2, 8), dtype=np.uint8)
+    m[:] = bits.reshape(B, Cin // 8, 8, H // 2, W // 2).transpose(0, 1, 3, 4, 2)
+    got = conv(ops.nchw_to_c8(dev(up)), mask_in=torch.from_numpy(m).cuda(), unpool_hw=(H, W))
+    assert np.array_equal(from_c8(got, Cout), ref)
+    got = conv(ops.nchw_to_c8(dev(up)), mask_in=torch.from_numpy(m).cuda(), unpool_hw=(H, W),
+               window=(3, 2, 9, 10))
+    assert np.array_equal(from_c8(got, Cout), ref[:, :, 3:12, 2:12])
+
+
+def test_conv_c8_statistical_at_layer_size(ops):
+    """Real-valued data at a configs[1] layer size: relative RMS error of the bf16 operand rounding."""
+    rng = np.random.default_rng(9)
+    B, Cin, H, W, Cout = 4, 128, 60, 60, 128
+    x = rng.standard_normal((B, Cin, H, W))
+    Wt = rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))
+    b = 0.1 * rng.standard_normal(Cout)
+    conv = ops.Conv(Wt, b, pad=1, relu=True, mma='bf16c8')
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=True)
+    got = from_c8(conv(ops.nchw_to_c8(dev(x))), Cout)
+    rel = float(np.sqrt(((got - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean()))
+    print('C8 conv 128 -> 128 at 60x60: relative RMS error %.2e' % rel)
+    assert rel <= 8e-3
