@@ -256,7 +256,8 @@ int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1
  * call iiseg_pool_mask_c8.
  * iiseg_nchw_to_c8 / iiseg_c8_to_nchw: layout converters (fp32 NCHW <-> C8 bf16, C8n chunks/image).
  * iiseg_pool_mask_c8: 2x2 max-pool (+ mask bytes, may be NULL) of the pooled-coordinate window
- * (y0, x0, wh, ww) from a stored piece `pre` (BC8 = B * chunks, PH, PW, 8) whose corner is at
+ * (y0, x0, wh, ww) from a stored piece `pre` (BC8 = B * chunks, PH, PW, 8; bf16, or with pre_f32 the
+ * C8 fp32 results of out_kind 2: the same fp32 comparisons as the fused pool) whose corner is at
  * (py0, px0) of the (H, W) map, into the full (BC8, H/2, W/2, 8) pooled / mask tensors. */
 int iiseg_conv_c8_supported(const iiseg_conv_desc* d);
 int iiseg_conv_c8_is_flat(const iiseg_conv_desc* d);
@@ -265,8 +266,9 @@ int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const 
                   int add_kind, void* out, int out_kind, void* pool_out, uint8_t* mask_out);
 int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
 int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8n);
-int iiseg_pool_mask_c8(void* stream, const void* pre, void* pooled, uint8_t* mask, int BC8, int PH,
-                       int PW, int py0, int px0, int H, int W, int y0, int x0, int wh, int ww);
+int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled, uint8_t* mask,
+                       int BC8, int PH, int PW, int py0, int px0, int H, int W, int y0, int x0, int wh,
+                       int ww);
 
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,

@@ -75,7 +75,7 @@ SIGNATURES = {
     'iiseg_conv_c8': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 6 + [_i32, _vp, _i32, _vp, _vp]),
     'iiseg_nchw_to_c8': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
-    'iiseg_pool_mask_c8': (C.c_int, [_vp] * 4 + [_i32] * 11),
+    'iiseg_pool_mask_c8': (C.c_int, [_vp, _vp, _i32, _vp, _vp] + [_i32] * 11),
     'iiseg_conv_gemm_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5 + [C.c_uint32]),

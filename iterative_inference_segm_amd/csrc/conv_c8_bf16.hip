@@ -545,25 +545,39 @@ __global__ __launch_bounds__(256) void c8_to_nchw_kernel(const uint4* __restrict
 }
 
 // 2x2 max-pool (ignore_border) of the window (y0, x0, wh, ww) -- pooled coordinates -- of a C8 map
-// `pre` (B, C8n, PH, PW, 8), whose top-left corner sits at (py0, px0) of the full (H, W) map:
-// pooled (B, C8n, H/2, W/2, 8) and, if mask != NULL, the DePool2D mask bytes.
+// `pre` (B, C8n, PH, PW, 8; F32: fp32 chunks, the unrounded conv results, else bf16), whose top-left
+// corner sits at (py0, px0) of the full (H, W) map: pooled (B, C8n, H/2, W/2, 8) bf16 and, if
+// mask != NULL, the DePool2D mask bytes.  With F32 the comparisons are those of the fused epilogue of
+// conv_c8_kernel (fp32 values, rounded after the max), so a level gives the same masks whichever
+// pixel tiling its conv ran on.
+template <bool F32>
 __global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restrict__ pre, uint4* __restrict__ pooled,
-                                                           uint2* __restrict__ mask, int C8n, int PH, int PW,
+                                                           uint2* __restrict__ mask, int PH, int PW,
                                                            int py0, int px0, int h2, int w2, int y0, int x0,
                                                            int wh, int ww, int64_t total) {
+    constexpr int Q = F32 ? 2 : 1;                  // uint4 per chunk
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int qx = (int)(t % ww);
         int64_t r = t / ww;
         const int qy = (int)(r % wh);
         r /= wh;                                    // b * C8n + c8
         const int Y = y0 + qy, X = x0 + qx;
-        const uint4* s = pre + (r * PH + (2 * Y - py0)) * PW + (2 * X - px0);
-        const uint4 u[4] = {s[0], s[1], s[PW], s[PW + 1]};
+        const uint4* s = pre + ((r * PH + (2 * Y - py0)) * PW + (2 * X - px0)) * Q;
         float v[4][8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            v[k][0] = bf_lo(u[k].x); v[k][1] = bf_hi(u[k].x); v[k][2] = bf_lo(u[k].y); v[k][3] = bf_hi(u[k].y);
-            v[k][4] = bf_lo(u[k].z); v[k][5] = bf_hi(u[k].z); v[k][6] = bf_lo(u[k].w); v[k][7] = bf_hi(u[k].w);
+            const uint4* sk = s + ((k >> 1) * PW + (k & 1)) * Q;
+            if constexpr (F32) {
+                const uint4 a = sk[0], b = sk[1];
+                v[k][0] = __builtin_bit_cast(float, a.x); v[k][1] = __builtin_bit_cast(float, a.y);
+                v[k][2] = __builtin_bit_cast(float, a.z); v[k][3] = __builtin_bit_cast(float, a.w);
+                v[k][4] = __builtin_bit_cast(float, b.x); v[k][5] = __builtin_bit_cast(float, b.y);
+                v[k][6] = __builtin_bit_cast(float, b.z); v[k][7] = __builtin_bit_cast(float, b.w);
+            } else {
+                const uint4 u = sk[0];
+                v[k][0] = bf_lo(u.x); v[k][1] = bf_hi(u.x); v[k][2] = bf_lo(u.y); v[k][3] = bf_hi(u.y);
+                v[k][4] = bf_lo(u.z); v[k][5] = bf_hi(u.z); v[k][6] = bf_lo(u.w); v[k][7] = bf_hi(u.w);
+            }
         }
         float m[8];
         unsigned bits[8];
@@ -717,8 +731,8 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
     if (pool_out) {
         // fused pool: RECT tiling, whole pooling windows (even origin, even extent unless the window
-        // ends at the map's last, unpaired row / column), no skip-add
-        if (plan.flat || add || ((d->oy0 | d->ox0) & 1) || ((d->OH & 1) && d->oy0 + d->OH != fullH) ||
+        // ends at the map's last, unpaired row / column)
+        if (plan.flat || ((d->oy0 | d->ox0) & 1) || ((d->OH & 1) && d->oy0 + d->OH != fullH) ||
             ((d->OW & 1) && d->ox0 + d->OW != fullW))
             return IISEG_ERR_UNSUPPORTED;
     }
@@ -772,9 +786,9 @@ extern "C" int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, 
     return iiseg_check_launch();
 }
 
-extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, void* pooled, uint8_t* mask, int BC8,
-                                  int PH, int PW, int py0, int px0, int H, int W, int y0, int x0,
-                                  int wh, int ww) {
+extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled,
+                                  uint8_t* mask, int BC8, int PH, int PW, int py0, int px0, int H,
+                                  int W, int y0, int x0, int wh, int ww) {
     if (!pre || !pooled) return IISEG_ERR_NULL;
     if (BC8 <= 0 || wh <= 0 || ww <= 0) return IISEG_ERR_SHAPE;
     // every 2x2 window of the pooled region must lie inside the stored piece of the pre-pool map
@@ -783,8 +797,13 @@ extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, void* pooled, u
         return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)BC8 * wh * ww;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(pool_mask_c8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)pre, (uint4*)pooled, (uint2*)mask, 0, PH, PW, py0, px0, H / 2, W / 2,
-                       y0, x0, wh, ww, total);
+    if (pre_f32)
+        hipLaunchKernelGGL(pool_mask_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)pre, (uint4*)pooled, (uint2*)mask, PH, PW, py0, px0, H / 2,
+                           W / 2, y0, x0, wh, ww, total);
+    else
+        hipLaunchKernelGGL(pool_mask_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4*)pre, (uint4*)pooled, (uint2*)mask, PH, PW, py0, px0, H / 2,
+                           W / 2, y0, x0, wh, ww, total);
     return iiseg_check_launch();
 }

@@ -55,6 +55,8 @@ class StandardDAE:
         'bf16' = 16-bit MFMA operands with fp32 accumulation; ops.Conv)."""
         concat_h = list(concat_h)
         self.mma = mma
+        # bf16 C8 activations between the layers (ops.Conv mma='bf16c8', `_scores_c8`)
+        self.c8 = mma == 'bf16c8' and dtype == torch.float32
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
                    for el in concat_h)                                   # fcn_down.py:39-41
         if concat_h[-1] == 'input' and additional_pool == 0:
@@ -213,6 +215,10 @@ class StandardDAE:
         h_list = list(h_list)
         if len(h_list) != len(self.concat_h):
             raise ValueError('expected %d h tensors, got %d' % (len(self.concat_h), len(h_list)))
+        if self.c8:
+            if mask_override is not None:
+                raise NotImplementedError("mask injection needs fp32 activations (mma='bf16' / 'f32')")
+            return self._scores_c8(h_list, y, session)
         pos = 0
         pending_h = None
         h_fresh = session is not None and session.get('h_fresh', False)
@@ -438,6 +444,149 @@ class StandardDAE:
             self.trace.update({'pre%d' % k: v for k, v in pre.items()})
             self.trace.update({'pool%d' % k: v for k, v in pool.items() if k > 0})
         self._saved = (mask_override, pre, pool)      # what backward_y needs (masks only)
+        return t
+
+    def _scores_c8(self, h_list, y, session):
+        """`scores` with bf16 C8 activations between the layers (csrc/conv_c8_bf16.hip): the same
+        layer plan, windows (decoder dead-code elimination, loop-invariant encoder maps, border
+        stores) and fusions, in the form every level takes here --
+          encoder level p : conv3x3 + ReLU whose epilogue writes pool_p (C8) and the DePool2D mask
+                            bytes of its windows, taken from the fp32 results; the pre-pool map is
+                            never stored (fcn_down.py:102-122);
+          decoder level p : conv3x3 whose input staging IS DePool2D (fused_up_{p+1} chunk + mask
+                            bytes, layers/mylayers.py:88-115), skip sum with pool_{p-1} and the crop
+                            in the epilogue (fcn_up.py:64-113); the last one writes fp32 NCHW scores.
+        y arrives fp32 NCHW and is converted once per call; the h half of the conv behind a concat
+        point is a cached fp32 C8 addend (loop-invariant, `hsplit`)."""
+        if self.conv_before_pool != 1 or self.bn or self.unpool_type == 'standard' or \
+                self.trace is not None or self.keep_pre or \
+                (self.emulate_noise and (self.noise > 0 or self.dropout > 0)):
+            raise NotImplementedError("mma='bf16c8' runs the plain trackind / inverse DAE "
+                                      "(conv_before_pool=1, bn=0, no trace / gradient mode / noise "
+                                      "emulation): use mma='bf16' for those")
+        B, dev = y.shape[0], y.device
+        pos, pending_h = 0, None
+        h_fresh = session is not None and session.get('h_fresh', False)
+        if self.concat_h[pos] == 'input':
+            pending_h, pos = h_list[pos], pos + 1
+        primed = session is not None and session.get('primed', False) and self.licm
+        if session is not None:
+            if primed and session.get('masked') != 'c8':
+                primed = False
+            session['masked'] = 'c8'
+            if not primed:
+                session['gen'] = session.get('gen', 0) + 1
+        t = ops.nchw_to_c8(y)
+        pre_hw, pool8, masks = {}, {}, {}
+        pool_hw = {0: (y.shape[2], y.shape[3])}
+        dep = (0, 0, y.shape[2], y.shape[3])
+
+        def clip(lo, hi, size):
+            lo, hi = max(lo, 0), min(hi, size)
+            return lo, max(hi - lo, 0)
+
+        for p in range(self.total):                      # fcn_down.py:77-136
+            name = 'conv%d_1' % (p + 1)
+            conv = self.enc[name]
+            fh, fw = conv.out_hw(t.shape[2], t.shape[3])
+            pre_hw[p + 1] = (fh, fw)
+            if primed and pending_h is not None and h_fresh:
+                hd = session['h_dep'][pos - 1]           # a new batch: h changed inside its region
+                y1 = max(dep[0] + dep[2], hd[0] + hd[2])
+                x1 = max(dep[1] + dep[3], hd[1] + hd[3])
+                dep = (min(dep[0], hd[0]), min(dep[1], hd[1]), 0, 0)
+                dep = (dep[0], dep[1], y1 - dep[0], x1 - dep[1])
+            kw = {}
+            if primed:
+                wy0, wh = clip(dep[0] + conv.pad - 2, dep[0] + dep[2] + conv.pad, fh)
+                wx0, ww = clip(dep[1] + conv.pad - 2, dep[1] + dep[3] + conv.pad, fw)
+                dep = (wy0, wx0, wh, ww)
+                kw['window'] = conv.pool_window(t.shape[2], t.shape[3], dep)
+                pooled_t, m = session['pool%d' % (p + 1)], session['mask%d' % (p + 1)]
+            else:
+                pooled_t = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev)
+                m = torch.empty(pooled_t.shape, dtype=torch.uint8, device=dev)
+            kw.update(pool_out=pooled_t, mask_out=m, store_out=False)
+            if pending_h is not None and name in self.hsplit:
+                conv_h, conv_y = self.hsplit[name]
+                keep = session is not None and self.licm
+                hb = session.get('hb_' + name) if keep else None
+                if hb is None:                           # loop-invariant: once per refine()
+                    hb = conv_h(ops.nchw_to_c8(pending_h), out_format='c8f32')
+                    if keep:
+                        session['hb_' + name] = hb
+                elif h_fresh:                            # reused session: only where h changed
+                    hd = session['h_dep'][pos - 1]
+                    hy0, hh = clip(hd[0] + conv_h.pad - 2, hd[0] + hd[2] + conv_h.pad, hb.shape[2])
+                    hx0, hw = clip(hd[1] + conv_h.pad - 2, hd[1] + hd[3] + conv_h.pad, hb.shape[3])
+                    conv_h(ops.nchw_to_c8(pending_h), window=(hy0, hx0, hh, hw), out=hb,
+                           place=(hy0, hx0), out_format='c8f32')
+                off = (kw['window'][0], kw['window'][1]) if 'window' in kw else (0, 0)
+                conv_y(t, add=hb, add_off=off, **kw)
+                pending_h = None
+            elif pending_h is not None:                  # h first, then features (P13)
+                conv(ops.nchw_to_c8(pending_h), x2=t, **kw)
+                pending_h = None
+            else:
+                conv(t, **kw)
+            if session is not None and not primed:
+                session['pool%d' % (p + 1)], session['mask%d' % (p + 1)] = pooled_t, m
+            if self.conv_log is not None:
+                cw_ = kw['window'] if 'window' in kw else (0, 0, fh, fw)
+                self.conv_log.append((name, conv.flops(B, fh, fw), conv.flops(B, cw_[2], cw_[3])))
+            pool8[p + 1], masks[p + 1] = pooled_t, m
+            pool_hw[p + 1] = (fh // 2, fw // 2)
+            if primed:
+                qy0, qh = clip(dep[0] // 2, (dep[0] + dep[2] + 1) // 2, fh // 2)
+                qx0, qw = clip(dep[1] // 2, (dep[1] + dep[3] + 1) // 2, fw // 2)
+                dep = (qy0, qx0, qh, qw)
+            t = pooled_t
+            if p < self.n_pool and pos < len(self.concat_h) and \
+                    self.concat_h[pos] == 'pool%d' % (p + 1):   # :131-134
+                pending_h, pos = h_list[pos], pos + 1
+        if session is not None:
+            session['primed'] = True
+            session['h_fresh'] = False
+        if pending_h is not None:
+            raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
+                                      '(additional_pool=0); not shape-consistent in the reference')
+        # ---- decoder, fcn_up.py:143-151 (windows as in `scores`) -------------------------------
+        geom = {}
+        for p in range(self.total, 0, -1):
+            ph, pw = pre_hw[p]
+            oh, ow = min(ph, pool_hw[p - 1][0]), min(pw, pool_hw[p - 1][1])
+            geom[p] = (ph, pw, oh, ow, _center(ph, oh), _center(pw, ow))
+        win = {1: (0, 0, geom[1][2], geom[1][3])}
+        for p in range(1, self.total):
+            ph, pw, oh, ow, cy, cx = geom[p]
+            y0, x0, nh, nw = win[p]
+            uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)
+            uy1, ux1 = min(cy + y0 + nh + 1, ph), min(cx + x0 + nw + 1, pw)
+            qh, qw = geom[p + 1][2], geom[p + 1][3]
+            ny0, nx0 = uy0 // 2, ux0 // 2
+            ny1, nx1 = min((uy1 + 1) // 2, qh), min((ux1 + 1) // 2, qw)
+            win[p + 1] = (ny0, nx0, ny1 - ny0, nx1 - nx0)
+        need = win if self.dce else {p: (0, 0, geom[p][2], geom[p][3]) for p in geom}
+        for p in range(self.total, 0, -1):
+            name = 'up_conv%d' % p
+            conv = self.dec[name]
+            ph, pw, oh, ow, cy, cx = geom[p]
+            y0, x0, nh, nw = need[p]
+            full = (nh, nw) == (oh, ow)
+            out = None
+            if not full:
+                out = torch.empty((B, conv.Cout, oh, ow), dtype=torch.float32, device=dev) if p == 1 \
+                    else ops.empty_c8(B, conv.Cout, oh, ow, dev)
+            kw = dict(mask_in=masks[p], unpool_hw=(ph, pw), window=(cy + y0, cx + x0, nh, nw),
+                      out=out, place=None if full else (y0, x0),
+                      out_format='nchw' if p == 1 else 'c8')
+            if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
+                oth = pool_hw[p - 1]
+                kw.update(add=pool8[p - 1], add_off=(_center(oth[0], oh) + y0, _center(oth[1], ow) + x0))
+            t = conv(t, **kw)                            # else :104-113 CroppingLayer
+            if self.conv_log is not None:
+                self.conv_log.append((name, conv.flops(B, ph, pw), conv.flops(B, nh, nw)))
+        self._saved = None
         return t
 
     # ---- true-gradient mode (SURVEY 8f rank 4; not in the reference, F1) -----------------------

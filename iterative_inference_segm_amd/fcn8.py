@@ -53,7 +53,9 @@ class FCN8:
     def __init__(self, params, n_classes, layer=('probs_dimshuffle',), pad=100, temperature=1.0,
                  device='cuda', dtype=torch.float32, mma=None):
         """mma: matrix-pipe operand precision of the float32 path's convolutions ('f32' default,
-        'bf16' = 16-bit MFMA operands with fp32 accumulation; ops.Conv)."""
+        'bf16' = 16-bit MFMA operands with fp32 accumulation; 'bf16c8' = additionally bf16 C8
+        activations between the 3x3 layers, the h maps handed out stay fp32 NCHW; ops.Conv)."""
+        self.c8 = mma == 'bf16c8' and dtype == torch.float32
         self.layer = list(layer)
         self.n_classes = n_classes
         self.pad = pad
@@ -112,6 +114,9 @@ class FCN8:
         primed = session is not None and session.get('primed', False)
         net = {'input': x}
         t = x
+        c8 = self.c8 and not hs
+        if c8:
+            t = ops.nchw_to_c8(x)                  # bf16 C8 from here to pool5 (conv_c8_bf16.hip)
         dep = (0, 0, x.shape[2], x.shape[3])       # region of `t` that depends on x
         deps = {}
         pending = hs.get('input')
@@ -132,10 +137,17 @@ class FCN8:
                         if primed:
                             fused_pool = session['pool%d' % (bi + 1)]
                             kw.update(window=pw_, place=(pw_[0], pw_[1]))
+                        elif c8:
+                            fused_pool = ops.empty_c8(t.shape[0], conv.Cout, fh // 2, fw // 2, t.device)
                         else:
                             fused_pool = torch.empty((t.shape[0], conv.Cout, fh // 2, fw // 2),
                                                      dtype=t.dtype, device=t.device)
                         kw['pool_out'] = fused_pool
+                        if c8:
+                            # C8: nothing reads the pre-pool map of a block's last conv
+                            kw = dict(pool_out=fused_pool, store_out=False)
+                            if primed:
+                                kw['window'] = pw_
                 if pending is not None:
                     t = self._conv(name, pending, x2=t, **kw)
                     pending = None
@@ -144,7 +156,7 @@ class FCN8:
                 if session is not None and not primed:
                     session[name] = t
             pname = 'pool%d' % (bi + 1)
-            dep = _pool_region(dep, t.shape[2] // 2, t.shape[3] // 2)
+            dep = _pool_region(dep, fh // 2, fw // 2)
             if fused_pool is not None:
                 t = fused_pool
                 if session is not None and not primed:
@@ -160,6 +172,13 @@ class FCN8:
             pending = hs.get(pname)
         if session is not None:
             session['primed'] = True
+        if c8:
+            # the h maps of the API, the 1x1 score layers and fc6 take fp32 NCHW
+            f32 = {k: ops.c8_to_nchw(v, self.convs[_BLOCKS[int(k[-1]) - 1][-1]].Cout)
+                   for k, v in net.items() if k.startswith('pool') and
+                   (k in self.layer or k in ('pool3', 'pool4'))}
+            net.update(f32)
+            t = ops.c8_to_nchw(t, self.convs['conv5_3'].Cout)
         if pending is not None:          # concat after pool5 feeds fc6 (7x7: table kernel)
             t = self._conv('fc6', pending, x2=t)
         else:
@@ -189,7 +208,8 @@ class FCN8:
             t = net[el]
             tag = None
             if own and el.startswith('pool'):
-                t = t.clone()
+                if not c8:                   # (C8: already a fresh fp32 copy of the stored map)
+                    t = t.clone()
                 tag = ((self._uid, session['key']), deps[el])
             res.append(t)
             prov.append(tag)
@@ -206,10 +226,14 @@ class FCN8:
         if self.conv_log is not None:
             # (name, nominal FLOPs of the full layer, FLOPs of the computed window)
             fh, fw = conv.out_hw(t.shape[2], t.shape[3])
-            ch, cw = (kw['window'][2], kw['window'][3]) if 'window' in kw else \
-                (out.shape[2], out.shape[3])
-            self.conv_log.append((name, conv.flops(out.shape[0], fh, fw),
-                                  conv.flops(out.shape[0], ch, cw)))
+            if kw.get('window') is not None:
+                ch, cw = kw['window'][2], kw['window'][3]
+            elif out is not None:
+                ch, cw = out.shape[2], out.shape[3]
+            else:
+                ch, cw = fh, fw
+            self.conv_log.append((name, conv.flops(t.shape[0], fh, fw),
+                                  conv.flops(t.shape[0], ch, cw)))
         return out
 
     def _deconv_sum(self, deconv, t, score_name, pool):
@@ -228,8 +252,9 @@ class FCN8DAE:
                  dtype=torch.float32, mma=None):
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input'] for el in concat_h)  # :33-34
         self.concat_h = list(concat_h)
+        # (the concat points of this kind are two-source gathers: fp32 NCHW activations)
         self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype,
-                        mma=mma)
+                        mma='bf16' if mma == 'bf16c8' else mma)
         self.net.fold_border = False       # the border depends on h here: sessions only
         self.licm = os.environ.get('IISEG_ENCODER_LICM', '1') != '0'
 

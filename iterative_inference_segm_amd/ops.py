@@ -631,13 +631,15 @@ class Conv:
         flat_pool = pool_out is not None and bool(lib.iiseg_conv_c8_is_flat(C.byref(d)))
         tmp = None
         if flat_pool:
-            # flat pixel tiling (small windows): the conv stores its window, a second kernel pools it
-            if not store_out:
-                tmp = torch.empty((B, oc8, OH, OW, 8), dtype=torch.bfloat16, device=x1.device)
-                d.out_H = d.out_W = d.out_y0 = d.out_x0 = 0
-            conv_out, conv_kind, conv_pool, conv_mask = (tmp if tmp is not None else out), 1, None, None
-            if tmp is None and fmt != 'c8':
-                raise RuntimeError('pooling a C8 layer needs a bf16 C8 output')
+            # flat pixel tiling (small windows; no fused pool): the conv stores its window as fp32
+            # chunks, a second kernel takes max and mask bits from those -- the very comparisons of
+            # the fused epilogue, so a level's masks do not depend on the tiling its conv ran on
+            if store_out:
+                raise RuntimeError('a flat-tiled C8 layer pools from a private fp32 copy of its '
+                                   'window: call it with store_out=False')
+            tmp = torch.empty((B, oc8, OH, OW, 8), dtype=torch.float32, device=x1.device)
+            d.out_H = d.out_W = d.out_y0 = d.out_x0 = 0
+            conv_out, conv_kind, conv_pool, conv_mask = tmp, 2, None, None
         else:
             conv_out, conv_kind, conv_pool, conv_mask = out, kind, pool_out, mask_out
         prof = CONV_PROFILE
@@ -648,14 +650,7 @@ class Conv:
         if prof is not None:
             prof.append(('conv_c8_kernel', self.flops(B, OH, OW), ev0, _ev()))
         if flat_pool:
-            src = tmp if tmp is not None else out
-            if tmp is not None:
-                ph_, pw_, py0, px0 = OH, OW, oy0, ox0
-            else:
-                ph_, pw_ = out.shape[2], out.shape[3]
-                py0 = oy0 - (int(place[0]) if place is not None else 0)
-                px0 = ox0 - (int(place[1]) if place is not None else 0)
-            pool_mask_c8(src, pool_out, mask_out, (py0, px0), (fullH, fullW),
+            pool_mask_c8(tmp, pool_out, mask_out, (oy0, ox0), (fullH, fullW),
                          (oy0 // 2, ox0 // 2, min((oy0 + OH) // 2, fullH // 2) - oy0 // 2,
                           min((ox0 + OW) // 2, fullW // 2) - ox0 // 2))
         return out
@@ -826,14 +821,15 @@ def c8_to_nchw(x8, channels, out=None):
 
 def pool_mask_c8(pre, pooled, mask, origin, full_hw, window):
     """2x2 max-pool (+ DePool2D mask bytes, `mask` may be None) of the pooled-coordinate `window`
-    (y0, x0, h, w) from the stored piece `pre` (C8) whose corner sits at `origin` of the `full_hw`
-    map, into the full-size `pooled` / `mask` tensors."""
+    (y0, x0, h, w) from the stored piece `pre` (C8 bf16, or C8 fp32: the unrounded conv results)
+    whose corner sits at `origin` of the `full_hw` map, into the full-size `pooled` / `mask` tensors."""
     B, C8n, PH, PW, _ = pre.shape
     y0, x0, wh, ww = window
     if wh <= 0 or ww <= 0:
         return pooled
     check(_lib.load().iiseg_pool_mask_c8(
-        _stream(), C.c_void_p(pre.data_ptr()), C.c_void_p(pooled.data_ptr()),
+        _stream(), C.c_void_p(pre.data_ptr()), 1 if pre.dtype == torch.float32 else 0,
+        C.c_void_p(pooled.data_ptr()),
         None if mask is None else C.c_void_p(mask.data_ptr()), B * C8n, PH, PW, int(origin[0]),
         int(origin[1]), int(full_hw[0]), int(full_hw[1]), int(y0), int(x0), int(wh), int(ww)),
         'iiseg_pool_mask_c8')

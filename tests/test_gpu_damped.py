@@ -17,8 +17,9 @@ criterion:
       and such bits are < 1e-5 of all bits at every step.
   (C) the float64 HIP path itself is pinned to the float64 CPU oracle on THIS set (one image, two
       steps, 1e-10), as it is on the default set by tests/test_gpu_f64.py.
-  (D) bf16 operands: refined argmax agreement >= 0.99 with float64; labels = argmax of the
-      float64-refined map, so mIoU(float64) == 1 and |mIoU(bf16) - 1| <= 0.05 is a real statement.
+  (D) bf16 operands (fp32 activations, mma='bf16', and bf16 C8 activations, mma='bf16c8'): refined
+      argmax agreement >= 0.99 with float64; labels = argmax of the float64-refined map, so
+      mIoU(float64) == 1 and |mIoU(bf16) - 1| <= 0.05 is a real statement.
 """
 import numpy as np
 import pytest
@@ -194,18 +195,19 @@ def test_fp32_free_running_fixed_tolerance(built_lib):
 
 def test_bf16_agreement_and_miou_fixed_tolerance(built_lib):
     """(D): 16 images, 10 steps; labels are the argmax of the float64-refined map."""
-    ii16, ii32, ii64 = engine(F32, 'bf16'), engine(F32), engine(F64)
-    cm = {k: np.zeros((11, 12)) for k in ('bf16', 'f32', 'f64')}
-    agree, agree_fcn = {'bf16': [], 'f32': []}, []
+    ii16, ii32, ii64, iic8 = engine(F32, 'bf16'), engine(F32), engine(F64), engine(F32, 'bf16c8')
+    cm = {k: np.zeros((11, 12)) for k in ('bf16', 'c8', 'f32', 'f64')}
+    agree, agree_fcn = {'bf16': [], 'c8': [], 'f32': []}, []
     for i in range(2):
         X = S.make_images(8, 224, 224, seed=700 + i)
         res = {}
-        for k, ii in (('f64', ii64), ('f32', ii32), ('bf16', ii16)):
+        engines = (('f64', ii64), ('f32', ii32), ('bf16', ii16), ('c8', iic8))
+        for k, ii in engines:
             out = ii.pred_fcn_fn(X)
             Yii = ii.refine(out[:-1], out[-1], STEP, NSTEPS, early_stop=False)[0]
             res[k] = (out[-1], Yii)
         T = S.labels_from_map(host(res['f64'][1]), seed=800 + i)
-        for k, ii in (('f64', ii64), ('f32', ii32), ('bf16', ii16)):
+        for k, ii in engines:
             cm[k] += ii.val_device(res[k][1], T).cm.cpu().numpy().reshape(11, 12)
         ref = res['f64'][1].argmax(1)
         agree_fcn.append(float((res['bf16'][0].argmax(1) == res['f64'][0].argmax(1)).double().mean()))
@@ -217,10 +219,11 @@ def test_bf16_agreement_and_miou_fixed_tolerance(built_lib):
         tp = np.diag(c)
         with np.errstate(invalid='ignore', divide='ignore'):
             miou[k] = float(np.nanmean(tp / (c.sum(1) + c.sum(0) - tp)))
-    print('damped set, 16 images x %d steps: mIoU f64 %.5f fp32 %.5f bf16 %.5f; refined argmax '
-          'agreement with f64: fp32 %.5f bf16 %.5f (bf16 FCN-8 output %.5f)'
-          % (NSTEPS, miou['f64'], miou['f32'], miou['bf16'], np.mean(agree['f32']),
-             np.mean(agree['bf16']), np.mean(agree_fcn)))
+    print('damped set, 16 images x %d steps: mIoU f64 %.5f fp32 %.5f bf16 %.5f bf16+C8 %.5f; refined '
+          'argmax agreement with f64: fp32 %.5f bf16 %.5f bf16+C8 %.5f (bf16 FCN-8 output %.5f)'
+          % (NSTEPS, miou['f64'], miou['f32'], miou['bf16'], miou['c8'], np.mean(agree['f32']),
+             np.mean(agree['bf16']), np.mean(agree['c8']), np.mean(agree_fcn)))
     assert miou['f64'] == 1.0
     assert np.mean(agree['f32']) >= 0.9999 and abs(miou['f32'] - 1.0) <= 1e-3
     assert np.mean(agree['bf16']) >= 0.99 and abs(miou['bf16'] - 1.0) <= 0.05
+    assert np.mean(agree['c8']) >= 0.99 and abs(miou['c8'] - 1.0) <= 0.05     # C8 activations
