@@ -117,16 +117,20 @@ struct C8Params {
     int debug;
 };
 
-// BM: output channels per workgroup (64; 32 for the class-score layer).  4 waves, each BM x 64 pixels.
-template <int BM, bool FLAT, bool UNPOOL, bool OUTF32>
+// BM: output channels per workgroup (64; 32 for the class-score layer).  4 waves, each BM channels x
+// TN 32-pixel columns: TN = 2 -> 8 x 32 pixel tiles (or 256 flat pixels), TN = 4 -> 16 x 32 pixel
+// tiles: twice the MFMAs per k-tile between two barriers, per weight DMA and per workgroup prologue /
+// epilogue -- the form of the large-window layers (few k-tiles, the fixed costs of a tile dominate).
+template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32>
 __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
-    constexpr int TH = 8, TW = 32;
+    constexpr int TH = 4 * TN, TW = 32;
+    static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
     constexpr int PCAP = FLAT ? 480 : (TH + 2) * (TW + 2);   // patch chunks per 8-channel half
     // (buffer size = whole 256-chunk DMA rounds: every wave issues all NE pieces, lanes past the patch
     // write zeros into the unused tail)
     constexpr int NE = (2 * PCAP + 255) / 256;
     constexpr int NCHK = NE * 256;
-    constexpr int TM = BM / 32, TN = 2;
+    constexpr int TM = BM / 32;
     constexpr int WCH = 18 * BM;                             // weight chunks per k-tile
     constexpr int WPT = (WCH + 255) / 256;
     static_assert(WCH % 64 == 0, "a wave's DMA piece is whole");
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
             bpos[j] = (eb[j] * (p.OH + 2) + ey[j] - vmin) * PWs + ex[j];
         } else {
             eb[j] = 0;
-            ey[j] = wy0 + wave * 2 + j; ex[j] = wx0 + l31;
+            ey[j] = wy0 + wave * TN + j; ex[j] = wx0 + l31;
             eok[j] = ey[j] < p.OH && ex[j] < p.OW;
-            bpos[j] = (wave * 2 + j) * PWs + l31;
+            bpos[j] = (wave * TN + j) * PWs + l31;
         }
     }
 
@@ -352,6 +356,9 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
             constexpr int tap = decltype(TAP)::value;
             if constexpr (tap + 1 < 9) lds_operands(ic<tap + 1>{}, ic<(tap + 1) & 1>{});
+            // (the reads of tap t+1 stay IN FRONT of the MFMAs of tap t: left to itself hipcc sinks them
+            // behind three of the four MFMAs and then waits for them one MFMA later)
+            __builtin_amdgcn_sched_barrier(0);
             {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -434,12 +441,17 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
             opix[j] = (unsigned)(eb[j] * oct8 * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
             apix[j] = (unsigned)(eb[j] * co8 * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
         }
-        // fused pool (RECT): the wave's two rows are one row pair, lane ^ 1 is the column partner
-        const int q_wy = wy0 + wave * 2, q_wx = wx0 + l31;
-        const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
-        const bool q_ok = pooling && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
-                          q_py < p.pool_H && q_px < p.pool_W;
-        const unsigned q_pix = (unsigned)(q_py * p.pool_W + q_px);
+        // fused pool (RECT): the wave's rows are TN / 2 row pairs, lane ^ 1 is the column partner
+        bool q_ok[TN / 2];
+        unsigned q_pix[TN / 2];
+#pragma unroll
+        for (int jp = 0; jp < TN / 2; ++jp) {
+            const int q_wy = wy0 + wave * TN + 2 * jp, q_wx = wx0 + l31;
+            const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
+            q_ok[jp] = pooling && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
+                       q_py < p.pool_H && q_px < p.pool_W;
+            q_pix[jp] = (unsigned)(q_py * p.pool_W + q_px);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -482,23 +494,26 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         // 2x2 max-pool of fp32 values + DePool2D mask bits (y & 1) * 2 + (x & 1):
                         // pre == pooled (layers/mylayers.py:111-114), window = rows (j = 0, 1) x
                         // columns (lane, lane ^ 1); the even lane stores
+#pragma unroll
+                        for (int jp = 0; jp < TN / 2; ++jp) {
                         f32x4 m;
                         unsigned bits[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float a0 = v[0][q], a1 = v[1][q];
+                            const float a0 = v[2 * jp][q], a1 = v[2 * jp + 1][q];
                             const float b0 = dpp_xor1(a0), b1 = dpp_xor1(a1);
                             m[q] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
                             const unsigned c = (unsigned)(l31 & 1);
                             const unsigned own = ((a0 == m[q] ? 1u : 0u) << c) | ((a1 == m[q] ? 1u : 0u) << (2 + c));
                             bits[q] = own | dpp_xor1(own);
                         }
-                        const unsigned po = q_pix + (unsigned)(c8 * PPL);
+                        const unsigned po = q_pix[jp] + (unsigned)(c8 * PPL);
                         u32x2 w2;
                         w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
-                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)((q_ok && cok) ? po * 16u + 8u * lh : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)((q_ok[jp] && cok) ? po * 16u + 8u * lh : OOB), 0, 0);
                         const unsigned mb = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
-                        __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)((q_ok && cok) ? po * 8u + 4u * lh : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)((q_ok[jp] && cok) ? po * 8u + 4u * lh : OOB), 0, 0);
+                        }
                     }
                 }
             }
@@ -616,6 +631,7 @@ int flat_patch_rows(int B, int OH, int OW) {
 
 struct C8Plan {
     bool flat;
+    bool tall;      // RECT with 16-row tiles (TN = 4)
     int PR;
 };
 
@@ -651,6 +667,13 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
         const double fill = (double)d->OH * d->OW / ((double)ty * 8 * tx * 32);
         plan->flat = false;
         plan->PR = 0;
+        // 16-row tiles where the window is tall enough that they cost at most 8 % more padded rows
+        // than 8-row tiles and the launch still fills the chip several times over
+        static const int tall_env = getenv("IISEG_C8_TALL") ? atoi(getenv("IISEG_C8_TALL")) : -1;
+        const int r8 = (d->OH + 7) / 8 * 8, r16 = (d->OH + 15) / 16 * 16;
+        const int64_t wgs16 = (int64_t)d->B * (r16 / 16) * tx * ((d->Cout + 63) / 64);
+        plan->tall = d->Cout > 32 && r16 * 100 <= r8 * 108 && wgs16 >= 1024;
+        if (tall_env >= 0) plan->tall = tall_env != 0 && d->Cout > 32;
         static const int force = getenv("IISEG_C8_TILING") ? atoi(getenv("IISEG_C8_TILING")) : 0;  // 1 rect, 2 flat
         if ((fill < 0.75 || force == 2) && force != 1 && d->C2 == 0 &&
             (int64_t)d->B * cmax * d->H * d->W * 2 < (1ll << 31) &&
@@ -659,6 +682,7 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
             const int pr = flat_patch_rows(d->B, d->OH, d->OW);
             if (pr * (d->OW + 2) <= FLAT_PCAP) {
                 plan->flat = true;
+                plan->tall = false;
                 plan->PR = pr;
             }
         }
@@ -669,23 +693,26 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
 template <int BM, bool OUTF32>
 int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
     p.n_mtiles = p.Mpad / BM;
+    const int th = plan.tall ? 16 : 8;
     if (plan.flat) {
         p.N = p.B * p.OH * p.OW;
         p.PR = plan.PR;
         p.PWs = p.OW + 2;
         p.n_ptiles = (p.N + 255) / 256;
     } else {
-        p.tiles_y = (p.OH + 7) / 8;
+        p.tiles_y = (p.OH + th - 1) / th;
         p.tiles_x = (p.OW + 31) / 32;
         p.n_ptiles = p.B * p.tiles_y * p.tiles_x;
     }
     const int grid = p.n_ptiles * p.n_mtiles;
-#define C8_LAUNCH(FL, UN) \
-    hipLaunchKernelGGL((conv_c8_kernel<BM, FL, UN, OUTF32>), dim3(grid), dim3(256), 0, s, p)
+#define C8_LAUNCH(TNV, FL, UN) \
+    hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32>), dim3(grid), dim3(256), 0, s, p)
     if (plan.flat) {
-        if (unpool) C8_LAUNCH(true, true); else C8_LAUNCH(true, false);
+        if (unpool) C8_LAUNCH(2, true, true); else C8_LAUNCH(2, true, false);
+    } else if (plan.tall && BM == 64) {
+        if (unpool) C8_LAUNCH(4, false, true); else C8_LAUNCH(4, false, false);
     } else {
-        if (unpool) C8_LAUNCH(false, true); else C8_LAUNCH(false, false);
+        if (unpool) C8_LAUNCH(2, false, true); else C8_LAUNCH(2, false, false);
     }
 #undef C8_LAUNCH
     return iiseg_check_launch();
