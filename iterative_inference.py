@@ -151,9 +151,15 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
               training_dict={}, data_augmentation=False, which_set='test', ae_h=False,
               full_im_ft=False, savepath=None, loadpath=None, test_from_0_255=False,
               weights_path=None, synthetic=False, n_images=20, image_size=(224, 224),
-              batch_size=10, early_stop=True, save_npz=True, verbose=True, update='residual'):
+              batch_size=10, early_stop=True, save_npz=True, verbose=True, update='residual',
+              dry_run=False):
     """Signature of reference iterative_inference.py:56-59 plus keyword-only extras.
-    Returns a dict of the three summary lines (the reference returns None and only prints)."""
+    Returns a dict of the three summary lines (the reference returns None and only prints).
+
+    dry_run: rehearse the multi-rank protocol without any HIP work (CPU, gloo): argument handling,
+    rendezvous from the torchrun environment, rank-0 directory / config.txt creation, the sharding
+    of the reference batches over ranks, one all-reduce of the three metric accumulators and the
+    summary from rank 0.  The per-batch "metrics" are counts of the synthetic labels themselves."""
     # Update DAE parameters (:64-79)
     dae_dict = {'kind': 'fcn8', 'dropout': 0.0, 'skip': True, 'unpool_type': 'standard',
                 'n_filters': 64, 'conv_before_pool': 1, 'additional_pool': 0,
@@ -169,7 +175,7 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     if savepath is None:
         raise ValueError('A saving directory must be specified')
 
-    rank, world, device = iidist.init_from_env()
+    rank, world, device = iidist.init_from_env('cpu' if dry_run else None)
     say = print if (verbose and rank == 0) else (lambda *a, **k: None)
     loadpath = loadpath if loadpath is not None else LOADPATH
     weights_path = weights_path if weights_path is not None else WEIGHTS_PATH
@@ -188,6 +194,9 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
                     f.write('{} = {}\n'.format(key, value))
     iidist.barrier()
 
+    if dry_run:
+        return _dry_run(dataset, which_set, synthetic, n_images, image_size, batch_size,
+                        test_from_0_255, rank, world, device, say)
     ii, data_iter = build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_set,
                                    device, synthetic=synthetic, n_images=n_images,
                                    image_size=image_size, batch_size=batch_size,
@@ -254,6 +263,38 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     return summary
 
 
+def _dry_run(dataset, which_set, synthetic, n_images, image_size, batch_size, test_from_0_255,
+             rank, world, device, say):
+    """The data-parallel protocol of `inference` on CPU: same data iterator, same sharding, same
+    accumulators and all-reduce; a batch's confusion counts are those of its labels against
+    themselves (diagonal), so the reduced summary is checkable: Jaccard 1, every batch counted once."""
+    data_iter = load_data(dataset, {}, one_hot=True, batch_size=[batch_size, 5, batch_size],
+                          return_0_255=test_from_0_255, which_set=which_set, synthetic=synthetic,
+                          n_images=n_images, image_size=image_size)
+    n_classes = data_iter.non_void_nclasses
+    tot = {k: iidist.EvalAccumulator(n_classes) for k in ('fcn', 'dae', 'ii')}
+    mine = iidist.shard_batches(data_iter.nbatches, rank, world)
+    for i in mine:
+        _, L = data_iter.batch(i) if hasattr(data_iter, 'batch') else data_iter.next()
+        counts = np.asarray(L)[:, :n_classes].sum(axis=(0, 2, 3))
+        cm = np.zeros((n_classes, n_classes + 1))
+        cm[np.arange(n_classes), np.arange(n_classes)] = counts
+        for acc in tot.values():
+            acc.add_batch(cm, 1.0, 0.0)
+    for acc in tot.values():
+        acc.all_reduce(device)
+    summary = {}
+    for label, key in (('>>>>> FCN:', 'fcn'), ('>>>>> FCN+DAE:', 'dae'),
+                       ('>>>>> ITERATIVE INFERENCE:', 'ii')):
+        loss, acc, miou, iou, nb = tot[key].results()
+        summary[key] = {'loss': loss, 'acc': acc, 'jaccard': miou, 'per_class': iou.tolist(),
+                        'batches': nb}
+        say(label + '\n    Loss: %s\n    Acc: %s\n    Jaccard: %s' % (loss, acc, miou))
+    say('DRY RUN: %d ranks, %d batches reduced, rank 0 owned %s' % (world, summary['ii']['batches'], mine))
+    iidist.barrier()
+    return summary
+
+
 def _json_dict(s):
     return json.loads(s) if isinstance(s, str) else s
 
@@ -291,6 +332,8 @@ def main():
     parser.add_argument('--image_size', type=int, nargs=2, default=[224, 224])
     parser.add_argument('--batch_size', type=int, default=10)
     parser.add_argument('--no_early_stop', action='store_true')
+    parser.add_argument('--dry_run', action='store_true',
+                        help='CPU rehearsal of the multi-rank protocol (gloo), no HIP work')
     parser.add_argument('--update', choices=['residual', 'gradient'], default='residual',
                         help="'residual': the reference's y += step*(r - y) (default); 'gradient': "
                              "descend the true gradient of ||r(y|h) - y||^2 (extension)")
@@ -303,7 +346,7 @@ def main():
               training_dict=args.training_dict, weights_path=args.weights_path,
               synthetic=args.synthetic, n_images=args.n_images,
               image_size=tuple(args.image_size), batch_size=args.batch_size,
-              early_stop=not args.no_early_stop, update=args.update)
+              early_stop=not args.no_early_stop, update=args.update, dry_run=args.dry_run)
 
 
 if __name__ == '__main__':

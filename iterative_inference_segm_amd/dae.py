@@ -54,6 +54,7 @@ class StandardDAE:
         """mma: matrix-pipe operand precision of the float32 path's convolutions ('f32' default,
         'bf16' = 16-bit MFMA operands with fp32 accumulation; ops.Conv)."""
         concat_h = list(concat_h)
+        mma = mma or ops.DEFAULT_MMA
         self.mma = mma
         # bf16 C8 activations between the layers (ops.Conv mma='bf16c8', `_scores_c8`)
         self.c8 = mma == 'bf16c8' and dtype == torch.float32

@@ -55,6 +55,7 @@ class FCN8:
         """mma: matrix-pipe operand precision of the float32 path's convolutions ('f32' default,
         'bf16' = 16-bit MFMA operands with fp32 accumulation; 'bf16c8' = additionally bf16 C8
         activations between the 3x3 layers, the h maps handed out stay fp32 NCHW; ops.Conv)."""
+        mma = mma or ops.DEFAULT_MMA
         self.c8 = mma == 'bf16c8' and dtype == torch.float32
         self.layer = list(layer)
         self.n_classes = n_classes

@@ -264,3 +264,52 @@ def test_config5_multi_concat_standard_dae_50_steps(built_lib):
     o = k32.pred_fcn_fn(X[:1])
     bits, flips, err = teacher_forced_mask_check(k32, o[:-1], o[-1], dp64, 6, dae_kw=kw)
     print('multi-concat DAE: mask bits %d, near-tie flips %d, forced err %.2e' % (bits, flips, err))
+
+
+# ---------------------------------------------------------------------------------------------
+# dae kind 'fcn8' at full size (the DEFAULT kind of inference(), iterative_inference.py:64)
+# ---------------------------------------------------------------------------------------------
+def test_fcn8_kind_dae_full_size(built_lib):
+    """`buildFCN8_DAE` (models/fcn8_dae.py:19-271) at real widths and 224x224: an FCN-8 on y (11
+    channels) with h concatenated at the input (the image, 3 channels) and after pool3 / pool4 (the
+    host FCN-8's 256- / 512-channel maps), fc6 / fc7 at 4096 channels -- ~120 GFLOP per image and
+    step, the heaviest DAE of the repository.  One image, two refinement steps:
+      * float64 HIP path against the float64 oracle, strict (1e-10; r, the refined map, iteration
+        counts);
+      * fp32 HIP path against the oracle <= 1e-4 on r and on the refined map -- a FIXED tolerance:
+        this kind has no DePool2D equality masks (transposed-conv upsampling, fcn8_dae.py:128-160),
+        hence no discontinuity;
+      * the bf16-operand mode runs it (finite, inside [0, 1], argmax agreement with float64 printed).
+    Timing of this DAE: scripts/bench_configs.py row `fcn8dae`."""
+    from iterative_inference_segm_amd.fcn8 import FCN8, FCN8DAE
+    concat_h = ['input', 'pool3', 'pool4']
+    fp = S.make_fcn8_params(seed=61)
+    dp = S.make_fcn8_dae_params(concat_h=concat_h, h_channels=(3, 256, 512), seed=62)
+    X = S.make_images(1, 224, 224, seed=63)
+    dp64, fp64 = to64(dp), to64(fp)
+    res = {}
+    for key, dtype, mma in (('f64', F64, None), ('f32', F32, None), ('bf16', F32, 'bf16')):
+        ii = _ii(FCN8(fp, 11, layer=concat_h + ['probs_dimshuffle'], dtype=dtype, mma=mma),
+                 FCN8DAE(dp, 11, concat_h=concat_h, dtype=dtype, mma=mma), dtype)
+        out = ii.pred_fcn_fn(X)
+        H, Y = out[:-1], out[-1]
+        r = ii.pred_dae_fn(*(list(H) + [Y]))
+        Yii, iters, _ = ii.refine(H, Y, 0.2, 2)
+        res[key] = (H, Y, host(r).astype(np.float64), host(Yii).astype(np.float64), list(host(iters)))
+        del ii
+        torch.cuda.empty_cache()
+    h_ref = ofcn8.fcn8_forward(fp64, X.astype(np.float64), layer=concat_h + ['probs_dimshuffle'])
+    y_ref = h_ref[-1]
+    dae_fn = lambda hh, yy: ofcn8.fcn8_forward(dp64, yy, concat_h=concat_h, h_list=hh)[0]
+    assert np.abs(host(res['f64'][1]) - y_ref).max() <= 1e-10
+    r_ref = dae_fn(list(h_ref[:-1]), y_ref)
+    yii_ref, it_ref = orefine.refine_batch(dae_fn, list(h_ref[:-1]), y_ref, 0.2, 2)
+    e64 = (np.abs(res['f64'][2] - r_ref).max(), np.abs(res['f64'][3] - yii_ref).max())
+    e32 = (np.abs(res['f32'][2] - r_ref).max(), np.abs(res['f32'][3] - yii_ref).max())
+    a16 = float((res['bf16'][3].argmax(1) == yii_ref.argmax(1)).mean())
+    print('fcn8-kind DAE, 224x224, real widths: float64 HIP vs oracle r %.2e refined %.2e | fp32 r %.2e '
+          'refined %.2e | bf16 refined argmax agreement %.4f' % (e64 + e32 + (a16,)))
+    assert max(e64) <= 1e-10 and res['f64'][4] == list(it_ref)
+    assert max(e32) <= TOL and res['f32'][4] == list(it_ref)
+    b = res['bf16'][3]
+    assert np.isfinite(b).all() and b.min() >= 0 and b.max() <= 1

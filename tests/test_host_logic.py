@@ -168,3 +168,27 @@ def test_bench_self_launches_two_ranks_dry_run():
                           '29677', os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--dry-run'],
                          env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0
+
+
+def test_entry_point_two_ranks_dry_run(tmp_path):
+    """`iterative_inference.py --synthetic` under torch.distributed.run with two ranks (gloo, CPU,
+    --dry_run: everything but the HIP work): flags parsed, rendezvous on 127.0.0.1, rank 0 alone
+    writes config.txt and prints, the 5 reference batches are sharded 3 + 2, ONE all-reduce puts all
+    5 into the summary."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29683',
+           os.path.join(ROOT, 'iterative_inference.py'), '--synthetic', '--dry_run', '--n_images', '10',
+           '--batch_size', '2', '--image_size', '32', '40', '-step', '0.1', '--num_iter', '3',
+           '-dae_dict', '{"kind": "standard", "concat_h": ["pool4"], "additional_pool": 2, '
+                        '"unpool_type": "trackind", "skip": true}',
+           '--savepath', str(tmp_path / 'save'), '--loadpath', str(tmp_path / 'load')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count('>>>>> ITERATIVE INFERENCE:') == 1            # rank 0 only
+    assert 'DRY RUN: 2 ranks, 5 batches reduced, rank 0 owned [0, 2, 4]' in r.stdout
+    assert 'Jaccard: 1.0' in r.stdout
+    cfgs = list((tmp_path / 'save').rglob('config.txt'))
+    assert len(cfgs) == 1
