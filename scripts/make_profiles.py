@@ -4,6 +4,9 @@
   python scripts/make_profiles.py steady <dir with *kernel_trace.csv> <out.csv>   (first batch dropped)
   python scripts/make_profiles.py pmc <fetch dir> <write dir> <out.md> [<commit>]
       (also rewrites profiles/hbm_traffic_latest.json, which bench.py reads for roofline.traffic)
+  python scripts/make_profiles.py pmc3 <prof dir> <out.md> <commit> <leg> [<leg> ...]
+      (round 3: <prof dir>/<leg>_fetch, _write, _sq summaries of scripts/profile_r03.sh; one traffic
+      and one SQ table per leg; hbm_traffic_latest.json = union over the legs)
 
 PMC units follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE count KiB; on gfx950
 FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled; WRITE_SIZE is exact."""
@@ -116,8 +119,66 @@ def pmc(fd, wd, out, commit=None):
               open(latest, 'w'), indent=1)
 
 
+def pmc3(prof, out, commit, legs):
+    import json
+    def load(d, counter):
+        per = collections.OrderedDict()
+        for r in csv.DictReader(open(d + '/summary.csv')):
+            if r['Counter_Name'] != counter:
+                continue
+            e = per.setdefault(short(r['Kernel_Name']), [0, 0.0])
+            e[0] += int(r['dispatches'])
+            e[1] += float(r['Counter_Sum'])
+        return per
+    union = {}
+    with open(out, 'w') as f:
+        f.write('# r03 -- rocprofv3 PMC passes (scripts/profile_r03.sh; one bench batch + load-time work '
+                'per leg)\n\nEvery counter set in its own pass with --kernel-trace only, within the gfx950 '
+                'slots (SQ 8, TCC 4: FETCH_SIZE 3, WRITE_SIZE 2; GRBM 2).  FETCH_SIZE / WRITE_SIZE in KiB; '
+                'reads doubled (gfx950 tallies 128-byte requests at 64 bytes -- calibrated for 16-byte-per-lane '
+                'streaming reads, which is what the LDS-DMA staging of the conv kernels issues; the 8-byte '
+                'stores of conv_c8_kernel are outside the calibrated widths: ratios only).\n')
+        for leg in legs:
+            fe, wr = load('%s/%s_fetch' % (prof, leg), 'FETCH_SIZE'), load('%s/%s_write' % (prof, leg), 'WRITE_SIZE')
+            rows = []
+            for k in fe:
+                n = fe[k][0]
+                rd = 2 * fe[k][1] * 1024 / n / 1e9
+                w = wr.get(k, [n, 0.0])
+                rows.append((k, n, rd, w[1] * 1024 / max(w[0], 1) / 1e9))
+            rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
+            f.write('\n## leg %s: HBM-side traffic per launch\n\n| kernel | launches | read GB/launch (x2) | '
+                    'write GB/launch | total GB/launch |\n|---|---:|---:|---:|---:|\n' % leg)
+            for k, n, rd, wg in rows[:14]:
+                f.write('| %s | %d | %.3f | %.3f | %.3f |\n' % (k, n, rd, wg, rd + wg))
+                union.setdefault(re.sub(r'<.*', '', k), round(rd + wg, 4))
+            sq = {c: load('%s/%s_sq' % (prof, leg), c) for c in
+                  ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY',
+                   'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE')}
+            f.write('\n## leg %s: matrix pipe and wave states\n\nmatrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / '
+                    '(GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); wave states as fractions of SQ_WAVE_CYCLES '
+                    '(parked on s_waitcnt / barrier, issue stall, issuing).\n\n| kernel | launches | matrix pipe '
+                    'busy | parked | issue stall | issuing |\n|---|---:|---:|---:|---:|---:|\n' % leg)
+            ks = sorted(sq['GRBM_GUI_ACTIVE'], key=lambda k: -sq['GRBM_GUI_ACTIVE'][k][1])
+            for k in ks[:10]:
+                gui = sq['GRBM_GUI_ACTIVE'][k][1] / 8.0
+                wc = max(sq['SQ_WAVE_CYCLES'].get(k, [0, 0.0])[1], 1.0)
+                g = lambda c: sq[c].get(k, [0, 0.0])[1]
+                f.write('| %s | %d | %.3f | %.3f | %.3f | %.3f |\n'
+                        % (k, sq['GRBM_GUI_ACTIVE'][k][0], g('SQ_VALU_MFMA_BUSY_CYCLES') / (gui * 1024),
+                           g('SQ_WAIT_ANY') / wc, g('SQ_WAIT_INST_ANY') / wc, g('SQ_ACTIVE_INST_ANY') / wc))
+    print(open(out).read())
+    latest = os.path.join(os.path.dirname(os.path.abspath(out)), 'hbm_traffic_latest.json')
+    json.dump({'commit': commit, 'source': os.path.basename(out),
+               'method': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes per leg '
+                         '(%s); reads doubled (gfx950 tallies 128-B requests at 64 B), KiB units' % ', '.join(legs),
+               'gb_per_launch': union}, open(latest, 'w'), indent=1)
+
+
 if __name__ == '__main__':
-    if sys.argv[1] == 'stats':
+    if sys.argv[1] == 'pmc3':
+        pmc3(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5:])
+    elif sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == 'steady':
         stats(sys.argv[2], sys.argv[3], steady=True, nconf=int(sys.argv[4]) if len(sys.argv) > 4 else 3)
