@@ -500,19 +500,20 @@ def worker(args):
         del ii16
         torch.cuda.empty_cache()
     if not args.no_strict_f64:
-        # the float64 path (reference CPU numerics): same config at batch 16, the leg
+        # the float64 path (reference CPU numerics): same config at batch 32, the leg
         # that carries the end-to-end 1e-4 parity claim (tests/test_gpu_f64.py)
         del ii
         torch.cuda.empty_cache()
-        b64 = min(B, 16)
+        b64 = min(B, 32)
         ii64, _, _ = build_model(device, concat_h, dtype=torch.float64)
         ii64.prepare(b64, 224, 224)
         X64 = [x[:b64].to(torch.float64) for x in Xs[:2]]
         T64 = [t[:b64].to(torch.float64) for t in Ts[:2]]
         f64 = leg(ii64, X64, T64, 3, 1)
         f64.update(dtype='f64', batch=b64,
-                   note='float64 HIP kernels (v_mfma_f64_16x16x4_f64), identical loop and work '
-                        'eliminations; refined map within 1e-4 of the float64 oracle end to end '
+                   note='float64 HIP kernels (v_mfma_f64_16x16x4_f64; Winograd F(2x2,3x3) on the wide '
+                        '3x3 layers), identical loop and work eliminations; refined map within 1e-4 '
+                        'of the float64 oracle end to end '
                         '(measured ~1e-11, tests/test_gpu_f64.py)')
         line['strict_f64'] = f64
         del ii64

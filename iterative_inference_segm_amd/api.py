@@ -22,6 +22,8 @@ EPSILON = 1e-3  # iterative_inference.py:53
 # Replay the steady-state refinement step from a captured HIP graph (see IterativeInference.refine).
 # 'auto': when the loop is long enough to pay for the capture; IISEG_GRAPH=0 / 1 force it off / on.
 GRAPH_MODE = os.environ.get('IISEG_GRAPH', 'auto')
+# captured refinement steps kept per IterativeInference, one per (geometry, step, eps); LRU
+GRAPH_CONTEXTS = int(os.environ.get('IISEG_GRAPH_CONTEXTS', '4'))
 
 
 class Metrics:
@@ -254,7 +256,13 @@ class IterativeInference:
             B, _, Hh, Ww = y_src.shape
             ctx = {'y': torch.empty_like(y_src), 'H': [torch.empty_like(h) for h in H_src],
                    'st': _ops.RefineState(B, Hh, Ww, y_src.device), 'graph': None, 'sess': None}
-            self._graphs = {key: ctx}          # one geometry at a time (frees the previous buffers)
+            # a few geometries side by side (alternating batch shapes do not re-capture every call);
+            # the least recently used context goes first
+            while len(self._graphs) >= GRAPH_CONTEXTS:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = ctx
+        else:
+            self._graphs[key] = self._graphs.pop(key)      # most recently used last
         y, H, st = ctx['y'], ctx['H'], ctx['st']
         y.copy_(y_src)
         for dst, src in zip(H, H_src):

@@ -60,39 +60,6 @@ __device__ __forceinline__ unsigned dpp_xor1(unsigned v) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
 }
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// Buffer descriptor as four scalar words (for the inline-asm LDS-DMA below): base, stride 0,
-// num_records = bytes, raw 32-bit data format.  Every word is made wave-uniform explicitly.
-__device__ __forceinline__ i32x4 mk_srsrc(const void* base, unsigned bytes) {
-    const uint64_t a = (uint64_t)base;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = RSRC_W3;
-    return r;
-}
-// One LDS-DMA piece: every lane fetches the 16 bytes at (descriptor base + voff + soff) and the wave's
-// 64 pieces land contiguously at LDS byte address `lds` (wave-uniform).  Written as inline asm ON
-// PURPOSE: beside a `__builtin_amdgcn_raw_ptr_buffer_load_lds` hipcc puts `s_waitcnt vmcnt(0)` in
-// front of every later LDS read it cannot prove disjoint (all of them, with a runtime ring index),
-// which serialises the prefetch with the MFMAs it should run under (checked in the .s).  An asm DMA
-// is outside hipcc's bookkeeping: it is retired by the explicit `s_waitcnt vmcnt(0)` + barrier at the
-// top of the k-loop and nothing else.  M0 (the DMA's LDS base) is saved and restored in the same
-// statement (the compiler does not expect it to change).
-__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds, unsigned voff, unsigned soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
-                 : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
-}
-
 struct C8Params {
     const void* x1;               // C8 input (B, C1/8, H, W, 8); UNPOOL: `up` (B, C1/8, h2, w2, 8)
     const void* x2;               // second source of a channel concat (RECT only) or NULL
@@ -213,12 +180,12 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     const char* base2 = p.C2 > 0 ? (const char*)p.x2 + (size_t)tb * (p.C2 >> 3) * plane * 16 : base1;
     const unsigned n2 = p.C2 > 0 ? (unsigned)((p.C2 >> 3) * plane) * 16u : n1;
     const __amdgpu_buffer_rsrc_t r_x1 = mk_rsrc(base1, (p.debug & 2) ? 0u : n1);
-    const i32x4 s_x1 = mk_srsrc(base1, (p.debug & 2) ? 0u : n1);
-    const i32x4 s_x2 = mk_srsrc(base2, (p.debug & 2) ? 0u : n2);
+    const i32x4s s_x1 = mk_srsrc(base1, (p.debug & 2) ? 0u : n1);
+    const i32x4s s_x2 = mk_srsrc(base2, (p.debug & 2) ? 0u : n2);
     const __amdgpu_buffer_rsrc_t r_m =
         mk_rsrc(UNPOOL ? p.mask_in + (FLAT ? (size_t)0 : (size_t)tb * CC1 * hw2 * 8) : nullptr,
                 UNPOOL ? n1 / 2 : 0u);
-    const i32x4 s_w = mk_srsrc(p.wp, (p.debug & 1) ? 0u : (unsigned)(p.nkt * 18 * p.Mpad) * 16u);
+    const i32x4s s_w = mk_srsrc(p.wp, (p.debug & 1) ? 0u : (unsigned)(p.nkt * 18 * p.Mpad) * 16u);
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr(&Ws[0][0]) + (unsigned)wave * 1024u);
     const unsigned lds_p = __builtin_amdgcn_readfirstlane(lds_addr(&Ps[0][0]) + (unsigned)wave * 1024u);
 

@@ -115,4 +115,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p,
     }
 }
 
+typedef int i32x4s __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor as four scalar words (for the inline-asm LDS-DMA below): base, stride 0,
+// num_records = bytes, raw 32-bit data format.  Every word is made wave-uniform explicitly.
+__device__ __forceinline__ i32x4s mk_srsrc(const void* base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    i32x4s r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00027000;
+    return r;
+}
+// One LDS-DMA piece: every lane fetches the 16 bytes at (descriptor base + voff + soff) and the wave's
+// 64 pieces land contiguously at LDS byte address `lds` (wave-uniform).  Written as inline asm ON
+// PURPOSE: beside a `__builtin_amdgcn_raw_ptr_buffer_load_lds` hipcc puts `s_waitcnt vmcnt(0)` in
+// front of every later LDS read it cannot prove disjoint (all of them, with a runtime ring index),
+// which serialises the prefetch with the MFMAs it should run under (checked in the .s).  An asm DMA
+// is outside hipcc's bookkeeping: it is retired by the explicit `s_waitcnt vmcnt(0)` + barrier at the
+// top of the k-loop and nothing else.  M0 (the DMA's LDS base) is saved and restored in the same
+// statement (the compiler does not expect it to change).
+__device__ __forceinline__ void dma16(i32x4s rsrc, unsigned lds, unsigned voff, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+
 }  // namespace iiseg

@@ -23,6 +23,11 @@ _SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
 # Winograd F(2x2,3x3) form (conv_wino.hip); IISEG_WINO_MIN_CIN=0 switches the path off.  Below
 # these widths the HBM-bound transforms cost more than the saved MFMAs (scripts/bench_wino.py).
 WINO_MIN_CIN = int(os.environ.get('IISEG_WINO_MIN_CIN', '128'))
+# float64 (strict-parity) path: Winograd F(2x2,3x3) on v_mfma_f64_16x16x4_f64 from this many input /
+# output channels (conv_wino_f64.hip); IISEG_WINO_F64=0 keeps every layer on the direct kernel
+WINO_F64 = os.environ.get('IISEG_WINO_F64', '1') != '0'
+WINO_F64_MIN_CIN = int(os.environ.get('IISEG_WINO_F64_MIN_CIN', '128'))
+WINO_F64_MIN_COUT = int(os.environ.get('IISEG_WINO_F64_MIN_COUT', '64'))
 WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
 # Layers with at most this many input channels use the kernel that also applies the output
 # transform (products stay in registers, no M round trip through HBM); deeper layers are
@@ -85,6 +90,7 @@ def _bf16_static_pick(Cin, OW):
 BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
 BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '256'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
+_wino_ws64 = {}
 
 
 def _wino_workspace(n, device):
@@ -184,6 +190,9 @@ class Conv:
         self.wino = (dtype == torch.float32 and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
                      not self.transposed and self.Cin % 16 == 0 and
                      0 < WINO_MIN_CIN <= self.Cin and self.Cout >= WINO_MIN_COUT)
+        self.wino_f64 = (dtype == torch.float64 and WINO_F64 and (self.KH, self.KW) == (3, 3) and
+                         self.dil == 1 and not self.transposed and self.Cin % 16 == 0 and
+                         self.Cin >= WINO_F64_MIN_CIN and self.Cout >= WINO_F64_MIN_COUT)
         self.wino_bf16 = (self.mma == 'bf16' and (self.KH, self.KW) == (3, 3) and self.dil == 1 and
                           not self.transposed and self.Cin >= BF16_WINO_MIN_CIN and
                           self.Cout >= BF16_WINO_MIN_COUT)
@@ -457,6 +466,9 @@ class Conv:
                 prof.append((names[i], self.flops(B, d.OH, d.OW) if i == 1 else 0.0, ev0, ev1))
                 ev0 = ev1
             return out
+        if dt == torch.float64 and self.wino_f64 and not unpool and not self.via_im2col and \
+                self.lib.iiseg_conv_wino_f64_supported(C.byref(d)):
+            return self._call_wino_f64(d, x1, x2, add, out, prof, B)
         ev0 = _ev() if prof is not None else None
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
@@ -707,6 +719,28 @@ class Conv:
             ev1 = _ev()
             prof.append((name, fl, ev0, ev1))
             ev0 = ev1
+        return out
+
+    def _call_wino_f64(self, d, x1, x2, add, out, prof, B):
+        """float64 Winograd form (include/iiseg.h, iiseg_conv_wino_f64)."""
+        lib = self.lib
+        dt = torch.float64
+        if self._U is None:
+            self._U = torch.empty(lib.iiseg_conv_wino_f64_weight_elems(C.byref(d)), dtype=dt,
+                                  device=self.W.device)
+            check(lib.iiseg_conv_wino_pack_f64(_stream(), C.byref(d), _ptr(self.W, dt), self.so, self.sc,
+                                               _ptr(self._U, dt)), 'iiseg_conv_wino_pack_f64')
+        n = lib.iiseg_conv_wino_f64_workspace_elems(C.byref(d))
+        ws = _wino_ws64.get(x1.device)
+        if ws is None or ws.numel() < n:
+            _wino_ws64[x1.device] = None
+            ws = _wino_ws64[x1.device] = torch.empty(int(n), dtype=dt, device=x1.device)
+        ev0 = _ev() if prof is not None else None
+        check(lib.iiseg_conv_wino_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(self._U, dt),
+                                      _ptr(self.b, dt), _ptr(add, dt), _ptr(ws, dt), _ptr(out, dt)),
+              'iiseg_conv_wino_f64')
+        if prof is not None:
+            prof.append(('wino64_gemm_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
         return out
 
     def _call_wino(self, d, x1, x2, pre, pooled, add, out, prof):

@@ -152,3 +152,54 @@ def test_reference_function_is_chaotic_at_float32_resolution(built_lib):
           '1e-4 %.4f, argmax agreement %.5f'
           % (e.max(), e.mean(), frac, float((a.argmax(1) == b.argmax(1)).mean())))
     assert e.max() > 1e-2 and frac < 0.5
+
+
+WINO64_CASES = [  # B, Cin, H, W, Cout, pad, relu, window, anchor
+    (2, 128, 12, 14, 128, 1, True, None, (0, 0)),
+    (1, 144, 9, 21, 70, 1, False, None, (0, 0)),            # Cout padded to the 64-channel tile
+    (3, 256, 7, 7, 320, 1, True, None, (1, 1)),             # odd tile anchor
+    (2, 128, 6, 6, 128, 5, True, None, (0, 0)),             # wide zero padding (pad-100 rule, scaled)
+    (2, 160, 20, 18, 96, 1, True, (3, 5, 10, 9), (1, 1)),   # window, anchored at its parity
+]
+
+
+@pytest.mark.parametrize('case', WINO64_CASES)
+def test_conv_wino_f64(ops, case):
+    """float64 Winograd F(2x2,3x3) (csrc/conv_wino_f64.hip) vs the oracle, incl. windows and tile
+    anchors; and bit-identical between a windowed and the full-map launch with the same anchor."""
+    B, Cin, H, W, Cout, pad, relu, window, anchor = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x, Wt, b = rng.standard_normal((B, Cin, H, W)), rng.standard_normal((Cout, Cin, 3, 3)), \
+        rng.standard_normal(Cout)
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, dtype=F64)
+    assert conv.wino_f64
+    full = host(conv(dev(x), anchor=anchor))
+    assert np.abs(full - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
+    assert conv._U is not None                              # took the Winograd path
+    if window is not None:
+        y0, x0, h, w = window
+        got = host(conv(dev(x), window=window, anchor=anchor))
+        assert np.array_equal(got, full[:, :, y0:y0 + h, x0:x0 + w])
+
+
+def test_conv_wino_f64_concat_add_placement_and_exact_ties(ops):
+    rng = np.random.default_rng(31)
+    h, t = rng.standard_normal((2, 96, 10, 11)), rng.standard_normal((2, 64, 10, 11))
+    Wt, b = rng.standard_normal((72, 160, 3, 3)), rng.standard_normal(72)
+    other = rng.standard_normal((2, 72, 14, 15))
+    ref = onn.conv2d(onn.concat_h_first(h, t), Wt, b, pad=1) + other[:, :, 2:12, 3:14]
+    conv = ops.Conv(Wt, b, pad=1, relu=False, dtype=F64)
+    y0, x0, hh, ww = 2, 4, 7, 6
+    out = torch.full((2, 72, 10, 11), 5.0, dtype=F64, device='cuda')
+    conv(dev(h), x2=dev(t), add=dev(other), add_off=(2 + y0, 3 + x0), window=(y0, x0, hh, ww), out=out,
+         place=(y0, x0))
+    want = np.full_like(ref, 5.0)
+    want[:, :, y0:y0 + hh, x0:x0 + ww] = ref[:, :, y0:y0 + hh, x0:x0 + ww]
+    assert np.abs(host(out) - want).max() <= 1e-12 * (1 + np.abs(ref).max())
+    # equal patches -> bit-equal outputs: a map that is constant inside (the weights-only pad-100
+    # border of the encoder maps) gives one value per channel over the whole interior, whatever the
+    # position of a pixel inside its 2x2 Winograd tile -- DePool2D's exact ties depend on it
+    xc = np.broadcast_to(rng.standard_normal((1, 160, 1, 1)), (1, 160, 16, 16)).copy()
+    got = host(ops.Conv(Wt, b, pad=1, relu=True, dtype=F64)(dev(xc)))[:, :, 1:-1, 1:-1]
+    assert np.array_equal(got, np.broadcast_to(got[:, :, :1, :1], got.shape))
