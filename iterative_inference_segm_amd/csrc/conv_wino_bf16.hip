@@ -939,12 +939,26 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
         if (iiseg_check_launch()) return IISEG_ERR_LAUNCH;
         return iiseg_wino_output_launch(s, d, M, g.Mpad, g.Tpad, bias, add, out);
     }
+    // The kernel keeps four fp32 output accumulator sets next to the product tile: ~345 VGPRs.  With
+    // MINW = 2 (two 4-wave workgroups per CU) it is held to 256 and spills 151-172 of them to scratch;
+    // with MINW = 1 (IISEG_WBF_MINW=1) the 4-wave variants are spill-free at one workgroup per CU.
+    // Measured A/B on one MI355X (round 3, batch 64, profiles/r03_wino_fused_bf16_minw.txt): the
+    // spill-free form is SLOWER -- 512 -> 512 at 39^2 0.984 vs 0.844 ms, 256 -> 512 at 35^2 0.467 vs
+    // 0.367, 512 -> 1024 at 22^2 0.476 vs 0.367 (4-wave tiles) -- the second workgroup per CU hides
+    // more latency than the scratch traffic costs, so MINW = 2 stays the default.  (The 8-wave
+    // 128 x 128 variants cannot have more than 256 registers per lane and are the same in both forms.)
+    static const int minw2 = getenv("IISEG_WBF_MINW") ? atoi(getenv("IISEG_WBF_MINW")) != 1 : 1;
+#define WBF_UNPAREN(...) __VA_ARGS__
+#define WBF_FUSED_LAUNCH(ARGS, GRID, BLOCK)                                                        \
+    do {                                                                                           \
+        if (minw2) hipLaunchKernelGGL((wino_fused_bf16_kernel<WBF_UNPAREN ARGS, 2>), GRID, BLOCK, 0, s, p); \
+        else hipLaunchKernelGGL((wino_fused_bf16_kernel<WBF_UNPAREN ARGS, 1>), GRID, BLOCK, 0, s, p);      \
+    } while (0)
     if (stages & IISEG_WINO_GEMM) {
         if (g.bm == 64) {
             p.n_ttiles = g.Tpad / 128;
             p.n_mtiles = g.Mpad / 64;
-            hipLaunchKernelGGL((wino_fused_bf16_kernel<64, 128, 1, 4, WBF_BK, 3, 2>),
-                               dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 2)), dim3(256), 0, s, p);
+            WBF_FUSED_LAUNCH((64, 128, 1, 4, WBF_BK, 3), dim3(persistent_grid(p.n_ttiles * p.n_mtiles, 2)), dim3(256));
             return iiseg_check_launch();
         }
         p.n_mtiles = g.Mpad / 128;
@@ -957,26 +971,26 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
             p.n_ttiles = g.Tpad / 64;
             const dim3 grid(persistent_grid(p.n_ttiles * p.n_mtiles, 2));
             if (var == 1)        // 2-deep ring
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, 64, 2, 2>), grid, dim3(256), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 64, 2, 2, 64, 2), grid, dim3(256));
             else if (var == 2)   // 32-channel k-tiles, 6-deep ring (same LDS, more tiles in flight)
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, 32, 6, 2>), grid, dim3(256), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 64, 2, 2, 32, 6), grid, dim3(256));
             else
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 64, 2, 2, 64, 3, 2>), grid, dim3(256), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 64, 2, 2, 64, 3), grid, dim3(256));
         } else {
             p.n_ttiles = g.Tpad / 128;
             const dim3 grid(persistent_grid(p.n_ttiles * p.n_mtiles, 1));
             if (var == 1)
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 64, 2, 2>), grid, dim3(512), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 128, 2, 4, 64, 2), grid, dim3(512));
             else if (var == 2)
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 32, 6, 2>), grid, dim3(512), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 128, 2, 4, 32, 6), grid, dim3(512));
             else if (var == 3 || g.Kc % 128)
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 64, 3, 2>), grid, dim3(512), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 128, 2, 4, 64, 3), grid, dim3(512));
             else
                 // default: 128-channel k-tiles, 2-deep ring.  Measured on one device (A/B by
                 // IISEG_BF16_FUSED_VAR): a stage costs ~1 us + 35 ns/KB whatever the ring depth, so
                 // fewer, larger stages win (512 ch, 39^2 window: 0.65 vs 0.76 ms at 64-channel
                 // stages, 1.16 ms at 32-channel ones)
-                hipLaunchKernelGGL((wino_fused_bf16_kernel<128, 128, 2, 4, 128, 2, 2>), grid, dim3(512), 0, s, p);
+                WBF_FUSED_LAUNCH((128, 128, 2, 4, 128, 2), grid, dim3(512));
         }
     }
     return iiseg_check_launch();
