@@ -363,6 +363,13 @@ int iiseg_refine_partials(int32_t H, int32_t W);
 int iiseg_refine_update_f32(void* stream, const float* score, float* y, const int32_t* active,
                             double* partial, int32_t B, int32_t C, int32_t SH, int32_t SW,
                             int32_t sy0, int32_t sx0, int32_t H, int32_t W, float step);
+/* iiseg_refine_update_f32 that also writes the updated map as a bf16 C8 tensor y8 (B, C8n, H, W, 8)
+ * -- the input format of the DAE's first layer under mma='bf16c8' (iiseg_conv_c8): the conversion
+ * pass per refinement step disappears. */
+int iiseg_refine_update_c8_f32(void* stream, const float* score, float* y, const int32_t* active,
+                               double* partial, void* y8, int32_t C8n, int32_t B, int32_t C,
+                               int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W,
+                               float step);
 int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, int32_t* iters,
                           double* last_norm, int32_t B, int32_t nblk, int32_t HW, double eps);
 

@@ -217,7 +217,7 @@ class IterativeInference:
                 ops.grad_update(score, self.dae.backward_y(g_score, y.shape), y, st, step,
                                 off=(0, 0))
             elif mode == 'residual':
-                ops.refine_update(score, y, st, step, off=(0, 0))
+                self._update(score, y, st, step, sess)
             else:
                 raise ValueError('mode must be "residual" or "gradient"')
             ops.refine_finalize(st, eps_eff)
@@ -276,7 +276,7 @@ class IterativeInference:
 
         def one_step():
             score = dae_scores()
-            _ops.refine_update(score, y, st, step, off=(0, 0))
+            self._update(score, y, st, step, sess)
             _ops.refine_finalize(st, eps_eff)
             return score
 
@@ -289,7 +289,7 @@ class IterativeInference:
             ctx['graph'], ctx['fingerprint'] = None, fp
         r0 = _ops.crop_softmax(score, y.shape[2], y.shape[3], off=(0, 0)) if first_reconstruction \
             else None
-        _ops.refine_update(score, y, st, step, off=(0, 0))
+        self._update(score, y, st, step, sess)
         _ops.refine_finalize(st, eps_eff)
         it = 1
         if ctx['graph'] is None and it < num_iter:
@@ -318,6 +318,16 @@ class IterativeInference:
         if first_reconstruction:
             res = res + (r0,)
         return res
+
+    def _update(self, score, y, st, step, sess):
+        """The fused update of iterative_inference.py:270-273; under mma='bf16c8' it also writes the
+        new y in the DAE's input format (bf16 C8) into the session's buffer."""
+        y8 = self.dae.c8_feed(sess) if hasattr(self.dae, 'c8_feed') else None
+        if y8 is not None and y8.shape[0] == y.shape[0] and tuple(y8.shape[2:4]) == tuple(y.shape[2:]):
+            ops.refine_update(score, y, st, step, off=(0, 0), y8=y8)
+            self.dae.c8_fed(sess)
+        else:
+            ops.refine_update(score, y, st, step, off=(0, 0))
 
     def _launch_fingerprint(self, sess):
         """What a captured refinement step depends on besides shapes: the DAE's launch-structure

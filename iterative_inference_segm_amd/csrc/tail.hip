@@ -57,13 +57,20 @@ __global__ __launch_bounds__(256) void crop_softmax_kernel(const T* __restrict__
         if (c < C) op[(size_t)c * HW] = mp ? mp[(size_t)c * HW] - r[c] : r[c];
 }
 
+__device__ __forceinline__ unsigned pack_bf16_t(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 template <int CMAX, typename T>
 __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict__ score,
                                                             T* __restrict__ yio,
                                                             const int* __restrict__ active,
                                                             double* __restrict__ partial, int C,
                                                             int SH, int SW, int sy0, int sx0, int H,
-                                                            int W, T step) {
+                                                            int W, T step, uint4* __restrict__ y8,
+                                                            int C8n) {
     __shared__ double red[4];
     const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -78,19 +85,34 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
         load_softmax<CMAX, T>(sp, SHW, C, r);
         T* yp = yio + (size_t)b * C * HW + pix;
         T ss = 0;
+        float ynew[CMAX];
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
+        for (int c = 0; c < CMAX; ++c) {
+            ynew[c] = 0.f;
             if (c < C) {
                 const T yv = yp[(size_t)c * HW];
                 const T de = yv - r[c];  // iterative_inference.py:203-204
                 ss = fma(de, de, ss);
+                T yn = yv;
                 if (act) {
-                    T yn = yv - step * de;  // :270
+                    yn = yv - step * de;  // :270
                     yn = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);  // :273
                     yp[(size_t)c * HW] = yn;
                 }
+                ynew[c] = (float)yn;
             }
+        }
         nrm = sqrt_t(ss);  // np.linalg.norm(grad, axis=1), :275
+        // bf16 C8 copy of the updated map for the next DAE forward (mma='bf16c8': saves the
+        // nchw_to_c8 pass per step); chunk j = channels 8 j .. 8 j + 7, zeros beyond C
+        if (y8) {
+#pragma unroll
+            for (int j = 0; j < CMAX / 8; ++j)
+                if (j < C8n)
+                    y8[((size_t)b * C8n + j) * HW + pix] =
+                        make_uint4(pack_bf16_t(ynew[8 * j], ynew[8 * j + 1]), pack_bf16_t(ynew[8 * j + 2], ynew[8 * j + 3]),
+                                   pack_bf16_t(ynew[8 * j + 4], ynew[8 * j + 5]), pack_bf16_t(ynew[8 * j + 6], ynew[8 * j + 7]));
+        }
     }
     double d = wave_sum((double)nrm);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
@@ -209,18 +231,21 @@ int crop_softmax(void* stream, const T* score, const T* minuend, T* out, int32_t
 template <typename T>
 int refine_update(void* stream, const T* score, T* y, const int32_t* active, double* partial,
                   int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
-                  int32_t W, T step) {
+                  int32_t W, T step, void* y8 = nullptr, int32_t C8n = 0) {
     if (!score || !y || !active || !partial) return IISEG_ERR_NULL;
+    if (y8 && (C8n * 8 < C || C8n > 4 || ((uintptr_t)y8 & 15))) return IISEG_ERR_SHAPE;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
         return IISEG_ERR_SHAPE;
     if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
         hipLaunchKernelGGL((refine_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
-                           score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+                           score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step, (uint4*)y8,
+                           C8n);
     else
         hipLaunchKernelGGL((refine_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
-                           score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
+                           score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step, (uint4*)y8,
+                           C8n);
     return iiseg_check_launch();
 }
 
@@ -304,6 +329,14 @@ extern "C" int iiseg_refine_update_f32(void* stream, const float* score, float* 
                                        int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
                                        int32_t W, float step) {
     return refine_update<float>(stream, score, y, active, partial, B, C, SH, SW, sy0, sx0, H, W, step);
+}
+extern "C" int iiseg_refine_update_c8_f32(void* stream, const float* score, float* y,
+                                          const int32_t* active, double* partial, void* y8,
+                                          int32_t C8n, int32_t B, int32_t C, int32_t SH, int32_t SW,
+                                          int32_t sy0, int32_t sx0, int32_t H, int32_t W, float step) {
+    if (!y8) return IISEG_ERR_NULL;
+    return refine_update<float>(stream, score, y, active, partial, B, C, SH, SW, sy0, sx0, H, W, step,
+                                y8, C8n);
 }
 extern "C" int iiseg_refine_update_f64(void* stream, const double* score, double* y,
                                        const int32_t* active, double* partial, int32_t B, int32_t C,

@@ -194,6 +194,7 @@ class StandardDAE:
             key = (tuple(t[0] for t in tags), tuple(y.shape), y.dtype)
             st = self._store
             if st is not None and st.get('key') == key and st.get('primed'):
+                st['y8_fresh'] = False       # (a C8 copy of the PREVIOUS loop's last y may be there)
                 st['h_fresh'] = True
                 st['h_dep'] = [t[1] for t in tags]
                 return st
@@ -447,6 +448,16 @@ class StandardDAE:
         self._saved = (mask_override, pre, pool)      # what backward_y needs (masks only)
         return t
 
+    def c8_feed(self, session):
+        """The C8 buffer a fused refinement update may write the new y into for the NEXT `scores`
+        call of this session (ops.refine_update(..., y8=)), or None; `c8_fed(session)` afterwards."""
+        if not self.c8 or not isinstance(session, dict):
+            return None
+        return session.get('y8')
+
+    def c8_fed(self, session):
+        session['y8_fresh'] = True
+
     def _scores_c8(self, h_list, y, session):
         """`scores` with bf16 C8 activations between the layers (csrc/conv_c8_bf16.hip): the same
         layer plan, windows (decoder dead-code elimination, loop-invariant encoder maps, border
@@ -477,7 +488,20 @@ class StandardDAE:
             session['masked'] = 'c8'
             if not primed:
                 session['gen'] = session.get('gen', 0) + 1
-        t = ops.nchw_to_c8(y)
+        # y as a C8 tensor: converted here, unless the refinement step that produced y has already
+        # written it (`c8_feed`: api passes the session's buffer to ops.refine_update)
+        if session is not None and session.get('y8_fresh') and session.get('y8') is not None and \
+                tuple(session['y8'].shape[2:4]) == tuple(y.shape[2:4]):
+            t = session['y8']
+        else:
+            t = ops.nchw_to_c8(y, out=session.get('y8') if session is not None and
+                               session.get('y8') is not None and
+                               tuple(session['y8'].shape[2:4]) == tuple(y.shape[2:4]) and
+                               session['y8'].shape[0] == B else None)
+            if session is not None:
+                session['y8'] = t
+        if session is not None:
+            session['y8_fresh'] = False
         pre_hw, pool8, masks = {}, {}, {}
         pool_hw = {0: (y.shape[2], y.shape[3])}
         dep = (0, 0, y.shape[2], y.shape[3])

@@ -940,12 +940,23 @@ class RefineState:
         self.last_norm.zero_()
 
 
-def refine_update(score, y, state, step, off=None):
-    """One fused refinement step on y (in place) from the DAE's pre-softmax score map."""
+def refine_update(score, y, state, step, off=None, y8=None):
+    """One fused refinement step on y (in place) from the DAE's pre-softmax score map.  `y8`: a
+    bf16 C8 tensor (B, chunks, H, W, 8) that also receives the updated map (the DAE's input format
+    under mma='bf16c8'; float32 only)."""
     B, Cc, SH, SW = score.shape
     H, W = y.shape[2], y.shape[3]
     sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
     dt = y.dtype
+    if y8 is not None:
+        if dt != torch.float32 or not is_c8(y8) or tuple(y8.shape) != (B, y8.shape[1], H, W, 8) or \
+                y8.shape[1] * 8 < Cc:
+            raise RuntimeError('y8: bf16 C8 tensor of y\'s geometry')
+        check(_lib.load().iiseg_refine_update_c8_f32(
+            _stream(), _ptr(score), _ptr(y), _ptr(state.active, torch.int32),
+            _ptr(state.partial, torch.float64), C.c_void_p(y8.data_ptr()), y8.shape[1], B, Cc, SH, SW,
+            sy0, sx0, H, W, float(step)), 'iiseg_refine_update_c8_f32')
+        return
     check(_fn('refine_update', dt)(_stream(), _ptr(score, dt), _ptr(y, dt),
                                    _ptr(state.active, torch.int32),
                                    _ptr(state.partial, torch.float64), B, Cc, SH, SW, sy0, sx0,
