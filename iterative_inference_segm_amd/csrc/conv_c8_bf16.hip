@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         // buf ^ 1 (k-tile kt - 1), which the next k-tile's DMA overwrites from here on
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if constexpr (!UNPOOL) {
-            if (more) {
+            if (more && !(p.debug & 16)) {     // (debug 16: timing experiment, no DMA issued at all)
                 C8_DMA_X(kt + 1, buf ^ 1)
                 C8_DMA_W(kt + 1, buf ^ 1)
             }
@@ -419,27 +419,51 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                        q_py < p.pool_H && q_px < p.pool_W;
             q_pix[jp] = (unsigned)(q_py * p.pool_W + q_px);
         }
+        // Every load of the epilogue first (bias, skip-add; out-of-range pieces get the out-of-bounds
+        // offset instead of a branch), then the stores: a buffer load that follows a buffer store in
+        // program order cannot be moved above it (they may alias as far as hipcc knows), so a
+        // {load, add, store} body per chunk is one memory round trip per chunk -- eight in a row
+        // (hoisted per 32-channel block i: one register set of 4 x TN pieces serves both add formats)
+        const bool has_add1 = p.add_kind == 1, has_add2 = p.add_kind == 2;
+        constexpr int GH = TN == 4 ? 2 : 4;      // chunks whose loads are hoisted together (registers)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int ig = 0; ig < TM * (4 / GH); ++ig) {
+            const int i = ig / (4 / GH), g0 = (ig % (4 / GH)) * GH;
+            f32x4 bvs[4];
+            u32x4 adr[4][TN];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = g0; g < g0 + GH; ++g) {
+                const int c8 = ((m0 + i * 32) >> 3) + g;
+                const bool cok = c8 < co8;
+                bvs[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_bias, (int)(4u * (unsigned)(c8 * 8 + 4 * lh)), 0, 0));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (has_add1) {
+                        const u32x2 a2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 16u + 8u * lh : OOB), 0, 0));
+                        adr[g][j][0] = a2[0]; adr[g][j][1] = a2[1];
+                    } else if (has_add2) {
+                        adr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 32u + 16u * lh : OOB), 0, 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = g0; g < g0 + GH; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;            // chunk of the output channels
                 const bool cok = c8 < co8;
-                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_bias, (int)(4u * (unsigned)(c8 * 8 + 4 * lh)), 0, 0));
+                const f32x4 bv = bvs[g];
                 f32x4 v[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[j][q] = acc[i][j][g * 4 + q] + bv[q];
-                    if (p.add_kind == 1) {
-                        const u32x2 a2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 16u + 8u * lh : OOB), 0, 0));
-                        v[j][0] += bf_lo(a2[0]); v[j][1] += bf_hi(a2[0]);
-                        v[j][2] += bf_lo(a2[1]); v[j][3] += bf_hi(a2[1]);
-                    } else if (p.add_kind == 2) {
-                        v[j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 32u + 16u * lh : OOB), 0, 0));
+                    if (has_add1) {
+                        v[j][0] += bf_lo(adr[g][j][0]); v[j][1] += bf_hi(adr[g][j][0]);
+                        v[j][2] += bf_lo(adr[g][j][1]); v[j][3] += bf_hi(adr[g][j][1]);
+                    } else if (has_add2) {
+                        v[j] += __builtin_bit_cast(f32x4, adr[g][j]);
                     }
                     if (p.relu) {
                         v[j][0] = fmaxf(v[j][0], 0.f); v[j][1] = fmaxf(v[j][1], 0.f);

@@ -595,7 +595,7 @@ class Conv:
         add_kind = 0
         if add is not None:
             add_kind = 1 if is_c8(add) else 2
-            if add.dim() != 5 or add.shape[0] != B or add.shape[1] * 8 != self.Cout or \
+            if add.dim() != 5 or add.shape[0] != B or add.shape[1] != c8_chunks(self.Cout) or \
                     add.dtype not in (torch.bfloat16, torch.float32):
                 raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
             d.AH, d.AW, d.ay0, d.ax0 = add.shape[2], add.shape[3], add_off[0], add_off[1]
