@@ -313,6 +313,9 @@ def main():
     ap.add_argument('--bf16-mode', default='bf16c8', choices=['bf16c8', 'bf16'],
                     help="activations of the bf16 leg: 'bf16c8' = bf16 C8 chunks between the layers "
                          "(conv_c8_bf16.hip), 'bf16' = fp32 NCHW (round-2 form)")
+    ap.add_argument('--no-two-streams', action='store_true',
+                    help='skip the legs that run the batch as concurrent sub-batches on several HIP streams')
+    ap.add_argument('--streams', default='2', help='comma-separated stream counts of those legs')
     ap.add_argument('--all-legs', action='store_true',
                     help='N > 1: also run the per_batch_only / full_recompute / bf16 / strict_f64 legs '
                          '(by default a multi-GPU run times the headline leg only)')
@@ -339,7 +342,7 @@ def worker(args):
     concat_h = ['pool4']
     if world > 1 and not args.all_legs:
         # a scaling run measures the headline leg; the ablation legs are single-GPU diagnostics
-        args.no_full_recompute = args.no_bf16 = args.no_strict_f64 = True
+        args.no_full_recompute = args.no_bf16 = args.no_strict_f64 = args.no_two_streams = True
     ii, fp, dp = build_model(device, concat_h)
     B = args.batch
     # weak scaling: every rank refines its own shard of `B` synthetic images per step;
@@ -459,6 +462,49 @@ def worker(args):
                  'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in full every '
                  'step and batch (same kernels)')
         ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
+    if not args.no_two_streams:
+        # The same fp32 batch as N concurrent sub-batches: N engines (own nets, sessions, graphs and
+        # scratch), each on its own HIP stream, so that the tail of one engine's kernels (the last,
+        # partly filled round of workgroups of every launch) overlaps the others'.  Same kernels,
+        # same per-image results (an image's result does not depend on its batch:
+        # test_full_config_batch_properties); reported next to `value`, never as `value`.
+        line['concurrent_streams'] = {}
+        for ns in [int(v) for v in args.streams.split(',') if v]:
+            if ns < 2 or B % ns:
+                continue
+            part = B // ns
+            engines = [build_model(device, concat_h)[0] for _ in range(ns)]
+            streams = [torch.cuda.Stream(device=device) for _ in range(ns)]
+            for e, st_ in zip(engines, streams):
+                with torch.cuda.stream(st_):
+                    e.prepare(part, 224, 224)
+            torch.cuda.synchronize()
+
+            def stepn(x, t):
+                for k, (e, st_) in enumerate(zip(engines, streams)):
+                    with torch.cuda.stream(st_):
+                        one_step(e, x[k * part:(k + 1) * part], t[k * part:(k + 1) * part],
+                                 args.num_iter, args.step_size)
+
+            it2 = 0
+            for _ in range(max(args.warmup, 2)):
+                stepn(Xs[it2 % n_distinct], Ts[it2 % n_distinct]); it2 += 1
+            torch.cuda.synchronize()
+            iidist.barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                stepn(Xs[it2 % n_distinct], Ts[it2 % n_distinct]); it2 += 1
+            torch.cuda.synchronize()
+            iidist.barrier()
+            d2 = time.perf_counter() - t2
+            line['concurrent_streams'][str(ns)] = {
+                'value': round(world * B * args.steps / d2, 3), 'unit': 'images/s',
+                'ms_per_step': round(d2 / args.steps * 1e3, 2), 'sub_batch': part}
+            del engines, streams
+            torch.cuda.empty_cache()
+        line['concurrent_streams']['note'] = (
+            'fp32, the batch of %d as N concurrent sub-batches on N HIP streams (N engines); a '
+            'scheduling variant of the same work, not the headline' % B)
     if not args.no_bf16:
         # 16-bit MFMA leg (VERDICT row N1; north_star: ">= 1000 images/s at >= 40 % of fp16 MFMA
         # peak"): bf16 operands + fp32 accumulation on the wide 3x3 layers, everything else as in

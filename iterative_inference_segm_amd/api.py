@@ -18,7 +18,10 @@ import torch
 
 from . import ops
 
+import itertools
+
 EPSILON = 1e-3  # iterative_inference.py:53
+_ENGINE_IDS = itertools.count(1)
 # Replay the steady-state refinement step from a captured HIP graph (see IterativeInference.refine).
 # 'auto': when the loop is long enough to pay for the capture; IISEG_GRAPH=0 / 1 force it off / on.
 GRAPH_MODE = os.environ.get('IISEG_GRAPH', 'auto')
@@ -73,6 +76,18 @@ class IterativeInference:
         # keyed by tensor identity: id -> (weakref, torch version counter, record)
         self._prov = {}
         self._graphs = {}        # steady-state refinement steps captured as HIP graphs
+        # scratch buffers (Winograd workspaces, ...) are per engine: two engines may run concurrently
+        # on two streams (ops.workspace_tag)
+        self._ws_tag = next(_ENGINE_IDS)
+
+    def __del__(self):
+        # the engine's scratch buffers go with it
+        try:
+            for cache in (ops._wino_ws, ops._wino_ws64, ops._bn_ws):
+                for k in [k for k in cache if isinstance(k, tuple) and k[1] == self._ws_tag]:
+                    cache.pop(k, None)
+        except Exception:
+            pass
 
     def _remember(self, outs):
         prov = getattr(self.fcn, 'last_provenance', None)
@@ -103,6 +118,10 @@ class IterativeInference:
             return
         x0 = torch.zeros((int(batch), int(channels), int(height), int(width)), dtype=self.dtype,
                          device=self.device)
+        with ops.workspace_tag(self._ws_tag):
+            return self._prepare(x0)
+
+    def _prepare(self, x0):
         out = self._remember(self.fcn(x0))
         if not isinstance(out, (list, tuple)) or len(out) < 2 or not hasattr(self.dae, 'new_session'):
             return
@@ -113,13 +132,16 @@ class IterativeInference:
 
     # ---- reference function level -------------------------------------------------------
     def pred_fcn_fn(self, X):
-        return self._remember(self.fcn(self._dev(X)))
+        with ops.workspace_tag(self._ws_tag):
+            return self._remember(self.fcn(self._dev(X)))
 
     def pred_dae_fn(self, *args):
-        return self.dae(*[self._dev(a) for a in args])
+        with ops.workspace_tag(self._ws_tag):
+            return self.dae(*[self._dev(a) for a in args])
 
     def de_fn(self, *args):
-        return self.dae.residual(*[self._dev(a) for a in args])
+        with ops.workspace_tag(self._ws_tag):
+            return self.dae.residual(*[self._dev(a) for a in args])
 
     def val_fn(self, Y, T):
         """[acc, jacc, mse] on the host (synchronises); use `val_device` inside loops."""
@@ -132,9 +154,13 @@ class IterativeInference:
         return m
 
     # ---- fused loop ---------------------------------------------------------------------
-    def refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
-               per_iter_target=None, mode='residual', h_provenance=None,
-               first_reconstruction=False, graph=None):
+    def refine(self, *args, **kw):
+        with ops.workspace_tag(self._ws_tag):
+            return self._refine(*args, **kw)
+
+    def _refine(self, H, Y, step, num_iter, eps=EPSILON, early_stop=True, inplace=False,
+                per_iter_target=None, mode='residual', h_provenance=None,
+                first_reconstruction=False, graph=None):
         """Batched replacement of iterative_inference.py:258-284.
 
         for it in range(num_iter):  score = DAE(H, y)                    # de_fn, :267
@@ -304,7 +330,7 @@ class IterativeInference:
                 _ops.CONV_PROFILE = prof
                 ctx['graph'] = g
                 # scratch the captured launches point at must outlive the graph
-                ctx['keep'] = (_ops._wino_ws.get(y.device), sess)
+                ctx['keep'] = (_ops._wino_ws.get(_ops._ws_key(y.device)), sess)
         g = ctx['graph']
         while it < num_iter:
             g.replay()

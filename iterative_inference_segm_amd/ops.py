@@ -93,11 +93,37 @@ _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are 
 _wino_ws64 = {}
 
 
+# Scratch is reused by consecutive launches of ONE stream (stream-ordered).  Engines that run
+# concurrently on different streams (bench.py --streams 2) must not share it: every
+# IterativeInference tags its launches (`workspace_tag`), and the caches are keyed (device, tag).
+_WS_TAG = [0]
+
+
+class workspace_tag:
+    """Context manager: launches inside use the scratch buffers of `tag` (an engine's id)."""
+
+    def __init__(self, tag):
+        self.tag, self.prev = tag, None
+
+    def __enter__(self):
+        self.prev, _WS_TAG[0] = _WS_TAG[0], self.tag
+        return self
+
+    def __exit__(self, *exc):
+        _WS_TAG[0] = self.prev
+        return False
+
+
+def _ws_key(device):
+    return (device, _WS_TAG[0])
+
+
 def _wino_workspace(n, device):
-    ws = _wino_ws.get(device)
+    key = _ws_key(device)
+    ws = _wino_ws.get(key)
     if ws is None or ws.numel() < n:
-        _wino_ws[device] = None
-        ws = _wino_ws[device] = torch.empty(int(n), dtype=torch.float32, device=device)
+        _wino_ws[key] = None
+        ws = _wino_ws[key] = torch.empty(int(n), dtype=torch.float32, device=device)
     return ws
 
 
@@ -731,10 +757,11 @@ class Conv:
             check(lib.iiseg_conv_wino_pack_f64(_stream(), C.byref(d), _ptr(self.W, dt), self.so, self.sc,
                                                _ptr(self._U, dt)), 'iiseg_conv_wino_pack_f64')
         n = lib.iiseg_conv_wino_f64_workspace_elems(C.byref(d))
-        ws = _wino_ws64.get(x1.device)
+        key = _ws_key(x1.device)
+        ws = _wino_ws64.get(key)
         if ws is None or ws.numel() < n:
-            _wino_ws64[x1.device] = None
-            ws = _wino_ws64[x1.device] = torch.empty(int(n), dtype=dt, device=x1.device)
+            _wino_ws64[key] = None
+            ws = _wino_ws64[key] = torch.empty(int(n), dtype=dt, device=x1.device)
         ev0 = _ev() if prof is not None else None
         check(lib.iiseg_conv_wino_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(self._U, dt),
                                       _ptr(self.b, dt), _ptr(add, dt), _ptr(ws, dt), _ptr(out, dt)),
@@ -1045,10 +1072,10 @@ def bn_stats(buf, c0, n, mean, inv_std, eps=1e-4):
     item = buf.element_size()
     _ptr(buf, dt), _ptr(mean, dt), _ptr(inv_std, dt)
     xp = C.c_void_p(buf.data_ptr() + c0 * H * W * item)
-    ws = _bn_ws.get(buf.device)
+    ws = _bn_ws.get(_ws_key(buf.device))
     need = _lib.load().iiseg_bn_stats_workspace_elems(n)
     if ws is None or ws.numel() < need:
-        ws = _bn_ws[buf.device] = torch.empty(int(need), dtype=torch.float64, device=buf.device)
+        ws = _bn_ws[_ws_key(buf.device)] = torch.empty(int(need), dtype=torch.float64, device=buf.device)
     check(_fn('bn_stats', dt)(_stream(), xp, Ctot * H * W, B, n, H * W, float(eps),
                               C.c_void_p(mean.data_ptr() + c0 * item),
                               C.c_void_p(inv_std.data_ptr() + c0 * item),
