@@ -462,18 +462,18 @@ def worker(args):
                  'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in full every '
                  'step and batch (same kernels)')
         ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
-    if not args.no_two_streams:
-        # The same fp32 batch as N concurrent sub-batches: N engines (own nets, sessions, graphs and
-        # scratch), each on its own HIP stream, so that the tail of one engine's kernels (the last,
-        # partly filled round of workgroups of every launch) overlaps the others'.  Same kernels,
-        # same per-image results (an image's result does not depend on its batch:
-        # test_full_config_batch_properties); reported next to `value`, never as `value`.
-        line['concurrent_streams'] = {}
+    def concurrent_leg(mma):
+        """The same batch as N concurrent sub-batches: N engines (own nets, sessions, graphs and
+        scratch), each on its own HIP stream, so that the tail of one engine's kernels (the last,
+        partly filled round of workgroups of every launch) overlaps the others'.  Same kernels, same
+        per-image results (an image's result does not depend on its batch:
+        test_full_config_batch_properties); reported next to a leg's value, never as it."""
+        res = {}
         for ns in [int(v) for v in args.streams.split(',') if v]:
             if ns < 2 or B % ns:
                 continue
             part = B // ns
-            engines = [build_model(device, concat_h)[0] for _ in range(ns)]
+            engines = [build_model(device, concat_h, mma=mma)[0] for _ in range(ns)]
             streams = [torch.cuda.Stream(device=device) for _ in range(ns)]
             for e, st_ in zip(engines, streams):
                 with torch.cuda.stream(st_):
@@ -497,14 +497,16 @@ def worker(args):
             torch.cuda.synchronize()
             iidist.barrier()
             d2 = time.perf_counter() - t2
-            line['concurrent_streams'][str(ns)] = {
-                'value': round(world * B * args.steps / d2, 3), 'unit': 'images/s',
-                'ms_per_step': round(d2 / args.steps * 1e3, 2), 'sub_batch': part}
+            res[str(ns)] = {'value': round(world * B * args.steps / d2, 3), 'unit': 'images/s',
+                            'ms_per_step': round(d2 / args.steps * 1e3, 2), 'sub_batch': part}
             del engines, streams
             torch.cuda.empty_cache()
-        line['concurrent_streams']['note'] = (
-            'fp32, the batch of %d as N concurrent sub-batches on N HIP streams (N engines); a '
-            'scheduling variant of the same work, not the headline' % B)
+        res['note'] = ('the batch of %d as N concurrent sub-batches on N HIP streams (N engines); a '
+                       'scheduling variant of the same work, not the leg\'s value' % B)
+        return res
+
+    if not args.no_two_streams:
+        line['concurrent_streams'] = concurrent_leg(None)
     if not args.no_bf16:
         # 16-bit MFMA leg (VERDICT row N1; north_star: ">= 1000 images/s at >= 40 % of fp16 MFMA
         # peak"): bf16 operands + fp32 accumulation on the wide 3x3 layers, everything else as in
@@ -542,6 +544,8 @@ def worker(args):
         if not args.no_roofline:
             leg16['roofline'] = conv_roofline(ii16, X, T, args.num_iter, args.step_size,
                                               d16 / args.steps * 1e3, PEAK_TFLOPS_BF16_MFMA)
+        if not args.no_two_streams:
+            leg16['concurrent_streams'] = concurrent_leg(args.bf16_mode)
         line['bf16'] = leg16
         del ii16
         torch.cuda.empty_cache()
