@@ -25,6 +25,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
@@ -604,19 +607,35 @@ __global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restri
 
 constexpr int FLAT_PCAP = 480;
 
-// FLAT tiling: patch rows a 256-pixel tile can need (worst case over tile positions)
+// FLAT tiling: patch rows a 256-pixel tile can need (worst case over tile positions).  Tile t starts
+// at pixel 256 t of the stacked window list; its first / last pixel fix the virtual rows it spans.
+// The start offsets inside an image repeat with period OH*OW / gcd(256, OH*OW) tiles, so at most that
+// many (and never more than the launch has) are looked at; the result is cached per (B, OH, OW).
 int flat_patch_rows(int B, int OH, int OW) {
-    const int64_t N = (int64_t)B * OH * OW;
-    const int npt = (int)((N + 255) / 256);
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int>, int> cache;
+    const auto key = std::make_tuple(B, OH, OW);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    const int64_t ohw = (int64_t)OH * OW, N = (int64_t)B * ohw;
+    const int64_t npt = (N + 255) / 256;
+    int64_t a = 256, b = ohw;
+    while (b) { const int64_t t = a % b; a = b; b = t; }      // gcd(256, OH*OW)
+    const int64_t period = ohw / a;
     int worst = 0;
-    for (int t = 0; t < npt; ++t) {
-        const int64_t n0 = (int64_t)t * 256, n1 = (n0 + 255 < N - 1) ? n0 + 255 : N - 1;
-        const int b0 = (int)(n0 / (OH * OW)), r0 = (int)(n0 % (OH * OW));
-        const int b1 = (int)(n1 / (OH * OW)), r1 = (int)(n1 % (OH * OW));
+    for (int64_t t = 0; t < npt; ++t) {
+        const int64_t n0 = t * 256, n1 = (n0 + 255 < N - 1) ? n0 + 255 : N - 1;
+        const int b0 = (int)(n0 / ohw), r0 = (int)(n0 % ohw);
+        const int b1 = (int)(n1 / ohw), r1 = (int)(n1 % ohw);
         const int v0 = b0 * (OH + 2) + r0 / OW, v1 = b1 * (OH + 2) + r1 / OW;
         if (v1 - v0 + 3 > worst) worst = v1 - v0 + 3;
-        if (t > 4096) break;                       // the pattern repeats with the image period
+        if (t >= period && t + 1 < npt) t = npt - 2;   // one full period seen: only the last tile is left
     }
+    std::lock_guard<std::mutex> g(mu);
+    cache[key] = worst;
     return worst;
 }
 
