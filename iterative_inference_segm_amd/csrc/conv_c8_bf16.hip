@@ -490,22 +490,28 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         // columns (lane, lane ^ 1); the even lane stores
 #pragma unroll
                         for (int jp = 0; jp < TN / 2; ++jp) {
+                        // (instruction count matters: on the 1- and 4-k-tile pooled layers this epilogue
+                        // is most of a workgroup -- rocprofv3 on the 16 -> 64 first layer: 1240 VALU +
+                        // 740 SALU instructions per wave around 36 MFMAs.  Vertical max first, ONE lane
+                        // exchange for the column partner's max, the four channels' bit pairs packed
+                        // into one dword before the single exchange of the partner's bits.)
                         f32x4 m;
-                        unsigned bits[4];
+                        unsigned own = 0;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const float a0 = v[2 * jp][q], a1 = v[2 * jp + 1][q];
-                            const float b0 = dpp_xor1(a0), b1 = dpp_xor1(a1);
-                            m[q] = fmaxf(fmaxf(a0, a1), fmaxf(b0, b1));
-                            const unsigned c = (unsigned)(l31 & 1);
-                            const unsigned own = ((a0 == m[q] ? 1u : 0u) << c) | ((a1 == m[q] ? 1u : 0u) << (2 + c));
-                            bits[q] = own | dpp_xor1(own);
+                            const float mv = fmaxf(a0, a1);
+                            m[q] = fmaxf(mv, dpp_xor1(mv));
+                            own |= ((a0 == m[q] ? 1u : 0u) | (a1 == m[q] ? 4u : 0u)) << (8 * q);
                         }
+                        // byte q of `own`: bit 0 = row 0, bit 2 = row 1 of THIS lane's column; shifted
+                        // to the column's bit position (x & 1) and merged with the partner's
+                        own <<= (unsigned)(l31 & 1);
+                        const unsigned mb = own | dpp_xor1(own);
                         const unsigned po = q_pix[jp] + (unsigned)(c8 * PPL);
                         u32x2 w2;
                         w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
                         __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)((q_ok[jp] && cok) ? po * 16u + 8u * lh : OOB), 0, 0);
-                        const unsigned mb = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
                         __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)((q_ok[jp] && cok) ? po * 8u + 4u * lh : OOB), 0, 0);
                         }
                     }
@@ -682,8 +688,8 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
         static const int tall_env = getenv("IISEG_C8_TALL") ? atoi(getenv("IISEG_C8_TALL")) : -1;
         const int r8 = (d->OH + 7) / 8 * 8, r16 = (d->OH + 15) / 16 * 16;
         const int64_t wgs16 = (int64_t)d->B * (r16 / 16) * tx * ((d->Cout + 63) / 64);
-        plan->tall = d->Cout > 32 && r16 * 100 <= r8 * 108 && wgs16 >= 1024;
-        if (tall_env >= 0) plan->tall = tall_env != 0 && d->Cout > 32;
+        plan->tall = r16 * 100 <= r8 * 108 && wgs16 >= 1024;
+        if (tall_env >= 0) plan->tall = tall_env != 0;
         static const int force = getenv("IISEG_C8_TILING") ? atoi(getenv("IISEG_C8_TILING")) : 0;  // 1 rect, 2 flat
         if ((fill < 0.75 || force == 2) && force != 1 && d->C2 == 0 &&
             (int64_t)d->B * cmax * d->H * d->W * 2 < (1ll << 31) &&
@@ -719,7 +725,7 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
     hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32>), dim3(grid), dim3(256), 0, s, p)
     if (plan.flat) {
         if (unpool) C8_LAUNCH(2, true, true); else C8_LAUNCH(2, true, false);
-    } else if (plan.tall && BM == 64) {
+    } else if (plan.tall) {
         if (unpool) C8_LAUNCH(4, false, true); else C8_LAUNCH(4, false, false);
     } else {
         if (unpool) C8_LAUNCH(2, false, true); else C8_LAUNCH(2, false, false);

@@ -15,6 +15,7 @@ LAYERS = [
     ('fcn.conv3_2', 256, 256, 105, 1, (21, 64), 'plain'),
     ('fcn.conv4_2', 512, 512, 52, 1, (8, 37), 'plain'),
     ('fcn.conv5_2', 512, 512, 26, 1, (1, 24), 'plain'),
+    ('dae.conv1_1', 16, 64, 224, 100, (98, 226), 'pool'),
     ('dae.conv2_1', 64, 128, 211, 1, (48, 116), 'pool'),
     ('dae.conv3_1', 128, 256, 105, 1, (22, 62), 'pool'),
     ('dae.conv4_1', 256, 512, 52, 1, (10, 33), 'pool'),
@@ -69,9 +70,10 @@ for name, cin, cout, H, pad, (org, win), kind in LAYERS:
         x8 = ops.nchw_to_c8(x)
         if kind == 'pool':
             pw = c_new.pool_window(H, H, window)
-            po = torch.empty(B, cout, H // 2, H // 2, device='cuda')
-            mo = torch.empty(B, cout, H // 2, H // 2, device='cuda', dtype=torch.uint8)
-            po8 = ops.empty_c8(B, cout, H // 2, H // 2, 'cuda')
+            fh = H + 2 * pad - 2
+            po = torch.empty(B, cout, fh // 2, fh // 2, device='cuda')
+            mo = torch.empty(B, cout, fh // 2, fh // 2, device='cuda', dtype=torch.uint8)
+            po8 = ops.empty_c8(B, cout, fh // 2, fh // 2, 'cuda')
             mo8 = torch.empty(po8.shape, dtype=torch.uint8, device='cuda')
             if c_old.mask_ok() and c_old.pool_fusable():
                 f_old = lambda: c_old(x, window=pw, pool_out=po, mask_out=mo, store_out=False)
