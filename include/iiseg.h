@@ -235,7 +235,8 @@ int iiseg_conv_halo_bf16(void* stream, const iiseg_conv_desc* d, const float* x1
                          uint8_t* mask_out);
 
 /* float64 Winograd F(2x2,3x3) form of iiseg_conv_f64 for the wide 3x3 layers of the strict-parity
- * path (stride 1, dil 1, (C1+C2) % 16 == 0, no IISEG_CONV_UNPOOL / TRANSPOSED2): input transform ->
+ * path (stride 1, dil 1, (C1+C2) % 16 == 0, no TRANSPOSED2; with IISEG_CONV_UNPOOL x1 = up, pre,
+ * pooled as in iiseg_conv_f64 and the DePool2D mask is applied by the input transform): input transform ->
  * 16 batched GEMMs on v_mfma_f64_16x16x4_f64 (operands by LDS-DMA) -> output transform + epilogue.
  * Same descriptor semantics as iiseg_conv_wino_f32 (window, placement, channel slice, add, ReLU, tile
  * anchor parity tile_y0 / tile_x0); results equal to iiseg_conv_f64 up to float64 rounding.
@@ -247,8 +248,8 @@ int64_t iiseg_conv_wino_f64_workspace_elems(const iiseg_conv_desc* d);
 int iiseg_conv_wino_pack_f64(void* stream, const iiseg_conv_desc* d, const double* w,
                              int64_t stride_o, int64_t stride_c, double* U);
 int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const double* x1, const double* x2,
-                        const double* U, const double* bias, const double* add, double* workspace,
-                        double* out);
+                        const double* pre, const double* pooled, const double* U, const double* bias,
+                        const double* add, double* workspace, double* out);
 
 /* bf16 "C8" activations: the 16-bit MFMA path with the tensors BETWEEN layers already in the matrix
  * pipe's operand format.  A C8 tensor of C channels is (B, ceil(C/8), H, W, 8) bf16 -- the 8 channels

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -74,7 +74,7 @@ SIGNATURES = {
     'iiseg_conv_wino_f64_weight_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_wino_f64_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_wino_pack_f64': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
-    'iiseg_conv_wino_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 7),
+    'iiseg_conv_wino_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_conv_c8_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_c8_is_flat': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_c8': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 6 + [_i32, _vp, _i32, _vp, _vp]),

@@ -15,8 +15,8 @@
 // coordinates of a fixed parity (descriptor tile_y0 / tile_x0), so a windowed launch reproduces the
 // full-map launch bit for bit (the loop-invariant / decoder-window eliminations rely on it).
 // Same Lasagne Conv2DLayer(3x3, stride 1) call sites as conv_wino.hip (models/fcn8.py:41-71,
-// models/fcn_down.py:102-104, models/fcn_up.py:83-86).  No DePool2D input form: the float64 path
-// materialises the unpooled map (csrc/pool_unpool.hip) and calls the plain layer.
+// models/fcn_down.py:102-104, models/fcn_up.py:83-86); with IISEG_CONV_UNPOOL the DePool2D mask
+// (layers/mylayers.py:88-115) is applied while the input transform loads its patches.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "iiseg.h"
@@ -32,6 +32,9 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 struct Wino64Params {
     const double* x1;
     const double* x2;
+    const double* pre;      // UNPOOL: x1 = up (B, C1, h2, w2), pre (B, C1, H, W), pooled (B, C1, h2, w2)
+    const double* pooled;
+    int h2, w2;
     const double* U;
     const double* bias;
     const double* add;
@@ -80,8 +83,12 @@ __global__ void wino64_weight_kernel(const double* __restrict__ w, int64_t so, i
     }
 }
 
-// one thread = one tile x 2 channels; lanes run along tiles (coalesced V stores)
+// one thread = one tile x 2 channels; lanes run along tiles (coalesced V stores).  UNPOOL: the logical
+// input is DePool2D(up = x1, pre, pooled) (layers/mylayers.py:88-115), formed while the patch is
+// loaded: element (iy, ix) = pre[iy][ix] == pooled[iy/2][ix/2] ? up[iy/2][ix/2] : 0 inside the
+// 2 h2 x 2 w2 region, 0 outside -- the materialised unpooled map (pool_unpool.hip) is not needed.
 constexpr int ICH64 = 2;
+template <bool UNPOOL>
 __global__ __launch_bounds__(256) void wino64_input_kernel(const Wino64Params p) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= p.T) return;
@@ -106,12 +113,46 @@ __global__ __launch_bounds__(256) void wino64_input_kernel(const Wino64Params p)
 #pragma unroll
     for (int cc = 0; cc < ICH64; ++cc) {
         const int c = min(c0 + cc, p.Kc - 1);
-        const double* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
-                                     : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+        if constexpr (UNPOOL) {
+            // the 4 x 4 patch touches at most 3 x 3 pooling cells: their pooled / up values loaded
+            // once, each element picks its cell by the parity of the patch origin
+            const size_t hw2 = (size_t)p.h2 * p.w2;
+            const double* prep = p.pre + ((size_t)b * p.C1 + c) * HW;
+            const double* poolp = p.pooled + ((size_t)b * p.C1 + c) * hw2;
+            const double* upp = p.x1 + ((size_t)b * p.C1 + c) * hw2;
+            const int qy0 = iy0 >> 1, qx0 = ix0 >> 1;      // arithmetic shift: floor for iy0 = -pad
+            const bool py = iy0 & 1, px = ix0 & 1;
+            double pq[3][3], uq[3][3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pv[cc][i][j] = src[(rok[i] && cok[j]) ? rowoff[i] + j : 0];
+                for (int j = 0; j < 3; ++j) {
+                    const bool ok = (unsigned)(qy0 + i) < (unsigned)p.h2 && (unsigned)(qx0 + j) < (unsigned)p.w2;
+                    const int q = ok ? (qy0 + i) * p.w2 + qx0 + j : 0;
+                    pq[i][j] = poolp[q];
+                    uq[i][j] = ok ? upp[q] : 0.0;
+                    if (!ok) pq[i][j] = __builtin_nan("");  // never equal: outside the pooled map -> 0
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rok[i] && cok[j];
+                    const double pr = prep[ok ? rowoff[i] + j : 0];
+                    const double pa = px ? pq[i >> 1][(j + 1) >> 1] : pq[i >> 1][j >> 1];
+                    const double pb = px ? pq[(i + 1) >> 1][(j + 1) >> 1] : pq[(i + 1) >> 1][j >> 1];
+                    const double ua = px ? uq[i >> 1][(j + 1) >> 1] : uq[i >> 1][j >> 1];
+                    const double ub = px ? uq[(i + 1) >> 1][(j + 1) >> 1] : uq[(i + 1) >> 1][j >> 1];
+                    pv[cc][i][j] = (ok && pr == (py ? pb : pa)) ? (py ? ub : ua) : 0.0;
+                }
+        } else {
+            const double* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
+                                         : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[cc][i][j] = src[(rok[i] && cok[j]) ? rowoff[i] + j : 0];
+        }
     }
 #pragma unroll
     for (int cc = 0; cc < ICH64; ++cc) {
@@ -121,7 +162,7 @@ __global__ __launch_bounds__(256) void wino64_input_kernel(const Wino64Params p)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[i][j] = (rok[i] && cok[j]) ? pv[cc][i][j] : 0.0;
+            for (int j = 0; j < 4; ++j) d[i][j] = (UNPOOL || (rok[i] && cok[j])) ? pv[cc][i][j] : 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // B^T d
             e[0][j] = d[0][j] - d[2][j];
@@ -294,8 +335,9 @@ struct Wino64Geom {
 
 int wino64_geom(const iiseg_conv_desc* d, Wino64Geom& g) {
     if (!d) return IISEG_ERR_NULL;
-    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & (IISEG_CONV_TRANSPOSED2 | IISEG_CONV_UNPOOL)))
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2))
         return IISEG_ERR_UNSUPPORTED;
+    if ((d->flags & IISEG_CONV_UNPOOL) && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
     if (d->B <= 0 || d->C1 <= 0 || d->C2 < 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 ||
         d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
         return IISEG_ERR_SHAPE;
@@ -352,18 +394,22 @@ extern "C" int iiseg_conv_wino_pack_f64(void* stream, const iiseg_conv_desc* d, 
 }
 
 extern "C" int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const double* x1,
-                                   const double* x2, const double* U, const double* bias,
-                                   const double* add, double* workspace, double* out) {
+                                   const double* x2, const double* pre, const double* pooled,
+                                   const double* U, const double* bias, const double* add,
+                                   double* workspace, double* out) {
     Wino64Geom g;
     const int st = wino64_geom(d, g);
     if (st) return st;
     if (!x1 || !U || !workspace || !out) return IISEG_ERR_NULL;
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
     if (((uintptr_t)U & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
     if (add && (d->ay0 < 0 || d->ax0 < 0 || d->ay0 + d->OH > d->AH || d->ax0 + d->OW > d->AW))
         return IISEG_ERR_SHAPE;
     Wino64Params p = {};
-    p.x1 = x1; p.x2 = x2; p.U = U; p.bias = bias; p.add = add;
+    p.x1 = x1; p.x2 = x2; p.pre = pre; p.pooled = pooled; p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.U = U; p.bias = bias; p.add = add;
     p.V = workspace;
     p.M = workspace + (size_t)16 * g.Kc * g.Tpad;
     p.out = out;
@@ -387,7 +433,10 @@ extern "C" int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const
     p.n_mtiles = g.Mpad / GBM;
     hipStream_t s = (hipStream_t)stream;
     const int tb = (g.T + 255) / 256;
-    hipLaunchKernelGGL(wino64_input_kernel, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
+    if (unpool)
+        hipLaunchKernelGGL(wino64_input_kernel<true>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(wino64_input_kernel<false>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
     hipLaunchKernelGGL(wino64_gemm_kernel, dim3(16 * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
     hipLaunchKernelGGL(wino64_output_kernel, dim3(tb, (d->Cout + OCH64 - 1) / OCH64), dim3(256), 0, s, p);
     return iiseg_check_launch();

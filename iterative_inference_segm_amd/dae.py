@@ -418,7 +418,9 @@ class StandardDAE:
                 mpre, mpool = mask_override[p]
             fuse = self.fuse_unpool
             if fuse is None:
-                fuse = conv.dtype == torch.float32
+                # fused in float32; in float64 where the layer runs in Winograd form (its input
+                # transform applies the mask), materialised for the direct float64 kernel
+                fuse = conv.dtype == torch.float32 or getattr(conv, 'wino_f64', False)
             if not fuse:
                 # materialise DePool2D with the HBM-bound kernel and run the plain conv
                 uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)

@@ -492,9 +492,9 @@ class Conv:
                 prof.append((names[i], self.flops(B, d.OH, d.OW) if i == 1 else 0.0, ev0, ev1))
                 ev0 = ev1
             return out
-        if dt == torch.float64 and self.wino_f64 and not unpool and not self.via_im2col and \
+        if dt == torch.float64 and self.wino_f64 and not self.via_im2col and \
                 self.lib.iiseg_conv_wino_f64_supported(C.byref(d)):
-            return self._call_wino_f64(d, x1, x2, add, out, prof, B)
+            return self._call_wino_f64(d, x1, x2, pre, pooled, add, out, prof, B)
         ev0 = _ev() if prof is not None else None
         if dt == torch.float64:
             check(self.lib.iiseg_conv_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt),
@@ -747,7 +747,7 @@ class Conv:
             ev0 = ev1
         return out
 
-    def _call_wino_f64(self, d, x1, x2, add, out, prof, B):
+    def _call_wino_f64(self, d, x1, x2, pre, pooled, add, out, prof, B):
         """float64 Winograd form (include/iiseg.h, iiseg_conv_wino_f64)."""
         lib = self.lib
         dt = torch.float64
@@ -763,7 +763,8 @@ class Conv:
             _wino_ws64[key] = None
             ws = _wino_ws64[key] = torch.empty(int(n), dtype=dt, device=x1.device)
         ev0 = _ev() if prof is not None else None
-        check(lib.iiseg_conv_wino_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(self._U, dt),
+        check(lib.iiseg_conv_wino_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(pre, dt),
+                                      _ptr(pooled, dt), _ptr(self._U, dt),
                                       _ptr(self.b, dt), _ptr(add, dt), _ptr(ws, dt), _ptr(out, dt)),
               'iiseg_conv_wino_f64')
         if prof is not None:

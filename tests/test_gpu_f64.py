@@ -203,3 +203,31 @@ def test_conv_wino_f64_concat_add_placement_and_exact_ties(ops):
     xc = np.broadcast_to(rng.standard_normal((1, 160, 1, 1)), (1, 160, 16, 16)).copy()
     got = host(ops.Conv(Wt, b, pad=1, relu=True, dtype=F64)(dev(xc)))[:, :, 1:-1, 1:-1]
     assert np.array_equal(got, np.broadcast_to(got[:, :, :1, :1], got.shape))
+
+
+@pytest.mark.parametrize('shape,window,anchor', [((2, 128, 13, 15), None, (0, 0)),
+                                                 ((1, 144, 16, 12), (3, 2, 9, 8), (1, 0)),
+                                                 ((2, 128, 9, 9), (0, 0, 9, 9), (1, 1))])
+def test_conv_wino_f64_fused_unpool(ops, shape, window, anchor):
+    """DePool2D (layers/mylayers.py:88-115) applied inside the float64 Winograd input transform: vs the
+    oracle, and bit-identical to the same Winograd layer run on the materialised unpooled map (odd
+    sizes leave the last row / column of `pre` outside every pooling window -> zeros)."""
+    B, Cc, H, W = shape
+    rng = np.random.default_rng(H * W + Cc)
+    pre = np.maximum(rng.standard_normal(shape), 0)          # ReLU zeros -> genuine ties
+    pooled = onn.maxpool2(pre)
+    up = rng.standard_normal(pooled.shape)
+    Wt, b = rng.standard_normal((80, Cc, 3, 3)), rng.standard_normal(80)
+    un = onn.depool_eqmask(up, pre, pooled)
+    ref = onn.conv2d(un, Wt, b, pad=1, relu=True)
+    conv = ops.Conv(Wt, b, pad=1, relu=True, dtype=F64)
+    assert conv.wino_f64
+    kw = dict(window=window) if window is not None else {}
+    got = host(conv(dev(up), pre=dev(pre), pooled=dev(pooled), anchor=anchor, **kw))
+    mat = host(conv(dev(un), anchor=anchor, **kw))
+    assert conv._U is not None
+    if window is not None:
+        y0, x0, h, w = window
+        ref = ref[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.abs(got - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
+    assert np.array_equal(got, mat)
