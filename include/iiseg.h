@@ -57,6 +57,13 @@ const char* iiseg_target_arch(void);
  * stride_c = Cout*K*K), the spatial flip of Lasagne's gradient form is applied
  * while packing; pad/dil are ignored. */
 #define IISEG_CONV_TRANSPOSED2 4u
+/* iiseg_conv_c8 only: the split-operand ("bf16x3") fp32-class mode of the 16-bit matrix pipe.  Every
+ * bf16 C8 tensor of the call (x1, `up`, add of kind 1, out of kind 1, pool_out) is a hi / lo PAIR in
+ * one allocation, (B, 2 C/8, H, W, 8): chunks [0, C/8) of an image = bf16(v), chunks [C/8, 2 C/8) =
+ * bf16(v - hi); the packed weights hold three k-groups [W_hi | W_lo | W_hi] (pack a (Cout, 3 C1)
+ * filter built that way with iiseg_conv_halo_bf16_pack); the layer accumulates
+ * x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32.  d->C1 stays the logical channel count; C2 must be 0. */
+#define IISEG_CONV_X3 8u
 
 typedef struct iiseg_conv_desc {
     /* logical input (after concat / unpool): (B, C1 + C2, H, W) */
@@ -286,6 +293,13 @@ int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int 
 int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled, uint8_t* mask,
                        int BC8, int PH, int PW, int py0, int px0, int H, int W, int y0, int x0, int wh,
                        int ww);
+/* The two helpers of the IISEG_CONV_X3 mode: fp32 NCHW -> hi / lo pair (B, 2 C8n, H, W, 8), and the
+ * pool of a C8 fp32 piece `pre` (B, C8n, PH, PW, 8) into a pooled hi / lo pair (B, 2 C8n, H/2, W/2, 8)
+ * + the (B, C8n, H/2, W/2, 8) mask bytes (same comparisons as iiseg_pool_mask_c8 with pre_f32). */
+int iiseg_nchw_to_c8x3(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
+int iiseg_pool_mask_c8x3(void* stream, const void* pre, void* pooled, uint8_t* mask, int B, int C8n,
+                         int PH, int PW, int py0, int px0, int H, int W, int y0, int x0, int wh,
+                         int ww);
 
 /* im2col + split-K GEMM form of iiseg_conv_f32 for 'valid' (pad 0, dil 1) KxK layers computed in
  * full into a dense output (FCN-8's fc6, models/fcn8.py:75-76): same packed weights `wp` (d->Kpad,

@@ -9,10 +9,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
+CONV_X3 = 8
 CONV_TRANSPOSED2 = 4
 
 
@@ -81,6 +82,8 @@ SIGNATURES = {
     'iiseg_nchw_to_c8': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8': (C.c_int, [_vp, _vp, _i32, _vp, _vp] + [_i32] * 11),
+    'iiseg_nchw_to_c8x3': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
+    'iiseg_pool_mask_c8x3': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 12),
     'iiseg_conv_gemm_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5 + [C.c_uint32]),

@@ -84,6 +84,7 @@ struct C8Params {
     int n_ptiles, n_mtiles, tiles_y, tiles_x;
     int N;                        // FLAT: B * OH * OW
     int PR, PWs;                  // FLAT: patch rows (capacity of a launch), patch row stride OW + 2
+    int x3;                       // split-operand mode (template X3)
     int debug;
 };
 
@@ -91,7 +92,16 @@ struct C8Params {
 // TN 32-pixel columns: TN = 2 -> 8 x 32 pixel tiles (or 256 flat pixels), TN = 4 -> 16 x 32 pixel
 // tiles: twice the MFMAs per k-tile between two barriers, per weight DMA and per workgroup prologue /
 // epilogue -- the form of the large-window layers (few k-tiles, the fixed costs of a tile dominate).
-template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32>
+//
+// X3 ("bf16x3", the fp32-class mode of the 16-bit pipe): every activation is a PAIR of C8 tensors in
+// one allocation, (B, 2 C/8, H, W, 8): chunks [0, C/8) of an image hold hi = bf16(v), chunks
+// [C/8, 2 C/8) hold lo = bf16(v - hi) -- 16 significant bits.  The weights are split the same way on
+// the host and packed as THREE k-groups [W_hi | W_lo | W_hi]; the kernel walks 3 C/16 k-tiles whose
+// inputs are [x_lo | x_hi | x_hi]: acc = x_lo W_hi + x_hi W_lo + x_hi W_hi in ONE fp32 accumulation
+// (small terms first; the dropped x_lo W_lo term is 2^-18 relative).  Same loop, same tiles, same
+// epilogue; outputs / skip addends / pooled maps of kind 1 are hi / lo pairs, the DePool2D masks and
+// the pool still come from the fp32 accumulators.
+template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3>
 __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     constexpr int TH = 4 * TN, TW = 32;
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
@@ -117,7 +127,9 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int HW = p.H * p.W, hw2 = p.h2 * p.w2;
     const int OHW = p.OH * p.OW;
-    const int CC1 = p.C1 >> 3;                               // chunks per image of source 1
+    const int CCh = p.C1 >> 3;                               // chunks of the C1 channels
+    const int CC1 = X3 ? 2 * CCh : CCh;                      // chunks per image of source 1
+    const int kt1 = p.C1 >> 4;                               // X3: k-tiles per k-group
 
     // ---- tile geometry -----------------------------------------------------------------------
     int tb = 0, wy0 = 0, wx0 = 0;     // RECT: image, tile origin in window coordinates
@@ -168,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         if constexpr (UNPOOL) {
             // DePool2D (layers/mylayers.py:95-114): only the 2 h2 x 2 w2 region has pooling windows
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
-            const unsigned idx = (unsigned)((b * CC1 + h) * hw2 + (iy >> 1) * p.w2 + (ix >> 1));
-            voff[i] = ok ? idx * 16u : OOB;
-            voffm[i] = ok ? idx * 8u : OOB;
+            const unsigned pq = (unsigned)((iy >> 1) * p.w2 + (ix >> 1));
+            voff[i] = ok ? ((unsigned)((b * CC1 + h) * hw2) + pq) * 16u : OOB;
+            voffm[i] = ok ? ((unsigned)((b * CCh + h) * hw2) + pq) * 8u : OOB;
             bsel[i] = ((iy & 1) << 1) | (ix & 1);
         } else {
             voff[i] = ok ? (unsigned)((b * CC1 + h) * HW + iy * p.W + ix) * 16u : OOB;
@@ -186,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     const i32x4s s_x1 = mk_srsrc(base1, (p.debug & 2) ? 0u : n1);
     const i32x4s s_x2 = mk_srsrc(base2, (p.debug & 2) ? 0u : n2);
     const __amdgpu_buffer_rsrc_t r_m =
-        mk_rsrc(UNPOOL ? p.mask_in + (FLAT ? (size_t)0 : (size_t)tb * CC1 * hw2 * 8) : nullptr,
-                UNPOOL ? n1 / 2 : 0u);
+        mk_rsrc(UNPOOL ? p.mask_in + (FLAT ? (size_t)0 : (size_t)tb * CCh * hw2 * 8) : nullptr,
+                UNPOOL ? (unsigned)((FLAT ? p.B : 1) * CCh * hw2) * 8u : 0u);
     const i32x4s s_w = mk_srsrc(p.wp, (p.debug & 1) ? 0u : (unsigned)(p.nkt * 18 * p.Mpad) * 16u);
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr(&Ws[0][0]) + (unsigned)wave * 1024u);
     const unsigned lds_p = __builtin_amdgcn_readfirstlane(lds_addr(&Ps[0][0]) + (unsigned)wave * 1024u);
@@ -224,9 +236,14 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 
     // k-tile KT = channels [16 KT, 16 KT + 16) of the logical (concatenated) input; its source is
     // tile-uniform (C1 % 16 == 0)
+    // (X3: k-group 0 reads the lo chunks, groups 1 and 2 the hi chunks)
+#define C8_KS(KT)                                                                                  \
+    const int ks = !X3 ? (KT) : ((KT) < kt1 ? (KT) : ((KT) < 2 * kt1 ? (KT) - kt1 : (KT) - 2 * kt1)); \
+    const int kc = 2 * ks + ((X3 && (KT) < kt1) ? CCh : 0);
 #define C8_SRC(KT)                                                                                 \
-    const bool s1 = UNPOOL || (KT) * 2 < CC1;                                                      \
-    const unsigned so = (unsigned)(((KT) * 2 - (s1 ? 0 : CC1)) * plane) * 16u;
+    C8_KS(KT)                                                                                      \
+    const bool s1 = X3 || UNPOOL || kc < CC1;                                                      \
+    const unsigned so = (unsigned)((kc - (s1 ? 0 : CC1)) * plane) * 16u;
     // patch of k-tile KT by LDS-DMA: lane -> one chunk, a wave's 64 chunks land contiguously
 #define C8_DMA_X(KT, BUF)                                                                          \
     {                                                                                              \
@@ -258,13 +275,15 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     u32x2 xm[UNPOOL ? NE : 1];
 #define C8_LOAD_U(KT)                                                                              \
     {                                                                                              \
-        const unsigned so = (unsigned)((KT) * 2 * hw2) * 16u;                                      \
+        C8_KS(KT)                                                                                  \
+        const unsigned so = (unsigned)(kc * hw2) * 16u;                                            \
+        const unsigned som = (unsigned)(2 * ks * hw2) * 8u;                                        \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(               \
                 r_x1, (int)voff[i], (int)so, 0));                                                  \
             xm[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                \
-                r_m, (int)voffm[i], (int)(so >> 1), 0));                                           \
+                r_m, (int)voffm[i], (int)som, 0));                                                 \
         });                                                                                        \
     }
 #define C8_STORE_U(BUF)                                                                            \
@@ -348,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         }
     }
 #undef C8_SRC
+#undef C8_KS
 #undef C8_DMA_X
 #undef C8_DMA_W
 #undef C8_LOAD_U
@@ -389,18 +409,22 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         // chunks of the Cout output channels: whole 16-channel groups (the layout every C8 consumer
         // expects); channels past Cout come out as exact zeros (zero weight rows, no bias)
         const int oct8 = p.out_ctot >> 3, co8 = ((p.Cout + 15) >> 4) << 1;
+        // X3: a kind-1 tensor holds hi chunks, then lo chunks, per image
+        const int octT = (X3 && p.out_kind == 1) ? 2 * oct8 : oct8;
+        const int co8A = (X3 && p.add_kind == 1) ? 2 * co8 : co8;
+        const int co8P = X3 ? 2 * co8 : co8;
         const unsigned osz = p.out_kind == 2 ? 32u : 16u;     // bytes per output chunk
         const __amdgpu_buffer_rsrc_t r_out =
-            mk_rsrc(p.out ? (const char*)p.out + (size_t)ib * oct8 * OPL * osz : nullptr,
-                    p.out ? (unsigned)((FLAT ? p.B : 1) * oct8 * OPL) * osz : 0u);
+            mk_rsrc(p.out ? (const char*)p.out + (size_t)ib * octT * OPL * osz : nullptr,
+                    p.out ? (unsigned)((FLAT ? p.B : 1) * octT * OPL) * osz : 0u);
         const unsigned asz = p.add_kind == 2 ? 32u : 16u;
         const __amdgpu_buffer_rsrc_t r_add =
-            mk_rsrc(p.add ? (const char*)p.add + (size_t)ib * co8 * APL * asz : nullptr,
-                    p.add ? (unsigned)((FLAT ? p.B : 1) * co8 * APL) * asz : 0u);
+            mk_rsrc(p.add ? (const char*)p.add + (size_t)ib * co8A * APL * asz : nullptr,
+                    p.add ? (unsigned)((FLAT ? p.B : 1) * co8A * APL) * asz : 0u);
         const bool pooling = !FLAT && p.pool != nullptr;
         const __amdgpu_buffer_rsrc_t r_pool =
-            mk_rsrc(pooling ? (const char*)p.pool + (size_t)ib * co8 * PPL * 16 : nullptr,
-                    pooling ? (unsigned)(co8 * PPL) * 16u : 0u);
+            mk_rsrc(pooling ? (const char*)p.pool + (size_t)ib * co8P * PPL * 16 : nullptr,
+                    pooling ? (unsigned)(co8P * PPL) * 16u : 0u);
         const __amdgpu_buffer_rsrc_t r_mask =
             mk_rsrc(pooling && p.mask_out ? p.mask_out + (size_t)ib * co8 * PPL * 8 : nullptr,
                     pooling && p.mask_out ? (unsigned)(co8 * PPL) * 8u : 0u);
@@ -408,8 +432,8 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         unsigned opix[TN], apix[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            opix[j] = (unsigned)(eb[j] * oct8 * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
-            apix[j] = (unsigned)(eb[j] * co8 * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+            opix[j] = (unsigned)(eb[j] * octT * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
+            apix[j] = (unsigned)(eb[j] * co8A * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
         }
         // fused pool (RECT): the wave's rows are TN / 2 row pairs, lane ^ 1 is the column partner
         bool q_ok[TN / 2];
@@ -446,6 +470,11 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         const u32x2 a2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
                             r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 16u + 8u * lh : OOB), 0, 0));
                         adr[g][j][0] = a2[0]; adr[g][j][1] = a2[1];
+                        if constexpr (X3) {
+                            const u32x2 a3 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)((c8 + co8) * APL)) * 16u + 8u * lh : OOB), 0, 0));
+                            adr[g][j][2] = a3[0]; adr[g][j][3] = a3[1];
+                        }
                     } else if (has_add2) {
                         adr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                             r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 32u + 16u * lh : OOB), 0, 0));
@@ -465,6 +494,11 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                     if (has_add1) {
                         v[j][0] += bf_lo(adr[g][j][0]); v[j][1] += bf_hi(adr[g][j][0]);
                         v[j][2] += bf_lo(adr[g][j][1]); v[j][3] += bf_hi(adr[g][j][1]);
+                        if constexpr (X3) {
+                            // hi + lo first: the pair is the 16-bit value the producer stored
+                            v[j][0] += bf_lo(adr[g][j][2]); v[j][1] += bf_hi(adr[g][j][2]);
+                            v[j][2] += bf_lo(adr[g][j][3]); v[j][3] += bf_hi(adr[g][j][3]);
+                        }
                     } else if (has_add2) {
                         v[j] += __builtin_bit_cast(f32x4, adr[g][j]);
                     }
@@ -478,6 +512,13 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         u32x2 w2;
                         w2[0] = pack_bf16(v[j][0], v[j][1]); w2[1] = pack_bf16(v[j][2], v[j][3]);
                         __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)(ok ? oo * 16u + 8u * lh : OOB), 0, 0);
+                        if constexpr (X3) {
+                            u32x2 l2;
+                            l2[0] = pack_bf16(v[j][0] - bf_lo(w2[0]), v[j][1] - bf_hi(w2[0]));
+                            l2[1] = pack_bf16(v[j][2] - bf_lo(w2[1]), v[j][3] - bf_hi(w2[1]));
+                            __builtin_amdgcn_raw_buffer_store_b64(
+                                l2, r_out, (int)(ok ? (oo + (unsigned)(oct8 * OPL)) * 16u + 8u * lh : OOB), 0, 0);
+                        }
                     } else if (p.out_kind == 2) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), r_out,
                                                                (int)(ok ? oo * 32u + 16u * lh : OOB), 0, 0);
@@ -512,6 +553,13 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         u32x2 w2;
                         w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
                         __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)((q_ok[jp] && cok) ? po * 16u + 8u * lh : OOB), 0, 0);
+                        if constexpr (X3) {
+                            u32x2 l2;
+                            l2[0] = pack_bf16(m[0] - bf_lo(w2[0]), m[1] - bf_hi(w2[0]));
+                            l2[1] = pack_bf16(m[2] - bf_lo(w2[1]), m[3] - bf_hi(w2[1]));
+                            __builtin_amdgcn_raw_buffer_store_b64(
+                                l2, r_pool, (int)((q_ok[jp] && cok) ? (po + (unsigned)(co8 * PPL)) * 16u + 8u * lh : OOB), 0, 0);
+                        }
                         __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)((q_ok[jp] && cok) ? po * 8u + 4u * lh : OOB), 0, 0);
                         }
                     }
@@ -521,7 +569,9 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     }
 }
 
-// x (B, C, H, W) fp32 -> C8 (B, C8n, H, W, 8) bf16, channels >= C zero
+// x (B, C, H, W) fp32 -> C8 (B, C8n, H, W, 8) bf16, channels >= C zero; X3: the hi / lo pair
+// (B, 2 C8n, H, W, 8), lo = bf16(x - hi)
+template <bool X3>
 __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ x, uint4* __restrict__ out,
                                                          int C, int HW, int C8n, int64_t total) {
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -535,8 +585,19 @@ __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict
             const int c = c8 * 8 + j;
             v[j] = c < C ? x[(b * C + c) * HW + pix] : 0.f;
         }
-        out[t] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
-                            pack_bf16(v[6], v[7]));
+        const uint4 hi = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
+                                    pack_bf16(v[6], v[7]));
+        if constexpr (X3) {
+            const int64_t o = ((b * 2 * C8n + c8) * HW) + pix;
+            out[o] = hi;
+            out[o + (int64_t)C8n * HW] =
+                make_uint4(pack_bf16(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x)),
+                           pack_bf16(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y)),
+                           pack_bf16(v[4] - bf_lo(hi.z), v[5] - bf_hi(hi.z)),
+                           pack_bf16(v[6] - bf_lo(hi.w), v[7] - bf_hi(hi.w)));
+        } else {
+            out[t] = hi;
+        }
     }
 }
 
@@ -565,11 +626,12 @@ __global__ __launch_bounds__(256) void c8_to_nchw_kernel(const uint4* __restrict
 // mask != NULL, the DePool2D mask bytes.  With F32 the comparisons are those of the fused epilogue of
 // conv_c8_kernel (fp32 values, rounded after the max), so a level gives the same masks whichever
 // pixel tiling its conv ran on.
+// x3_c8n > 0 (F32 only): pooled is a hi / lo pair (B, 2 x3_c8n, H/2, W/2, 8), the mask is not.
 template <bool F32>
 __global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restrict__ pre, uint4* __restrict__ pooled,
                                                            uint2* __restrict__ mask, int PH, int PW,
                                                            int py0, int px0, int h2, int w2, int y0, int x0,
-                                                           int wh, int ww, int64_t total) {
+                                                           int wh, int ww, int x3_c8n, int64_t total) {
     constexpr int Q = F32 ? 2 : 1;                  // uint4 per chunk
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int qx = (int)(t % ww);
@@ -603,8 +665,20 @@ __global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restri
                       (v[2][j] == m[j] ? 4u : 0u) | (v[3][j] == m[j] ? 8u : 0u);
         }
         const int64_t o = (r * h2 + Y) * w2 + X;
-        pooled[o] = make_uint4(pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3]), pack_bf16(m[4], m[5]),
-                               pack_bf16(m[6], m[7]));
+        const uint4 hi = make_uint4(pack_bf16(m[0], m[1]), pack_bf16(m[2], m[3]), pack_bf16(m[4], m[5]),
+                                    pack_bf16(m[6], m[7]));
+        if (x3_c8n > 0) {
+            const int64_t bb = r / x3_c8n, c8 = r - bb * x3_c8n;
+            const int64_t oh = (((bb * 2 * x3_c8n + c8) * h2) + Y) * w2 + X;
+            pooled[oh] = hi;
+            pooled[oh + (int64_t)x3_c8n * h2 * w2] =
+                make_uint4(pack_bf16(m[0] - bf_lo(hi.x), m[1] - bf_hi(hi.x)),
+                           pack_bf16(m[2] - bf_lo(hi.y), m[3] - bf_hi(hi.y)),
+                           pack_bf16(m[4] - bf_lo(hi.z), m[5] - bf_hi(hi.z)),
+                           pack_bf16(m[6] - bf_lo(hi.w), m[7] - bf_hi(hi.w)));
+        } else {
+            pooled[o] = hi;
+        }
         if (mask)
             mask[o] = make_uint2(bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24),
                                  bits[4] | (bits[5] << 8) | (bits[6] << 16) | (bits[7] << 24));
@@ -659,6 +733,8 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
         d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
         return IISEG_ERR_SHAPE;
     if (d->C1 % 16 || d->C2 % 16) return IISEG_ERR_UNSUPPORTED;     // whole k-tiles per source
+    const bool x3 = (d->flags & IISEG_CONV_X3) != 0;
+    if (x3 && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
     const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
     if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
     if ((d->flags & IISEG_CONV_UNPOOL) && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
@@ -666,15 +742,15 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
     if (d->out_H != 0 && (d->out_y0 < 0 || d->out_x0 < 0 || d->out_y0 + d->OH > d->out_H ||
                           d->out_x0 + d->OW > d->out_W))
         return IISEG_ERR_SHAPE;
-    const int64_t cmax = d->C1 > d->C2 ? d->C1 : d->C2;
+    const int64_t cmax = (d->C1 > d->C2 ? d->C1 : d->C2) * (x3 ? 2 : 1);
     // RECT: one image of every tensor is addressed with 32-bit byte offsets
     if (cmax * d->H * d->W * 2 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const int64_t octot = d->out_ctot ? d->out_ctot : d->Cout;
     const int64_t opl = d->out_H ? (int64_t)d->out_H * d->out_W : (int64_t)d->OH * d->OW;
-    if ((octot + 64) * opl * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if ((octot + 64) * opl * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;   // (x3 pair: 2 x 2 bytes)
     if (((int64_t)d->Cout + 64) * d->AH * d->AW * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const int bm = d->Cout > 32 ? 64 : 32, mpad = (d->Cout + bm - 1) / bm * bm;
-    const int nkt = (d->C1 + d->C2) / 16;
+    const int nkt = (d->C1 + d->C2) / 16 * (x3 ? 3 : 1);
     if ((int64_t)nkt * 18 * mpad * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     if (plan) {
         // FLAT where a 32-column tiling would leave more than a quarter of its MFMAs on padding and
@@ -721,8 +797,13 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
         p.n_ptiles = p.B * p.tiles_y * p.tiles_x;
     }
     const int grid = p.n_ptiles * p.n_mtiles;
-#define C8_LAUNCH(TNV, FL, UN) \
-    hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32>), dim3(grid), dim3(256), 0, s, p)
+#define C8_LAUNCH(TNV, FL, UN)                                                                     \
+    do {                                                                                           \
+        if (p.x3)                                                                                  \
+            hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, true>), dim3(grid), dim3(256), 0, s, p); \
+        else                                                                                       \
+            hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, false>), dim3(grid), dim3(256), 0, s, p); \
+    } while (0)
     if (plan.flat) {
         if (unpool) C8_LAUNCH(2, true, true); else C8_LAUNCH(2, true, false);
     } else if (plan.tall) {
@@ -787,7 +868,8 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     p.h2 = d->H / 2; p.w2 = d->W / 2;
     p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0; p.pad = d->pad;
     p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
-    p.nkt = (d->C1 + d->C2) / 16;
+    p.x3 = (d->flags & IISEG_CONV_X3) ? 1 : 0;
+    p.nkt = (d->C1 + d->C2) / 16 * (p.x3 ? 3 : 1);
     const int bm = d->Cout > 32 ? 64 : 32;
     p.Mpad = (d->Cout + bm - 1) / bm * bm;
     // dense C8 output: the Cout channels padded to whole 16-channel groups
@@ -813,8 +895,19 @@ extern "C" int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, 
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(nchw_to_c8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint4*)out,
-                       C, H * W, C8n, total);
+    hipLaunchKernelGGL(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint4*)out, C, H * W, C8n, total);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_nchw_to_c8x3(void* stream, const float* x, void* out, int B, int C, int H, int W,
+                                  int C8n) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)B * C8n * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(nchw_to_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint4*)out, C, H * W, C8n, total);
     return iiseg_check_launch();
 }
 
@@ -829,10 +922,11 @@ extern "C" int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, 
     return iiseg_check_launch();
 }
 
-extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled,
-                                  uint8_t* mask, int BC8, int PH, int PW, int py0, int px0, int H,
-                                  int W, int y0, int x0, int wh, int ww) {
+static int pool_mask_c8_impl(void* stream, const void* pre, int pre_f32, void* pooled, uint8_t* mask,
+                             int BC8, int PH, int PW, int py0, int px0, int H, int W, int y0, int x0,
+                             int wh, int ww, int x3_c8n) {
     if (!pre || !pooled) return IISEG_ERR_NULL;
+    if (x3_c8n && (!pre_f32 || x3_c8n < 0 || BC8 % x3_c8n)) return IISEG_ERR_UNSUPPORTED;
     if (BC8 <= 0 || wh <= 0 || ww <= 0) return IISEG_ERR_SHAPE;
     // every 2x2 window of the pooled region must lie inside the stored piece of the pre-pool map
     if (y0 < 0 || x0 < 0 || y0 + wh > H / 2 || x0 + ww > W / 2 || 2 * y0 < py0 || 2 * x0 < px0 ||
@@ -843,10 +937,25 @@ extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, vo
     if (pre_f32)
         hipLaunchKernelGGL(pool_mask_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)pre, (uint4*)pooled, (uint2*)mask, PH, PW, py0, px0, H / 2,
-                           W / 2, y0, x0, wh, ww, total);
+                           W / 2, y0, x0, wh, ww, x3_c8n, total);
     else
         hipLaunchKernelGGL(pool_mask_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)pre, (uint4*)pooled, (uint2*)mask, PH, PW, py0, px0, H / 2,
-                           W / 2, y0, x0, wh, ww, total);
+                           W / 2, y0, x0, wh, ww, 0, total);
     return iiseg_check_launch();
+}
+
+extern "C" int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled,
+                                  uint8_t* mask, int BC8, int PH, int PW, int py0, int px0, int H,
+                                  int W, int y0, int x0, int wh, int ww) {
+    return pool_mask_c8_impl(stream, pre, pre_f32, pooled, mask, BC8, PH, PW, py0, px0, H, W, y0, x0,
+                             wh, ww, 0);
+}
+
+extern "C" int iiseg_pool_mask_c8x3(void* stream, const void* pre, void* pooled, uint8_t* mask,
+                                    int B, int C8n, int PH, int PW, int py0, int px0, int H, int W,
+                                    int y0, int x0, int wh, int ww) {
+    if (B <= 0 || C8n <= 0) return IISEG_ERR_SHAPE;
+    return pool_mask_c8_impl(stream, pre, 1, pooled, mask, B * C8n, PH, PW, py0, px0, H, W, y0, x0, wh,
+                             ww, C8n);
 }

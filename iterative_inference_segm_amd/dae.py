@@ -57,7 +57,9 @@ class StandardDAE:
         mma = mma or ops.DEFAULT_MMA
         self.mma = mma
         # bf16 C8 activations between the layers (ops.Conv mma='bf16c8', `_scores_c8`)
-        self.c8 = mma == 'bf16c8' and dtype == torch.float32
+        # ('bf16x3': the same plan on hi / lo pairs, the fp32-class mode of that kernel)
+        self.c8 = mma in ('bf16c8', 'bf16x3') and dtype == torch.float32
+        self.x3 = self.c8 and mma == 'bf16x3'
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input', 'pool5']
                    for el in concat_h)                                   # fcn_down.py:39-41
         if concat_h[-1] == 'input' and additional_pool == 0:
@@ -453,7 +455,7 @@ class StandardDAE:
     def c8_feed(self, session):
         """The C8 buffer a fused refinement update may write the new y into for the NEXT `scores`
         call of this session (ops.refine_update(..., y8=)), or None; `c8_fed(session)` afterwards."""
-        if not self.c8 or not isinstance(session, dict):
+        if not self.c8 or self.x3 or not isinstance(session, dict):
             return None
         return session.get('y8')
 
@@ -499,7 +501,7 @@ class StandardDAE:
             t = ops.nchw_to_c8(y, out=session.get('y8') if session is not None and
                                session.get('y8') is not None and
                                tuple(session['y8'].shape[2:4]) == tuple(y.shape[2:4]) and
-                               session['y8'].shape[0] == B else None)
+                               session['y8'].shape[0] == B else None, x3=self.x3)
             if session is not None:
                 session['y8'] = t
         if session is not None:
@@ -531,27 +533,30 @@ class StandardDAE:
                 kw['window'] = conv.pool_window(t.shape[2], t.shape[3], dep)
                 pooled_t, m = session['pool%d' % (p + 1)], session['mask%d' % (p + 1)]
             else:
-                pooled_t = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev)
-                m = torch.empty(pooled_t.shape, dtype=torch.uint8, device=dev)
+                pooled_t = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev, x3=self.x3)
+                m = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev, dtype=torch.uint8)
             kw.update(pool_out=pooled_t, mask_out=m, store_out=False)
             if pending_h is not None and name in self.hsplit:
                 conv_h, conv_y = self.hsplit[name]
                 keep = session is not None and self.licm
                 hb = session.get('hb_' + name) if keep else None
                 if hb is None:                           # loop-invariant: once per refine()
-                    hb = conv_h(ops.nchw_to_c8(pending_h), out_format='c8f32')
+                    hb = conv_h(ops.nchw_to_c8(pending_h, x3=self.x3), out_format='c8f32')
                     if keep:
                         session['hb_' + name] = hb
                 elif h_fresh:                            # reused session: only where h changed
                     hd = session['h_dep'][pos - 1]
                     hy0, hh = clip(hd[0] + conv_h.pad - 2, hd[0] + hd[2] + conv_h.pad, hb.shape[2])
                     hx0, hw = clip(hd[1] + conv_h.pad - 2, hd[1] + hd[3] + conv_h.pad, hb.shape[3])
-                    conv_h(ops.nchw_to_c8(pending_h), window=(hy0, hx0, hh, hw), out=hb,
+                    conv_h(ops.nchw_to_c8(pending_h, x3=self.x3), window=(hy0, hx0, hh, hw), out=hb,
                            place=(hy0, hx0), out_format='c8f32')
                 off = (kw['window'][0], kw['window'][1]) if 'window' in kw else (0, 0)
                 conv_y(t, add=hb, add_off=off, **kw)
                 pending_h = None
             elif pending_h is not None:                  # h first, then features (P13)
+                if self.x3:
+                    raise NotImplementedError("mma='bf16x3' needs the h-split form of a concat "
+                                              "point (hsplit=True)")
                 conv(ops.nchw_to_c8(pending_h), x2=t, **kw)
                 pending_h = None
             else:
@@ -603,7 +608,7 @@ class StandardDAE:
             out = None
             if not full:
                 out = torch.empty((B, conv.Cout, oh, ow), dtype=torch.float32, device=dev) if p == 1 \
-                    else ops.empty_c8(B, conv.Cout, oh, ow, dev)
+                    else ops.empty_c8(B, conv.Cout, oh, ow, dev, x3=self.x3)
             kw = dict(mask_in=masks[p], unpool_hw=(ph, pw), window=(cy + y0, cx + x0, nh, nw),
                       out=out, place=None if full else (y0, x0),
                       out_format='nchw' if p == 1 else 'c8')

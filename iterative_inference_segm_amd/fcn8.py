@@ -56,6 +56,8 @@ class FCN8:
         'bf16' = 16-bit MFMA operands with fp32 accumulation; 'bf16c8' = additionally bf16 C8
         activations between the 3x3 layers, the h maps handed out stay fp32 NCHW; ops.Conv)."""
         mma = mma or ops.DEFAULT_MMA
+        if mma == 'bf16x3':
+            mma = 'f32'            # the split-operand mode is the DAE loop's; this net runs once per batch
         self.c8 = mma == 'bf16c8' and dtype == torch.float32
         self.layer = list(layer)
         self.n_classes = n_classes

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2, check
+from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2, CONV_X3, check
 
 # When set to a list, every conv launch appends (kernel, executed_flops, start_event, end_event):
 # HIP events recorded on the launch stream right around the kernel (bench.py's roofline leg).
@@ -172,17 +172,21 @@ class Conv:
         precision on the matrix pipe (float32 tensors only; None: ops.DEFAULT_MMA)."""
         self.lib = _lib.load()
         self.mma = (mma or DEFAULT_MMA) if dtype == torch.float32 else 'f32'
-        if self.mma not in ('f32', 'bf16', 'bf16c8'):
-            raise ValueError("mma must be 'f32', 'bf16' or 'bf16c8'")
+        if self.mma not in ('f32', 'bf16', 'bf16c8', 'bf16x3'):
+            raise ValueError("mma must be 'f32', 'bf16', 'bf16c8' or 'bf16x3'")
         # 'bf16c8': bf16 MFMA operands AND bf16 C8 activations between the 3x3 layers (conv_c8_bf16.hip);
-        # a layer takes that form when it is handed a C8 tensor, any other call is the 'bf16' mode
-        self.c8 = self.mma == 'bf16c8'
+        # a layer takes that form when it is handed a C8 tensor, any other call is the 'bf16' mode.
+        # 'bf16x3': the fp32-class mode of the same kernel -- activations and weights as bf16 hi / lo
+        # pairs, three products per term (IISEG_CONV_X3); any other call is the 'f32' mode
+        self.x3 = self.mma == 'bf16x3'
+        self.c8 = self.mma in ('bf16c8', 'bf16x3')
         if self.c8:
-            self.mma = 'bf16'
+            self.mma = 'f32' if self.x3 else 'bf16'
         self.transposed = bool(transposed)
         self.dtype = dtype
         self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
         self.b = None if b is None else torch.as_tensor(b).to(dtype).contiguous().to(device)
+        self.layout = layout
         if layout == 'oihw':
             self.Cout, self.Cin, self.KH, self.KW = self.W.shape
             self.so, self.sc = self.Cin * self.KH * self.KW, self.KH * self.KW
@@ -590,9 +594,14 @@ class Conv:
         if not self.c8:
             raise RuntimeError("C8 input needs a 3x3 layer built with mma='bf16c8'")
         unpool = mask_in is not None
-        B, CC1 = x1.shape[0], x1.shape[1]
+        x3 = self.x3
+        pair = 2 if x3 else 1                     # chunk planes of a kind-1 tensor per channel chunk
+        if x1.shape[1] % pair or (x3 and x2 is not None):
+            raise RuntimeError('bf16x3 layer: hi / lo pair input, no channel concat')
+        B, CC1 = x1.shape[0], x1.shape[1] // pair
         if unpool:
-            if unpool_hw is None or not is_c8_mask(mask_in) or mask_in.shape != x1.shape or \
+            if unpool_hw is None or not is_c8_mask(mask_in) or \
+                    tuple(mask_in.shape) != (B, CC1) + tuple(x1.shape[2:]) or \
                     (unpool_hw[0] // 2, unpool_hw[1] // 2) != tuple(x1.shape[2:4]) or x2 is not None:
                 raise RuntimeError('C8 DePool2D input: up %s, mask %s, unpool_hw %s'
                                    % (tuple(x1.shape), tuple(mask_in.shape), unpool_hw))
@@ -617,11 +626,13 @@ class Conv:
         d.B, d.C1, d.C2, d.H, d.W = B, CC1 * 8, CC2 * 8, H, W
         d.Cout, d.KH, d.KW, d.pad, d.dil = self.Cout, 3, 3, self.pad, 1
         d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
-        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0)
+        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0) | \
+            (CONV_X3 if x3 else 0)
         add_kind = 0
         if add is not None:
             add_kind = 1 if is_c8(add) else 2
-            if add.dim() != 5 or add.shape[0] != B or add.shape[1] != c8_chunks(self.Cout) or \
+            if add.dim() != 5 or add.shape[0] != B or \
+                    add.shape[1] != c8_chunks(self.Cout) * (pair if add_kind == 1 else 1) or \
                     add.dtype not in (torch.bfloat16, torch.float32):
                 raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
             d.AH, d.AW, d.ay0, d.ax0 = add.shape[2], add.shape[3], add_off[0], add_off[1]
@@ -638,20 +649,22 @@ class Conv:
             if fmt == 'nchw':
                 out = torch.empty((B, self.Cout, OH, OW), dtype=torch.float32, device=x1.device)
             else:
-                out = torch.empty((B, oc8, OH, OW, 8), device=x1.device,
+                out = torch.empty((B, oc8 * (pair if fmt == 'c8' else 1), OH, OW, 8), device=x1.device,
                                   dtype=torch.bfloat16 if fmt == 'c8' else torch.float32)
         if out is not None:
             ok = (out.dim() == 4 and out.dtype == torch.float32 and out.shape[1] == self.Cout) \
                 if fmt == 'nchw' else \
-                (out.dim() == 5 and out.shape[1] == oc8 and
+                (out.dim() == 5 and out.shape[1] == oc8 * (pair if fmt == 'c8' else 1) and
                  out.dtype == (torch.bfloat16 if fmt == 'c8' else torch.float32))
             if not ok or out.shape[0] != B or (place is None and tuple(out.shape[2:4]) != (OH, OW)):
                 raise RuntimeError('bad C8 output target %s' % (tuple(out.shape),))
         if pool_out is not None:
-            if not is_c8(pool_out) or tuple(pool_out.shape) != (B, oc8, fullH // 2, fullW // 2, 8):
+            if not is_c8(pool_out) or \
+                    tuple(pool_out.shape) != (B, oc8 * pair, fullH // 2, fullW // 2, 8):
                 raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
-            if mask_out is not None and (not is_c8_mask(mask_out) or mask_out.shape != pool_out.shape):
-                raise RuntimeError('mask_out: uint8 of pool_out\'s shape')
+            if mask_out is not None and (not is_c8_mask(mask_out) or
+                                         tuple(mask_out.shape) != (B, oc8, fullH // 2, fullW // 2, 8)):
+                raise RuntimeError('mask_out: uint8 (B, Cout/8, H/2, W/2, 8)')
         elif mask_out is not None:
             raise RuntimeError('mask_out needs pool_out')
         if self._W16c8 is None:
@@ -660,11 +673,25 @@ class Conv:
             dp.B, dp.C1, dp.C2, dp.H, dp.W = 1, self.Cin, 0, 8, 8
             dp.Cout, dp.KH, dp.KW, dp.pad, dp.dil = self.Cout, 3, 3, 1, 1
             dp.OH, dp.OW = 8, 8
+            Wsrc, so, sc = self.W, self.so, self.sc
+            if x3:
+                # three k-groups of whole 16-channel k-tiles [W_hi | W_lo | W_hi], to meet the
+                # kernel's [x_lo | x_hi | x_hi]; the split values are bf16 numbers, the pack's
+                # rounding leaves them as they are
+                Cp = (self.Cin + 15) // 16 * 16
+                Wo = self.W if self.layout == 'oihw' else self.W.permute(1, 0, 2, 3)
+                Wp = torch.zeros((self.Cout, Cp, 3, 3), dtype=torch.float32, device=self.W.device)
+                Wp[:, :self.Cin] = Wo
+                Wh = Wp.to(torch.bfloat16).to(torch.float32)
+                Wl = (Wp - Wh).to(torch.bfloat16).to(torch.float32)
+                Wsrc = torch.cat([Wh, Wl, Wh], dim=1).contiguous()
+                dp.C1, so, sc = 3 * Cp, 3 * Cp * 9, 9
             self._W16c8 = torch.empty(lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(dp)) // 2,
                                       dtype=torch.bfloat16, device=self.W.device)
-            check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(self.W), self.so, self.sc,
+            check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(Wsrc), so, sc,
                                                 _ptr(self._W16c8, torch.bfloat16)),
                   'iiseg_conv_halo_bf16_pack')
+            del Wsrc
         dtp = lambda t: None if t is None else _ptr(t, t.dtype)
         flat_pool = pool_out is not None and bool(lib.iiseg_conv_c8_is_flat(C.byref(d)))
         tmp = None
@@ -690,7 +717,7 @@ class Conv:
         if flat_pool:
             pool_mask_c8(tmp, pool_out, mask_out, (oy0, ox0), (fullH, fullW),
                          (oy0 // 2, ox0 // 2, min((oy0 + OH) // 2, fullH // 2) - oy0 // 2,
-                          min((ox0 + OW) // 2, fullW // 2) - ox0 // 2))
+                          min((ox0 + OW) // 2, fullW // 2) - ox0 // 2), x3=x3)
         return out
 
     def _call_halo_bf16(self, d, x1, x2, pre, pooled, add, out, pool_out, mask_in, mask_out, prof,
@@ -855,18 +882,31 @@ def c8_chunks(channels):
     return (int(channels) + 15) // 16 * 2
 
 
-def empty_c8(B, channels, H, W, device, dtype=torch.bfloat16):
-    return torch.empty((B, c8_chunks(channels), H, W, 8), dtype=dtype, device=device)
+def empty_c8(B, channels, H, W, device, dtype=torch.bfloat16, x3=False):
+    """x3: the hi / lo pair of the 'bf16x3' mode, (B, 2 C/8, H, W, 8) (include/iiseg.h,
+    IISEG_CONV_X3)."""
+    return torch.empty((B, c8_chunks(channels) * (2 if x3 else 1), H, W, 8), dtype=dtype, device=device)
 
 
-def nchw_to_c8(x, out=None):
-    """fp32 NCHW -> bf16 C8 (channels padded with zeros to a whole 16-channel group)."""
+def nchw_to_c8(x, out=None, x3=False):
+    """fp32 NCHW -> bf16 C8 (channels padded with zeros to a whole 16-channel group); x3: the
+    hi / lo pair."""
     B, Cc, H, W = x.shape
     if out is None:
-        out = empty_c8(B, Cc, H, W, x.device)
-    check(_lib.load().iiseg_nchw_to_c8(_stream(), _ptr(x), C.c_void_p(out.data_ptr()), B, Cc, H, W,
-                                       out.shape[1]), 'iiseg_nchw_to_c8')
+        out = empty_c8(B, Cc, H, W, x.device, x3=x3)
+    if tuple(out.shape) != (B, c8_chunks(Cc) * (2 if x3 else 1), H, W, 8) or not is_c8(out):
+        raise RuntimeError('nchw_to_c8 target %s' % (tuple(out.shape),))
+    fn = _lib.load().iiseg_nchw_to_c8x3 if x3 else _lib.load().iiseg_nchw_to_c8
+    check(fn(_stream(), _ptr(x), C.c_void_p(out.data_ptr()), B, Cc, H, W, c8_chunks(Cc)),
+          'iiseg_nchw_to_c8')
     return out
+
+
+def c8x3_to_float(t):
+    """hi / lo pair (B, 2 C/8, H, W, 8) -> float32 (B, C/8 * 8, H, W) (torch; tests and debugging)."""
+    B, C2, H, W, _ = t.shape
+    v = t[:, :C2 // 2].to(torch.float32) + t[:, C2 // 2:].to(torch.float32)
+    return v.permute(0, 1, 4, 2, 3).reshape(B, C2 // 2 * 8, H, W)
 
 
 def c8_to_nchw(x8, channels, out=None):
@@ -881,13 +921,20 @@ def c8_to_nchw(x8, channels, out=None):
     return out
 
 
-def pool_mask_c8(pre, pooled, mask, origin, full_hw, window):
+def pool_mask_c8(pre, pooled, mask, origin, full_hw, window, x3=False):
     """2x2 max-pool (+ DePool2D mask bytes, `mask` may be None) of the pooled-coordinate `window`
     (y0, x0, h, w) from the stored piece `pre` (C8 bf16, or C8 fp32: the unrounded conv results)
     whose corner sits at `origin` of the `full_hw` map, into the full-size `pooled` / `mask` tensors."""
     B, C8n, PH, PW, _ = pre.shape
     y0, x0, wh, ww = window
     if wh <= 0 or ww <= 0:
+        return pooled
+    if x3:
+        check(_lib.load().iiseg_pool_mask_c8x3(
+            _stream(), C.c_void_p(pre.data_ptr()), C.c_void_p(pooled.data_ptr()),
+            None if mask is None else C.c_void_p(mask.data_ptr()), B, C8n, PH, PW, int(origin[0]),
+            int(origin[1]), int(full_hw[0]), int(full_hw[1]), int(y0), int(x0), int(wh), int(ww)),
+            'iiseg_pool_mask_c8x3')
         return pooled
     check(_lib.load().iiseg_pool_mask_c8(
         _stream(), C.c_void_p(pre.data_ptr()), 1 if pre.dtype == torch.float32 else 0,

@@ -1,0 +1,326 @@
+"""mma='bf16x3' (IISEG_CONV_X3, csrc/conv_c8_bf16.hip): the fp32-class mode of the 16-bit matrix pipe.
+Activations and weights are bf16 hi / lo pairs (16 significant bits), a layer accumulates
+x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32.  On integer data with at most 16 significant bits every
+step is exact, so results must agree BIT FOR BIT with the float64 oracle: that pins the pair layout,
+the three k-groups, the split of outputs / pooled maps, the pair form of the skip addend and of the
+DePool2D input; real-valued data then gives the error model (1e-5 class, against 4e-3 for one bf16
+operand), and the end-to-end tests hold the mode to the 1e-4 of `north_star` on the damped set."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops(built_lib):
+    from iterative_inference_segm_amd import ops as _ops
+    return _ops
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.float().cpu().numpy() if t.dtype == torch.bfloat16 else t.cpu().numpy()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def from_pair(ops, t, C):
+    """hi / lo pair (B, 2 C8, H, W, 8) -> (B, C, H, W) float64 on the host (hi + lo, exact in fp32)."""
+    torch.cuda.synchronize()
+    return ops.c8x3_to_float(t).cpu().numpy().astype(np.float64)[:, :C]
+
+
+def from_c8f32(t, C):
+    a = host(t).astype(np.float64)
+    B, C8, H, W, _ = a.shape
+    return a.transpose(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)[:, :C]
+
+
+def wide_ints(rng, *shape, small=3, big=1200, p_big=0.15):
+    """Integers most of which are small, some need the lo half (e.g. 257, 1001: 9-11 significant bits)."""
+    a = rng.integers(-small, small + 1, size=shape).astype(np.float64)
+    b = rng.integers(-big, big + 1, size=shape).astype(np.float64)
+    return np.where(rng.random(shape) < p_big, b, a)
+
+
+def small_ints(rng, *shape, lo=-1, hi=2):
+    return rng.integers(lo, hi, size=shape).astype(np.float64)
+
+
+def _masks(pre):
+    pooled = onn.maxpool2(pre)
+    h, w = pooled.shape[2], pooled.shape[3]
+    rep = np.repeat(np.repeat(pooled, 2, 2), 2, 3)
+    eq = (pre[:, :, :2 * h, :2 * w] == rep)
+    bits = (eq[:, :, 0::2, 0::2] * 1 + eq[:, :, 0::2, 1::2] * 2 + eq[:, :, 1::2, 0::2] * 4 +
+            eq[:, :, 1::2, 1::2] * 8)
+    return pooled, bits.astype(np.uint8)
+
+
+def mask_from_c8(m):
+    a = host(m)
+    B, C8, H, W, _ = a.shape
+    return a.transpose(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)
+
+
+def test_pair_converter_is_exact_on_16_bit_values(ops):
+    rng = np.random.default_rng(0)
+    x = rng.integers(-40000, 40001, size=(3, 11, 9, 13)).astype(np.float64)
+    x8 = ops.nchw_to_c8(dev(x), x3=True)
+    assert tuple(x8.shape) == (3, 4, 9, 13, 8) and ops.is_c8(x8)
+    full = from_pair(ops, x8, 16)
+    assert np.array_equal(full[:, :11], x) and not full[:, 11:].any()
+    hi = host(x8[:, :2]).astype(np.float64)
+    assert np.abs(hi).max() > 256 and not np.array_equal(hi.transpose(0, 1, 4, 2, 3).reshape(3, 16, 9, 13)[:, :11], x)
+    # real values: 16 significant bits
+    v = rng.standard_normal((2, 16, 8, 8))
+    got = from_pair(ops, ops.nchw_to_c8(dev(v), x3=True), 16)
+    assert np.abs(got - v.astype(np.float32)).max() <= 2.0 ** -16 * np.abs(v).max()
+
+
+CASES = [  # B, Cin, H, W, Cout, pad, relu, window
+    (2, 16, 20, 45, 64, 1, True, None),            # RECT, ragged tiles, one k-tile per group
+    (1, 48, 9, 70, 72, 1, False, None),            # channel tails, three column tiles
+    (2, 32, 12, 12, 64, 5, True, None),            # wide zero padding
+    (3, 64, 40, 40, 128, 1, True, (6, 10, 21, 27)),  # window of a larger map
+    (5, 32, 13, 13, 64, 1, True, None),            # FLAT: tiles run across images
+    (7, 64, 22, 22, 96, 1, False, (5, 6, 10, 10)),   # FLAT window
+    (2, 11, 17, 19, 64, 1, True, None),            # 11 input channels (the DAE's first layer)
+    (2, 64, 70, 40, 64, 1, True, None),            # tall tiles where the launch is large enough
+]
+
+
+@pytest.mark.parametrize('split', ['activations', 'weights'])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_x3_exact_on_integer_data(ops, case, split):
+    """Either the activations or the weights need their lo halves (the x_lo W_lo term is the one the
+    mode drops); outputs are read back as fp32 chunks and as pairs."""
+    B, Cin, H, W, Cout, pad, relu, window = case
+    rng = np.random.default_rng(sum(case[:6]))
+    if split == 'activations':
+        x, Wt = wide_ints(rng, B, Cin, H, W), small_ints(rng, Cout, Cin, 3, 3)
+    else:
+        x, Wt = small_ints(rng, B, Cin, H, W, lo=-2, hi=3), wide_ints(rng, Cout, Cin, 3, 3, small=1, big=700)
+    b = small_ints(rng, Cout, lo=-3, hi=4)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, mma='bf16x3')
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+    x8 = ops.nchw_to_c8(dev(x), x3=True)
+    kw = dict(window=window) if window is not None else {}
+    if window is not None:
+        y0, x0, h, w = window
+        ref = ref[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.abs(ref).max() < 2 ** 24
+    got32 = conv(x8, out_format='c8f32', **kw)
+    assert np.array_equal(from_c8f32(got32, Cout), ref)
+    got = conv(x8, **kw)
+    assert ops.is_c8(got) and got.shape[1] == 2 * ops.c8_chunks(Cout)
+    full = from_pair(ops, got, got.shape[1] * 4)
+    # the pair holds 16 significant bits: exact where the value has no more than that
+    ok16 = np.abs(ref) < 2 ** 16
+    assert ok16.mean() > 0.9
+    assert np.array_equal(full[:, :Cout][ok16], ref[ok16])
+    assert np.abs(full[:, :Cout] - ref).max() <= 2.0 ** -16 * np.abs(ref).max()
+    assert not full[:, Cout:].any()
+
+
+def test_conv_x3_drops_only_the_lo_lo_term(ops):
+    """Both operands with lo halves: the result is conv(x_hi, W_hi) + conv(x_lo, W_hi) + conv(x_hi, W_lo)
+    exactly (oracle on the split operands)."""
+    rng = np.random.default_rng(3)
+    B, Cin, H, W, Cout = 2, 32, 14, 37, 64
+    x, Wt = wide_ints(rng, B, Cin, H, W, big=600), wide_ints(rng, Cout, Cin, 3, 3, small=1, big=300)
+    bf = lambda a: torch.from_numpy(a).to(torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    xh, Wh = bf(x), bf(Wt)
+    xl, Wl = x - xh, Wt - Wh
+    assert np.abs(xl).max() > 0 and np.abs(Wl).max() > 0 and np.array_equal(bf(xl), xl) and np.array_equal(bf(Wl), Wl)
+    ref = onn.conv2d(x, Wt, None, pad=1) - onn.conv2d(xl, Wl, None, pad=1)
+    conv = ops.Conv(Wt, None, pad=1, relu=False, mma='bf16x3')
+    got = from_c8f32(conv(ops.nchw_to_c8(dev(x), x3=True), out_format='c8f32'), Cout)
+    assert np.abs(ref).max() < 2 ** 24
+    assert np.array_equal(got, ref)
+
+
+def test_conv_x3_skip_add_placement_and_score_layer(ops):
+    rng = np.random.default_rng(5)
+    B, Cin, Cout, H, W = 2, 32, 64, 30, 41
+    x = wide_ints(rng, B, Cin, H, W, big=400)
+    Wt, b = small_ints(rng, Cout, Cin, 3, 3), small_ints(rng, Cout, lo=-3, hi=4)
+    conv = ops.Conv(Wt, b, pad=1, relu=False, mma='bf16x3')
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=False)
+    x8 = ops.nchw_to_c8(dev(x), x3=True)
+    for add_fmt in ('pair', 'c8f32'):
+        skip = wide_ints(rng, B, Cout, H + 4, W + 6, big=5000)
+        s8 = ops.nchw_to_c8(dev(skip), x3=(add_fmt == 'pair'))
+        if add_fmt == 'c8f32':
+            s8 = ops.nchw_to_c8(dev(skip), x3=True)
+            s8 = (s8[:, :s8.shape[1] // 2].float() + s8[:, s8.shape[1] // 2:].float()).contiguous()
+        y0, x0, h, w = 4, 8, 19, 30
+        out = torch.zeros((B, 2 * ops.c8_chunks(Cout), H, W, 8), dtype=torch.bfloat16, device='cuda')
+        out[:, :ops.c8_chunks(Cout)] = 7.0
+        conv(x8, add=s8, add_off=(2 + y0, 3 + x0), window=(y0, x0, h, w), out=out, place=(y0, x0))
+        got = from_pair(ops, out, Cout)
+        want = np.full_like(ref, 7.0)
+        want[:, :, y0:y0 + h, x0:x0 + w] = (ref + skip[:, :, 2:2 + H, 3:3 + W])[:, :, y0:y0 + h, x0:x0 + w]
+        assert np.abs(want).max() < 2 ** 16
+        assert np.array_equal(got, want), add_fmt
+    # class-score layer: NCHW fp32 output
+    Ws, bs = small_ints(rng, 11, Cin, 3, 3), small_ints(rng, 11)
+    score = ops.Conv(Ws, bs, pad=1, relu=False, mma='bf16x3')
+    got = score(x8, window=(3, 5, 16, 30))
+    assert got.dtype == torch.float32 and tuple(got.shape) == (B, 11, 16, 30)
+    assert np.array_equal(host(got), onn.conv2d(x, Ws, bs, pad=1)[:, :, 3:19, 5:35].astype(np.float32))
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 38, 45, 64), (4, 32, 15, 15, 64)])   # RECT fused / FLAT + pool kernel
+def test_conv_x3_pool_and_mask_bytes(ops, shape):
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(H)
+    x = wide_ints(rng, B, Cin, H, W, big=300)
+    Wt, b = small_ints(rng, Cout, Cin, 3, 3), small_ints(rng, Cout, lo=-3, hi=4)
+    conv = ops.Conv(Wt, b, pad=1, relu=True, mma='bf16x3')
+    pre = onn.conv2d(x, Wt, b, pad=1, relu=True)
+    assert np.abs(pre).max() < 2 ** 16
+    pooled, bits = _masks(pre)
+    p8 = ops.empty_c8(B, Cout, H // 2, W // 2, 'cuda', x3=True)
+    m8 = torch.zeros((B, ops.c8_chunks(Cout), H // 2, W // 2, 8), dtype=torch.uint8, device='cuda')
+    assert conv(ops.nchw_to_c8(dev(x), x3=True), pool_out=p8, mask_out=m8, store_out=False) is None
+    assert np.array_equal(from_pair(ops, p8, Cout), pooled)
+    assert np.array_equal(mask_from_c8(m8)[:, :Cout], bits)
+    # a window of whole pooling windows leaves the rest untouched
+    p8.zero_(); m8.fill_(255)
+    win = conv.pool_window(H, W, (5, 9, 7, 12))
+    conv(ops.nchw_to_c8(dev(x), x3=True), pool_out=p8, mask_out=m8, store_out=False, window=win)
+    y0, x0, h, w = win[0] // 2, win[1] // 2, win[2] // 2, win[3] // 2
+    want_p = np.zeros_like(pooled); want_m = np.full_like(bits, 255)
+    want_p[:, :, y0:y0 + h, x0:x0 + w] = pooled[:, :, y0:y0 + h, x0:x0 + w]
+    want_m[:, :, y0:y0 + h, x0:x0 + w] = bits[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.array_equal(from_pair(ops, p8, Cout), want_p)
+    assert np.array_equal(mask_from_c8(m8)[:, :Cout], want_m)
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 37, 44, 64), (6, 64, 13, 13, 32), (2, 128, 33, 33, 11)])
+def test_conv_x3_depool_input_from_mask_bytes(ops, shape):
+    """DePool2D (layers/mylayers.py:88-115) as the input staging: `up` pair + mask bytes."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(W)
+    pre = small_ints(rng, B, Cin, H, W, lo=0, hi=3)          # many ties
+    pooled, bits = _masks(pre)
+    up = wide_ints(rng, B, Cin, H // 2, W // 2, big=500)
+    unp = onn.depool_eqmask(up, pre, pooled)
+    Wt, b = small_ints(rng, Cout, Cin, 3, 3), small_ints(rng, Cout, lo=-3, hi=4)
+    conv = ops.Conv(Wt, b, pad=1, relu=False, mma='bf16x3')
+    ref = onn.conv2d(unp, Wt, b, pad=1, relu=False)
+    m = np.zeros((B, ops.c8_chunks(Cin), H // 2, W // 2, 8), dtype=np.uint8)
+    m[:] = bits.reshape(B, Cin // 8, 8, H // 2, W // 2).transpose(0, 1, 3, 4, 2)
+    mt = torch.from_numpy(m).cuda()
+    up8 = ops.nchw_to_c8(dev(up), x3=True)
+    nchw = Cout % 8 != 0
+    rd = (lambda t: host(t).astype(np.float64)) if nchw else (lambda t: from_c8f32(t, Cout))
+    kw = {} if nchw else dict(out_format='c8f32')
+    assert np.array_equal(rd(conv(up8, mask_in=mt, unpool_hw=(H, W), **kw)), ref)
+    assert np.array_equal(rd(conv(up8, mask_in=mt, unpool_hw=(H, W), window=(3, 2, 9, 10), **kw)),
+                          ref[:, :, 3:12, 2:12])
+
+
+def test_conv_x3_error_model_at_layer_size(ops):
+    """Real-valued data at a configs[1] layer size, against the float64 oracle: the split mode next to
+    the fp32 MFMA path and the one-operand-rounding bf16 C8 mode."""
+    rng = np.random.default_rng(9)
+    B, Cin, H, W, Cout = 4, 128, 60, 60, 128
+    x = rng.standard_normal((B, Cin, H, W))
+    Wt = rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))
+    b = 0.1 * rng.standard_normal(Cout)
+    ref = onn.conv2d(x, Wt, b, pad=1, relu=True)
+    rms = np.sqrt((ref ** 2).mean())
+    c3 = ops.Conv(Wt, b, pad=1, relu=True, mma='bf16x3')
+    got3 = from_pair(ops, c3(ops.nchw_to_c8(dev(x), x3=True)), Cout)
+    got32 = host(ops.Conv(Wt, b, pad=1, relu=True)(dev(x))).astype(np.float64)
+    c8 = ops.Conv(Wt, b, pad=1, relu=True, mma='bf16c8')
+    a = host(c8(ops.nchw_to_c8(dev(x)))).astype(np.float64)
+    got8 = a.transpose(0, 1, 4, 2, 3).reshape(B, -1, H, W)[:, :Cout]
+    e3, e32, e8 = (float(np.sqrt(((g - ref) ** 2).mean()) / rms) for g in (got3, got32, got8))
+    m3 = float(np.abs(got3 - ref).max() / np.abs(ref).max())
+    print('128 -> 128 at 60x60, relative RMS error vs float64: bf16x3 %.2e (max %.2e), fp32 MFMA %.2e, '
+          'bf16 C8 %.2e' % (e3, m3, e32, e8))
+    assert e3 <= 1e-5 and m3 <= 2e-5 and e3 <= e8 / 100
+
+
+def _damped_engine(dtype, mma=None):
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, dp, temp = S.make_damped_set()
+    return IterativeInference(
+        FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], temperature=temp, dtype=dtype, mma=mma),
+        StandardDAE(dp, 11, dtype=dtype, mma=mma), 11, [11], dtype=dtype)
+
+
+def test_x3_engine_free_running_fixed_tolerance(built_lib):
+    """configs[1] on the damped set (tests/test_gpu_damped.py), 2 images, 10 steps of 0.1, early stop
+    off, the product path (`refine()`, own masks, HIP-graph replay): the FCN-8 runs its fp32 MFMA
+    kernels, the DAE loop runs on hi / lo pairs.  Same criterion as the fp32 path's (B): pixels within
+    the 1e-4 of north_star, mean error, argmax agreement with the float64 path -- and next to the fp32
+    path's own numbers on the same images."""
+    from iterative_inference_segm_amd import synthetic as S
+    TOL = 1e-4
+    X = S.make_images(2, 224, 224, seed=1234)
+    res = {}
+    for k, (dt, mma) in {'f64': (torch.float64, None), 'f32': (torch.float32, None),
+                         'x3': (torch.float32, 'bf16x3')}.items():
+        ii = _damped_engine(dt, mma)
+        out = ii.pred_fcn_fn(X)
+        r1 = ii.pred_dae_fn(*out)
+        res[k] = (r1.double(), ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)[0].double())
+        del ii
+        torch.cuda.empty_cache()
+    stats = {}
+    for k in ('f32', 'x3'):
+        e1 = (res[k][0] - res['f64'][0]).abs()
+        e = (res[k][1] - res['f64'][1]).abs()
+        frac = float((e.amax(1) <= TOL).double().mean())
+        agree = float((res[k][1].argmax(1) == res['f64'][1].argmax(1)).double().mean())
+        stats[k] = (float(e1.max()), float(e1.mean()), frac, float(e.max()), float(e.mean()), agree)
+        print('%s vs float64: one reconstruction max %.2e mean %.2e; after 10 steps pixels within 1e-4 '
+              '%.5f, max %.2e, mean %.2e, argmax agreement %.6f' % ((k,) + stats[k]))
+    r1max, r1mean, frac, emax, emean, agree = stats['x3']
+    assert frac >= 0.999 and emean <= 1e-5 and agree >= 0.9999
+
+
+def test_x3_engine_work_eliminations_are_bit_identical(built_lib):
+    """The exact work eliminations (decoder windows, loop-invariant encoder maps, weights-only border
+    stores across batches, HIP-graph replay) under mma='bf16x3', against the same engine recomputing
+    every layer in full for every step, eagerly -- bit for bit, three batches (as
+    tests/test_gpu_c8.py does for the one-operand mode: same kernel, same fixed-order sums)."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+
+    def small():
+        fp = S.make_fcn8_params(width_div=4, fc_channels=1024, seed=481)
+        dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=16, seed=482,
+                               out_gain=0.25, dec_gain=0.35)
+        return IterativeInference(
+            FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], mma='bf16x3'),
+            StandardDAE(dp, 11, n_filters=16, mma='bf16x3'), 11, [11])
+    ii_a, ii_b = small(), small()
+    assert ii_a.dae.x3 and ii_a.dae.c8
+    ii_b.dae.dce = ii_b.dae.licm = ii_b.dae.fold_border = False
+    ii_b.fcn.fold_border = False
+    B, H, W = 3, 64, 80
+    ii_a.prepare(B, H, W)
+    for i in range(3):
+        X = S.make_images(B, H, W, seed=490 + i)
+        oa, ob = ii_a.pred_fcn_fn(X), ii_b.pred_fcn_fn(X)
+        for a, b in zip(oa, ob):
+            assert np.array_equal(host(a), host(b)), 'FCN-8 output differs, batch %d' % i
+        ra = ii_a.refine(oa[:-1], oa[-1], 0.2, 5, eps=1e-4, graph=True, first_reconstruction=True)
+        rb = ii_b.refine(ob[:-1], ob[-1], 0.2, 5, eps=1e-4, graph=False, first_reconstruction=True)
+        for a, b in zip(ra, rb):
+            assert np.array_equal(host(a), host(b)), 'refined result differs, batch %d' % i
