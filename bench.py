@@ -57,14 +57,18 @@ PEAK_TFLOPS_F64_MFMA = 78.6      # v_mfma_f64_16x16x4_f64: half the fp32 matrix 
 PEAK_TFLOPS_BF16_MFMA = 2500.0   # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 / fp16 (no sparsity)
 
 
-def build_model(device, concat_h, dtype=torch.float32, mma=None):
+def build_model(device, concat_h, dtype=torch.float32, mma=None, fcn_mma='same'):
+    # (mma='bf16x3': the DAE loop on hi / lo pairs, the FCN-8 -- once per batch -- on its fp32 kernels:
+    # tests/test_gpu_x3.py::test_x3_engine_free_running_fixed_tolerance)
+    if fcn_mma == 'same':
+        fcn_mma = None if mma == 'bf16x3' else mma
     from iterative_inference_segm_amd.api import IterativeInference
     from iterative_inference_segm_amd.dae import StandardDAE
     from iterative_inference_segm_amd.fcn8 import FCN8
     fp = S.make_fcn8_params(seed=1234)      # same seed on every rank: replicated weights
     dp = S.make_dae_params(seed=4321)
     fcn = FCN8(fp, N_CLASSES, layer=concat_h + ['probs_dimshuffle'], device=device, dtype=dtype,
-               mma=mma)
+               mma=fcn_mma)
     dae = StandardDAE(dp, N_CLASSES, concat_h=concat_h, padding=100, n_filters=64,
                       additional_pool=2, skip=True, unpool_type='trackind', device=device,
                       dtype=dtype, mma=mma)

@@ -293,10 +293,11 @@ int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int 
 int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled, uint8_t* mask,
                        int BC8, int PH, int PW, int py0, int px0, int H, int W, int y0, int x0, int wh,
                        int ww);
-/* The two helpers of the IISEG_CONV_X3 mode: fp32 NCHW -> hi / lo pair (B, 2 C8n, H, W, 8), and the
+/* The helpers of the IISEG_CONV_X3 mode: fp32 NCHW <-> hi / lo pair (B, 2 C8n, H, W, 8), and the
  * pool of a C8 fp32 piece `pre` (B, C8n, PH, PW, 8) into a pooled hi / lo pair (B, 2 C8n, H/2, W/2, 8)
  * + the (B, C8n, H/2, W/2, 8) mask bytes (same comparisons as iiseg_pool_mask_c8 with pre_f32). */
 int iiseg_nchw_to_c8x3(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
+int iiseg_c8x3_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8n);
 int iiseg_pool_mask_c8x3(void* stream, const void* pre, void* pooled, uint8_t* mask, int B, int C8n,
                          int PH, int PW, int py0, int px0, int H, int W, int y0, int x0, int wh,
                          int ww);
@@ -385,6 +386,11 @@ int iiseg_refine_update_c8_f32(void* stream, const float* score, float* y, const
                                double* partial, void* y8, int32_t C8n, int32_t B, int32_t C,
                                int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W,
                                float step);
+/* ... as the hi / lo pair (B, 2 C8n, H, W, 8) of the IISEG_CONV_X3 mode */
+int iiseg_refine_update_c8x3_f32(void* stream, const float* score, float* y, const int32_t* active,
+                                 double* partial, void* y8, int32_t C8n, int32_t B, int32_t C,
+                                 int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
+                                 int32_t W, float step);
 int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, int32_t* iters,
                           double* last_norm, int32_t B, int32_t nblk, int32_t HW, double eps);
 

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 24
+ABI_VERSION = 26
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -83,6 +83,7 @@ SIGNATURES = {
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8': (C.c_int, [_vp, _vp, _i32, _vp, _vp] + [_i32] * 11),
     'iiseg_nchw_to_c8x3': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
+    'iiseg_c8x3_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8x3': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 12),
     'iiseg_conv_gemm_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
@@ -98,6 +99,7 @@ SIGNATURES = {
     'iiseg_refine_partials': (C.c_int, [_i32, _i32]),
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
     'iiseg_refine_update_c8_f32': (C.c_int, [_vp] * 6 + [_i32] * 9 + [_f32]),
+    'iiseg_refine_update_c8x3_f32': (C.c_int, [_vp] * 6 + [_i32] * 9 + [_f32]),
     'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
     'iiseg_confusion_masked_f32': (C.c_int, [_vp] * 6 + [_i32] * 3),

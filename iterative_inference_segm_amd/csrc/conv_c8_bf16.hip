@@ -601,7 +601,9 @@ __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict
     }
 }
 
-// C8 (B, C8n, H, W, 8) bf16 -> (B, C, H, W) fp32 (first C channels)
+// C8 (B, C8n, H, W, 8) bf16 -> (B, C, H, W) fp32 (first C channels); X3: from the hi / lo pair
+// (B, 2 C8n, H, W, 8), value = hi + lo (exact in fp32)
+template <bool X3>
 __global__ __launch_bounds__(256) void c8_to_nchw_kernel(const uint4* __restrict__ x, float* __restrict__ out,
                                                          int C, int HW, int C8n, int64_t total) {
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
@@ -609,9 +611,14 @@ __global__ __launch_bounds__(256) void c8_to_nchw_kernel(const uint4* __restrict
         const int64_t r = t / HW;
         const int c8 = (int)(r % C8n);
         const int64_t b = r / C8n;
-        const uint4 u = x[t];
-        const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y),
-                            bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+        const uint4 u = x[X3 ? ((b * 2 * C8n + c8) * HW + pix) : t];
+        float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y),
+                      bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+        if constexpr (X3) {
+            const uint4 w = x[(b * 2 * C8n + C8n + c8) * HW + pix];
+            v[0] += bf_lo(w.x); v[1] += bf_hi(w.x); v[2] += bf_lo(w.y); v[3] += bf_hi(w.y);
+            v[4] += bf_lo(w.z); v[5] += bf_hi(w.z); v[6] += bf_lo(w.w); v[7] += bf_hi(w.w);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c8 * 8 + j;
@@ -917,7 +924,18 @@ extern "C" int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, 
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(c8_to_nchw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(c8_to_nchw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, out, C, H * W, C8n, total);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_c8x3_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W,
+                                  int C8n) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)B * C8n * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(c8_to_nchw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)x, out, C, H * W, C8n, total);
     return iiseg_check_launch();
 }

@@ -56,9 +56,10 @@ class FCN8:
         'bf16' = 16-bit MFMA operands with fp32 accumulation; 'bf16c8' = additionally bf16 C8
         activations between the 3x3 layers, the h maps handed out stay fp32 NCHW; ops.Conv)."""
         mma = mma or ops.DEFAULT_MMA
-        if mma == 'bf16x3':
-            mma = 'f32'            # the split-operand mode is the DAE loop's; this net runs once per batch
-        self.c8 = mma == 'bf16c8' and dtype == torch.float32
+        # ('bf16x3': the same C8 plan on hi / lo pairs -- the 3x3 layers' fp32-class mode; fc6 / fc7 and
+        # the 1x1 score layers then run their fp32 kernels)
+        self.c8 = mma in ('bf16c8', 'bf16x3') and dtype == torch.float32
+        self.x3 = self.c8 and mma == 'bf16x3'
         self.layer = list(layer)
         self.n_classes = n_classes
         self.pad = pad
@@ -119,7 +120,7 @@ class FCN8:
         t = x
         c8 = self.c8 and not hs
         if c8:
-            t = ops.nchw_to_c8(x)                  # bf16 C8 from here to pool5 (conv_c8_bf16.hip)
+            t = ops.nchw_to_c8(x, x3=self.x3)      # bf16 C8 from here to pool5 (conv_c8_bf16.hip)
         dep = (0, 0, x.shape[2], x.shape[3])       # region of `t` that depends on x
         deps = {}
         pending = hs.get('input')
@@ -141,7 +142,8 @@ class FCN8:
                             fused_pool = session['pool%d' % (bi + 1)]
                             kw.update(window=pw_, place=(pw_[0], pw_[1]))
                         elif c8:
-                            fused_pool = ops.empty_c8(t.shape[0], conv.Cout, fh // 2, fw // 2, t.device)
+                            fused_pool = ops.empty_c8(t.shape[0], conv.Cout, fh // 2, fw // 2, t.device,
+                                                      x3=self.x3)
                         else:
                             fused_pool = torch.empty((t.shape[0], conv.Cout, fh // 2, fw // 2),
                                                      dtype=t.dtype, device=t.device)
@@ -177,11 +179,11 @@ class FCN8:
             session['primed'] = True
         if c8:
             # the h maps of the API, the 1x1 score layers and fc6 take fp32 NCHW
-            f32 = {k: ops.c8_to_nchw(v, self.convs[_BLOCKS[int(k[-1]) - 1][-1]].Cout)
+            f32 = {k: ops.c8_to_nchw(v, self.convs[_BLOCKS[int(k[-1]) - 1][-1]].Cout, x3=self.x3)
                    for k, v in net.items() if k.startswith('pool') and
                    (k in self.layer or k in ('pool3', 'pool4'))}
             net.update(f32)
-            t = ops.c8_to_nchw(t, self.convs['conv5_3'].Cout)
+            t = ops.c8_to_nchw(t, self.convs['conv5_3'].Cout, x3=self.x3)
         if pending is not None:          # concat after pool5 feeds fc6 (7x7: table kernel)
             t = self._conv('fc6', pending, x2=t)
         else:
@@ -257,7 +259,7 @@ class FCN8DAE:
         self.concat_h = list(concat_h)
         # (the concat points of this kind are two-source gathers: fp32 NCHW activations)
         self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype,
-                        mma='bf16' if mma == 'bf16c8' else mma)
+                        mma={'bf16c8': 'bf16', 'bf16x3': 'f32'}.get(mma, mma))
         self.net.fold_border = False       # the border depends on h here: sessions only
         self.licm = os.environ.get('IISEG_ENCODER_LICM', '1') != '0'
 

@@ -909,15 +909,18 @@ def c8x3_to_float(t):
     return v.permute(0, 1, 4, 2, 3).reshape(B, C2 // 2 * 8, H, W)
 
 
-def c8_to_nchw(x8, channels, out=None):
-    """bf16 C8 -> fp32 NCHW (first `channels` channels)."""
-    if not is_c8(x8) or not x8.is_contiguous():
+def c8_to_nchw(x8, channels, out=None, x3=False):
+    """bf16 C8 -> fp32 NCHW (first `channels` channels); x3: from the hi / lo pair."""
+    if not is_c8(x8) or not x8.is_contiguous() or (x3 and x8.shape[1] % 2):
         raise RuntimeError('c8_to_nchw needs a contiguous C8 tensor')
     B, C8n, H, W, _ = x8.shape
+    if x3:
+        C8n //= 2
     if out is None:
         out = torch.empty((B, int(channels), H, W), dtype=torch.float32, device=x8.device)
-    check(_lib.load().iiseg_c8_to_nchw(_stream(), C.c_void_p(x8.data_ptr()), _ptr(out), B,
-                                       int(channels), H, W, C8n), 'iiseg_c8_to_nchw')
+    fn = _lib.load().iiseg_c8x3_to_nchw if x3 else _lib.load().iiseg_c8_to_nchw
+    check(fn(_stream(), C.c_void_p(x8.data_ptr()), _ptr(out), B, int(channels), H, W, C8n),
+          'iiseg_c8_to_nchw')
     return out
 
 
@@ -1015,22 +1018,24 @@ class RefineState:
         self.last_norm.zero_()
 
 
-def refine_update(score, y, state, step, off=None, y8=None):
+def refine_update(score, y, state, step, off=None, y8=None, x3=False):
     """One fused refinement step on y (in place) from the DAE's pre-softmax score map.  `y8`: a
     bf16 C8 tensor (B, chunks, H, W, 8) that also receives the updated map (the DAE's input format
-    under mma='bf16c8'; float32 only)."""
+    under mma='bf16c8'; float32 only; x3: the hi / lo pair of mma='bf16x3')."""
     B, Cc, SH, SW = score.shape
     H, W = y.shape[2], y.shape[3]
     sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
     dt = y.dtype
     if y8 is not None:
+        # (x3: y8 is the hi / lo pair of mma='bf16x3', twice the chunks)
+        n8 = y8.shape[1] // 2 if x3 else y8.shape[1]
         if dt != torch.float32 or not is_c8(y8) or tuple(y8.shape) != (B, y8.shape[1], H, W, 8) or \
-                y8.shape[1] * 8 < Cc:
+                n8 * 8 < Cc:
             raise RuntimeError('y8: bf16 C8 tensor of y\'s geometry')
-        check(_lib.load().iiseg_refine_update_c8_f32(
-            _stream(), _ptr(score), _ptr(y), _ptr(state.active, torch.int32),
-            _ptr(state.partial, torch.float64), C.c_void_p(y8.data_ptr()), y8.shape[1], B, Cc, SH, SW,
-            sy0, sx0, H, W, float(step)), 'iiseg_refine_update_c8_f32')
+        fn = _lib.load().iiseg_refine_update_c8x3_f32 if x3 else _lib.load().iiseg_refine_update_c8_f32
+        check(fn(_stream(), _ptr(score), _ptr(y), _ptr(state.active, torch.int32),
+                 _ptr(state.partial, torch.float64), C.c_void_p(y8.data_ptr()), n8, B, Cc, SH, SW,
+                 sy0, sx0, H, W, float(step)), 'iiseg_refine_update_c8_f32')
         return
     check(_fn('refine_update', dt)(_stream(), _ptr(score, dt), _ptr(y, dt),
                                    _ptr(state.active, torch.int32),

@@ -250,37 +250,41 @@ def test_conv_x3_error_model_at_layer_size(ops):
     assert e3 <= 1e-5 and m3 <= 2e-5 and e3 <= e8 / 100
 
 
-def _damped_engine(dtype, mma=None):
+def _damped_engine(dtype, mma=None, fcn_mma=None):
     from iterative_inference_segm_amd import synthetic as S
     from iterative_inference_segm_amd.api import IterativeInference
     from iterative_inference_segm_amd.dae import StandardDAE
     from iterative_inference_segm_amd.fcn8 import FCN8
     fp, dp, temp = S.make_damped_set()
     return IterativeInference(
-        FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], temperature=temp, dtype=dtype, mma=mma),
+        FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], temperature=temp, dtype=dtype, mma=fcn_mma),
         StandardDAE(dp, 11, dtype=dtype, mma=mma), 11, [11], dtype=dtype)
 
 
 def test_x3_engine_free_running_fixed_tolerance(built_lib):
     """configs[1] on the damped set (tests/test_gpu_damped.py), 2 images, 10 steps of 0.1, early stop
-    off, the product path (`refine()`, own masks, HIP-graph replay): the FCN-8 runs its fp32 MFMA
-    kernels, the DAE loop runs on hi / lo pairs.  Same criterion as the fp32 path's (B): pixels within
-    the 1e-4 of north_star, mean error, argmax agreement with the float64 path -- and next to the fp32
-    path's own numbers on the same images."""
+    off, the product path (`refine()`, own masks, HIP-graph replay).  'x3' is the mode as bench.py runs
+    it: the FCN-8 (once per batch) on its fp32 MFMA kernels, the DAE loop (10 forwards per batch) on
+    hi / lo pairs -- held to the criterion of the fp32 path's (B): >= 0.999 of the pixels within the
+    1e-4 of north_star, mean error <= 1e-5, argmax agreement with the float64 path, next to the fp32
+    path's own numbers on the same images.  'x3all' also runs the FCN-8's 3x3 layers on pairs: its 13
+    layers and the sharpened softmax of this set put 0.7 % of the pixels beyond 1e-4 (>= 0.99
+    asserted) -- which is why the mode keeps the FCN-8 in fp32."""
     from iterative_inference_segm_amd import synthetic as S
     TOL = 1e-4
     X = S.make_images(2, 224, 224, seed=1234)
     res = {}
-    for k, (dt, mma) in {'f64': (torch.float64, None), 'f32': (torch.float32, None),
-                         'x3': (torch.float32, 'bf16x3')}.items():
-        ii = _damped_engine(dt, mma)
+    for k, (dt, mma, fm) in {'f64': (torch.float64, None, None), 'f32': (torch.float32, None, None),
+                             'x3': (torch.float32, 'bf16x3', None),
+                             'x3all': (torch.float32, 'bf16x3', 'bf16x3')}.items():
+        ii = _damped_engine(dt, mma, fm)
         out = ii.pred_fcn_fn(X)
         r1 = ii.pred_dae_fn(*out)
         res[k] = (r1.double(), ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)[0].double())
         del ii
         torch.cuda.empty_cache()
     stats = {}
-    for k in ('f32', 'x3'):
+    for k in ('f32', 'x3', 'x3all'):
         e1 = (res[k][0] - res['f64'][0]).abs()
         e = (res[k][1] - res['f64'][1]).abs()
         frac = float((e.amax(1) <= TOL).double().mean())
@@ -290,6 +294,8 @@ def test_x3_engine_free_running_fixed_tolerance(built_lib):
               '%.5f, max %.2e, mean %.2e, argmax agreement %.6f' % ((k,) + stats[k]))
     r1max, r1mean, frac, emax, emean, agree = stats['x3']
     assert frac >= 0.999 and emean <= 1e-5 and agree >= 0.9999
+    r1max, r1mean, frac, emax, emean, agree = stats['x3all']
+    assert frac >= 0.99 and emean <= 1e-5 and agree >= 0.9999
 
 
 def test_x3_engine_work_eliminations_are_bit_identical(built_lib):
