@@ -386,11 +386,6 @@ int iiseg_refine_update_c8_f32(void* stream, const float* score, float* y, const
                                double* partial, void* y8, int32_t C8n, int32_t B, int32_t C,
                                int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H, int32_t W,
                                float step);
-/* ... as the hi / lo pair (B, 2 C8n, H, W, 8) of the IISEG_CONV_X3 mode */
-int iiseg_refine_update_c8x3_f32(void* stream, const float* score, float* y, const int32_t* active,
-                                 double* partial, void* y8, int32_t C8n, int32_t B, int32_t C,
-                                 int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
-                                 int32_t W, float step);
 int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, int32_t* iters,
                           double* last_norm, int32_t B, int32_t nblk, int32_t HW, double eps);
 

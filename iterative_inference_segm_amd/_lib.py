@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -99,7 +99,6 @@ SIGNATURES = {
     'iiseg_refine_partials': (C.c_int, [_i32, _i32]),
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
     'iiseg_refine_update_c8_f32': (C.c_int, [_vp] * 6 + [_i32] * 9 + [_f32]),
-    'iiseg_refine_update_c8x3_f32': (C.c_int, [_vp] * 6 + [_i32] * 9 + [_f32]),
     'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
     'iiseg_confusion_masked_f32': (C.c_int, [_vp] * 6 + [_i32] * 3),

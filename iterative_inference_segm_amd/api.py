@@ -350,7 +350,7 @@ class IterativeInference:
         new y in the DAE's input format (bf16 C8) into the session's buffer."""
         y8 = self.dae.c8_feed(sess) if hasattr(self.dae, 'c8_feed') else None
         if y8 is not None and y8.shape[0] == y.shape[0] and tuple(y8.shape[2:4]) == tuple(y.shape[2:]):
-            ops.refine_update(score, y, st, step, off=(0, 0), y8=y8, x3=getattr(self.dae, 'x3', False))
+            ops.refine_update(score, y, st, step, off=(0, 0), y8=y8)
             self.dae.c8_fed(sess)
         else:
             ops.refine_update(score, y, st, step, off=(0, 0))

@@ -13,5 +13,5 @@ extern "C" const char* iiseg_strerror(int status) {
     }
 }
 
-extern "C" int iiseg_abi_version(void) { return 26; }
+extern "C" int iiseg_abi_version(void) { return 27; }
 extern "C" const char* iiseg_target_arch(void) { return "gfx950"; }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
                                                             double* __restrict__ partial, int C,
                                                             int SH, int SW, int sy0, int sx0, int H,
                                                             int W, T step, uint4* __restrict__ y8,
-                                                            int C8n, int x3) {
+                                                            int C8n) {
     __shared__ double red[4];
     const int HW = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -105,28 +105,13 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
         nrm = sqrt_t(ss);  // np.linalg.norm(grad, axis=1), :275
         // bf16 C8 copy of the updated map for the next DAE forward (mma='bf16c8': saves the
         // nchw_to_c8 pass per step); chunk j = channels 8 j .. 8 j + 7, zeros beyond C
-        // (x3: the hi / lo pair of mma='bf16x3', (B, 2 C8n, H, W, 8): lo = bf16(y - hi))
         if (y8) {
 #pragma unroll
             for (int j = 0; j < CMAX / 8; ++j)
-                if (j < C8n) {
-                    const uint4 hi =
+                if (j < C8n)
+                    y8[((size_t)b * C8n + j) * HW + pix] =
                         make_uint4(pack_bf16_t(ynew[8 * j], ynew[8 * j + 1]), pack_bf16_t(ynew[8 * j + 2], ynew[8 * j + 3]),
                                    pack_bf16_t(ynew[8 * j + 4], ynew[8 * j + 5]), pack_bf16_t(ynew[8 * j + 6], ynew[8 * j + 7]));
-                    if (x3) {
-                        const size_t o = ((size_t)b * 2 * C8n + j) * HW + pix;
-                        const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w};
-                        unsigned l[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            l[q] = pack_bf16_t(ynew[8 * j + 2 * q] - __builtin_bit_cast(float, h[q] << 16),
-                                               ynew[8 * j + 2 * q + 1] - __builtin_bit_cast(float, h[q] & 0xffff0000u));
-                        y8[o] = hi;
-                        y8[o + (size_t)C8n * HW] = make_uint4(l[0], l[1], l[2], l[3]);
-                    } else {
-                        y8[((size_t)b * C8n + j) * HW + pix] = hi;
-                    }
-                }
         }
     }
     double d = wave_sum((double)nrm);
@@ -246,7 +231,7 @@ int crop_softmax(void* stream, const T* score, const T* minuend, T* out, int32_t
 template <typename T>
 int refine_update(void* stream, const T* score, T* y, const int32_t* active, double* partial,
                   int32_t B, int32_t C, int32_t SH, int32_t SW, int32_t sy0, int32_t sx0, int32_t H,
-                  int32_t W, T step, void* y8 = nullptr, int32_t C8n = 0, int32_t x3 = 0) {
+                  int32_t W, T step, void* y8 = nullptr, int32_t C8n = 0) {
     if (!score || !y || !active || !partial) return IISEG_ERR_NULL;
     if (y8 && (C8n * 8 < C || C8n > 4 || ((uintptr_t)y8 & 15))) return IISEG_ERR_SHAPE;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
@@ -256,11 +241,11 @@ int refine_update(void* stream, const T* score, T* y, const int32_t* active, dou
     if (C <= 16)
         hipLaunchKernelGGL((refine_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step, (uint4*)y8,
-                           C8n, x3);
+                           C8n);
     else
         hipLaunchKernelGGL((refine_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step, (uint4*)y8,
-                           C8n, x3);
+                           C8n);
     return iiseg_check_launch();
 }
 
@@ -352,14 +337,6 @@ extern "C" int iiseg_refine_update_c8_f32(void* stream, const float* score, floa
     if (!y8) return IISEG_ERR_NULL;
     return refine_update<float>(stream, score, y, active, partial, B, C, SH, SW, sy0, sx0, H, W, step,
                                 y8, C8n);
-}
-extern "C" int iiseg_refine_update_c8x3_f32(void* stream, const float* score, float* y,
-                                            const int32_t* active, double* partial, void* y8,
-                                            int32_t C8n, int32_t B, int32_t C, int32_t SH, int32_t SW,
-                                            int32_t sy0, int32_t sx0, int32_t H, int32_t W, float step) {
-    if (!y8) return IISEG_ERR_NULL;
-    return refine_update<float>(stream, score, y, active, partial, B, C, SH, SW, sy0, sx0, H, W, step,
-                                y8, C8n, 1);
 }
 extern "C" int iiseg_refine_update_f64(void* stream, const double* score, double* y,
                                        const int32_t* active, double* partial, int32_t B, int32_t C,

@@ -455,8 +455,8 @@ class StandardDAE:
     def c8_feed(self, session):
         """The C8 buffer a fused refinement update may write the new y into for the NEXT `scores`
         call of this session (ops.refine_update(..., y8=)), or None; `c8_fed(session)` afterwards."""
-        if not self.c8 or not isinstance(session, dict):
-            return None
+        if not self.c8 or self.x3 or not isinstance(session, dict):
+            return None                  # (x3: y is converted to its pair per call, 0.05 ms)
         return session.get('y8')
 
     def c8_fed(self, session):

@@ -55,7 +55,10 @@ class FCN8:
         """mma: matrix-pipe operand precision of the float32 path's convolutions ('f32' default,
         'bf16' = 16-bit MFMA operands with fp32 accumulation; 'bf16c8' = additionally bf16 C8
         activations between the 3x3 layers, the h maps handed out stay fp32 NCHW; ops.Conv)."""
-        mma = mma or ops.DEFAULT_MMA
+        if mma is None:
+            # IISEG_MMA=bf16x3 means "the DAE loop on hi / lo pairs"; this net takes the pair form
+            # only when asked by name (tests/test_gpu_x3.py: the FCN-8 in fp32 keeps the mode's parity)
+            mma = 'f32' if ops.DEFAULT_MMA == 'bf16x3' else ops.DEFAULT_MMA
         # ('bf16x3': the same C8 plan on hi / lo pairs -- the 3x3 layers' fp32-class mode; fc6 / fc7 and
         # the 1x1 score layers then run their fp32 kernels)
         self.c8 = mma in ('bf16c8', 'bf16x3') and dtype == torch.float32

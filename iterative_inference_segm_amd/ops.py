@@ -713,7 +713,8 @@ class Conv:
                                 dtp(self._W16c8), _ptr(self.b), dtp(add), add_kind, dtp(conv_out),
                                 conv_kind, dtp(conv_pool), dtp(conv_mask)), 'iiseg_conv_c8')
         if prof is not None:
-            prof.append(('conv_c8_kernel', self.flops(B, OH, OW), ev0, _ev()))
+            prof.append(('conv_c8_kernel<x3>' if x3 else 'conv_c8_kernel', self.flops(B, OH, OW), ev0,
+                         _ev()))
         if flat_pool:
             pool_mask_c8(tmp, pool_out, mask_out, (oy0, ox0), (fullH, fullW),
                          (oy0 // 2, ox0 // 2, min((oy0 + OH) // 2, fullH // 2) - oy0 // 2,
@@ -1018,24 +1019,22 @@ class RefineState:
         self.last_norm.zero_()
 
 
-def refine_update(score, y, state, step, off=None, y8=None, x3=False):
+def refine_update(score, y, state, step, off=None, y8=None):
     """One fused refinement step on y (in place) from the DAE's pre-softmax score map.  `y8`: a
     bf16 C8 tensor (B, chunks, H, W, 8) that also receives the updated map (the DAE's input format
-    under mma='bf16c8'; float32 only; x3: the hi / lo pair of mma='bf16x3')."""
+    under mma='bf16c8'; float32 only)."""
     B, Cc, SH, SW = score.shape
     H, W = y.shape[2], y.shape[3]
     sy0, sx0 = off if off is not None else ((SH - H) // 2, (SW - W) // 2)
     dt = y.dtype
     if y8 is not None:
-        # (x3: y8 is the hi / lo pair of mma='bf16x3', twice the chunks)
-        n8 = y8.shape[1] // 2 if x3 else y8.shape[1]
         if dt != torch.float32 or not is_c8(y8) or tuple(y8.shape) != (B, y8.shape[1], H, W, 8) or \
-                n8 * 8 < Cc:
+                y8.shape[1] * 8 < Cc:
             raise RuntimeError('y8: bf16 C8 tensor of y\'s geometry')
-        fn = _lib.load().iiseg_refine_update_c8x3_f32 if x3 else _lib.load().iiseg_refine_update_c8_f32
-        check(fn(_stream(), _ptr(score), _ptr(y), _ptr(state.active, torch.int32),
-                 _ptr(state.partial, torch.float64), C.c_void_p(y8.data_ptr()), n8, B, Cc, SH, SW,
-                 sy0, sx0, H, W, float(step)), 'iiseg_refine_update_c8_f32')
+        check(_lib.load().iiseg_refine_update_c8_f32(
+            _stream(), _ptr(score), _ptr(y), _ptr(state.active, torch.int32),
+            _ptr(state.partial, torch.float64), C.c_void_p(y8.data_ptr()), y8.shape[1], B, Cc, SH, SW,
+            sy0, sx0, H, W, float(step)), 'iiseg_refine_update_c8_f32')
         return
     check(_fn('refine_update', dt)(_stream(), _ptr(score, dt), _ptr(y, dt),
                                    _ptr(state.active, torch.int32),

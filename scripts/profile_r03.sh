@@ -4,7 +4,7 @@
 # its own, with --kernel-trace only, and within the per-block counter slots of gfx950
 # (MI355X_MICROARCH.md "rocprofv3 PMC slots": SQ 8, TCC 4 with FETCH_SIZE = 3 and WRITE_SIZE = 2,
 # GRBM 2).  Raw output under gpurun_out/r03/prof (scratch); summaries by scripts/make_profiles.py.
-# Usage: profile_r03.sh [legs...]   legs: f32 bf16c8 f64 pmc_f32 pmc_bf16c8
+# Usage: profile_r03.sh [legs...]   legs: f32 bf16c8 bf16x3 f64 pmc_f32 pmc_bf16c8 pmcsq_<leg>[:batch]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r03/prof
 mkdir -p $O
@@ -31,7 +31,7 @@ rm -f $1/*/*counter_collection.csv
 }
 for leg in $LEGS; do
   case $leg in
-    f32|bf16c8|bf16)
+    f32|bf16c8|bf16|bf16x3)
       timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/$leg --output-format csv -- python3 $R/scripts/run_leg.py $leg 64 3 > $O/$leg.out 2> $O/$leg.err || exit 1 ;;
     f64)
       timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/f64 --output-format csv -- python3 $R/scripts/run_leg.py f64 16 2 > $O/f64.out 2> $O/f64.err || exit 1 ;;
