@@ -60,9 +60,9 @@ const char* iiseg_target_arch(void);
 /* iiseg_conv_c8 only: the split-operand ("bf16x3") fp32-class mode of the 16-bit matrix pipe.  Every
  * bf16 C8 tensor of the call (x1, `up`, add of kind 1, out of kind 1, pool_out) is a hi / lo PAIR in
  * one allocation, (B, 2 C/8, H, W, 8): chunks [0, C/8) of an image = bf16(v), chunks [C/8, 2 C/8) =
- * bf16(v - hi); the packed weights hold three k-groups [W_hi | W_lo | W_hi] (pack a (Cout, 3 C1)
- * filter built that way with iiseg_conv_halo_bf16_pack); the layer accumulates
- * x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32.  d->C1 stays the logical channel count; C2 must be 0. */
+ * bf16(v - hi); the packed weights hold two k-groups [W_hi | W_lo] (pack a (Cout, 2 C1) filter built
+ * that way with iiseg_conv_halo_bf16_pack); the layer accumulates x_lo W_hi + x_hi W_lo + x_hi W_hi
+ * in fp32.  d->C1 stays the logical channel count; C2 must be 0. */
 #define IISEG_CONV_X3 8u
 
 typedef struct iiseg_conv_desc {

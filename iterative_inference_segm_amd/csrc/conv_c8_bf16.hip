@@ -96,11 +96,10 @@ struct C8Params {
 // X3 ("bf16x3", the fp32-class mode of the 16-bit pipe): every activation is a PAIR of C8 tensors in
 // one allocation, (B, 2 C/8, H, W, 8): chunks [0, C/8) of an image hold hi = bf16(v), chunks
 // [C/8, 2 C/8) hold lo = bf16(v - hi) -- 16 significant bits.  The weights are split the same way on
-// the host and packed as THREE k-groups [W_hi | W_lo | W_hi]; the kernel walks 3 C/16 k-tiles whose
-// inputs are [x_lo | x_hi | x_hi]: acc = x_lo W_hi + x_hi W_lo + x_hi W_hi in ONE fp32 accumulation
-// (small terms first; the dropped x_lo W_lo term is 2^-18 relative).  Same loop, same tiles, same
-// epilogue; outputs / skip addends / pooled maps of kind 1 are hi / lo pairs, the DePool2D masks and
-// the pool still come from the fp32 accumulators.
+// the host and packed as two k-groups [W_hi | W_lo]; per 16-channel tile the kernel runs three steps,
+// x_lo W_hi, x_hi W_lo, x_hi W_hi, into ONE fp32 accumulation (the dropped x_lo W_lo term is 2^-18
+// relative).  Same MFMA loop, same tiles, same epilogue; outputs / skip addends / pooled maps of
+// kind 1 are hi / lo pairs, the DePool2D masks and the pool still come from the fp32 accumulators.
 template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3>
 __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     constexpr int TH = 4 * TN, TW = 32;
@@ -234,50 +233,45 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // k-tile KT = channels [16 KT, 16 KT + 16) of the logical (concatenated) input; its source is
-    // tile-uniform (C1 % 16 == 0)
-    // (X3: k-group 0 reads the lo chunks, groups 1 and 2 the hi chunks)
-#define C8_KS(KT)                                                                                  \
-    const int ks = !X3 ? (KT) : ((KT) < kt1 ? (KT) : ((KT) < 2 * kt1 ? (KT) - kt1 : (KT) - 2 * kt1)); \
-    const int kc = 2 * ks + ((X3 && (KT) < kt1) ? CCh : 0);
-#define C8_SRC(KT)                                                                                 \
-    C8_KS(KT)                                                                                      \
-    const bool s1 = X3 || UNPOOL || kc < CC1;                                                      \
-    const unsigned so = (unsigned)((kc - (s1 ? 0 : CC1)) * plane) * 16u;
-    // patch of k-tile KT by LDS-DMA: lane -> one chunk, a wave's 64 chunks land contiguously
-#define C8_DMA_X(KT, BUF)                                                                          \
+    // A staging step moves the 16 channels that start at chunk KC of the source (tile-uniform: C1 % 16
+    // == 0; chunks >= CC1 are the second source of a concat) and the packed weight k-tile WT.
+#define C8_SRC(KC)                                                                                 \
+    const bool s1 = X3 || UNPOOL || (KC) < CC1;                                                    \
+    const unsigned so = (unsigned)(((KC) - (s1 ? 0 : CC1)) * plane) * 16u;
+    // patch by LDS-DMA: lane -> one chunk, a wave's 64 chunks land contiguously
+#define C8_DMA_X(KC, BUF)                                                                          \
     {                                                                                              \
-        C8_SRC(KT)                                                                                 \
+        C8_SRC(KC)                                                                                 \
         const unsigned so_u = __builtin_amdgcn_readfirstlane(so);                                  \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             dma16(s1 ? s_x1 : s_x2, lds_p + (unsigned)((BUF) * NCHK + i * 256) * 16u, voff[i], so_u); \
         });                                                                                        \
     }
-    // weights of k-tile KT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
+    // weights of packed k-tile WT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
     unsigned woff[WPT];
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
         const int f = j * 256 + tid;
         woff[j] = f < WCH ? 16u * (unsigned)((f / BM) * p.Mpad + m0 + f % BM) : OOB;
     }
-#define C8_DMA_W(KT, BUF)                                                                          \
+#define C8_DMA_W(WT, BUF)                                                                          \
     {                                                                                              \
-        const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((KT) * 18 * p.Mpad) * 16u); \
+        const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((WT) * 18 * p.Mpad) * 16u); \
         static_for<0, WPT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
             if ((j + 1) * 256 <= WCH || j * 256 + wave * 64 < WCH)                                 \
                 dma16(s_w, lds_w + (unsigned)((BUF) * WCH + j * 256) * 16u, woff[j], so_w);        \
         });                                                                                        \
     }
-    // UNPOOL: up chunk + mask bytes into registers, selected and written to LDS later
+    // UNPOOL: up chunk (chunk KC of `up`) + mask bytes (chunk KM of the mask) into registers, selected
+    // and written to LDS later
     u32x4 xu[UNPOOL ? NE : 1];
     u32x2 xm[UNPOOL ? NE : 1];
-#define C8_LOAD_U(KT)                                                                              \
+#define C8_LOAD_U(KC, KM)                                                                          \
     {                                                                                              \
-        C8_KS(KT)                                                                                  \
-        const unsigned so = (unsigned)(kc * hw2) * 16u;                                            \
-        const unsigned som = (unsigned)(2 * ks * hw2) * 8u;                                        \
+        const unsigned so = (unsigned)((KC) * hw2) * 16u;                                          \
+        const unsigned som = (unsigned)((KM) * hw2) * 8u;                                          \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(               \
@@ -300,33 +294,59 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         if (i * 256 + tid < 2 * half) Ps[BUF][i * 256 + tid] = v;                                  \
     });
 
-    const int nkt = p.nkt;
+    // The k-loop.  Plain: step kt = k-tile kt, both rings alternate (buffer kt & 1), the step's top
+    // issues k-tile kt + 1 into the other buffers.
+    // X3: channel tile c = steps 3c .. 3c + 2, in the order
+    //     r = 0: x_lo_c (Ps[0]) x W_hi_c (Ws[c & 1])      top: stage x_hi_c -> Ps[1], W_lo_c -> Ws[~c & 1]
+    //     r = 1: x_hi_c (Ps[1]) x W_lo_c (Ws[~c & 1])     top: stage x_lo_{c+1} -> Ps[0]
+    //     r = 2: x_hi_c (Ps[1]) x W_hi_c (Ws[c & 1])      top: stage W_hi_{c+1} -> Ws[~c & 1]
+    // -- x_hi staged for the W_lo product stays in LDS for the W_hi product, W_hi staged for the x_lo
+    // product stays for the x_hi product: two patches and two weight tiles per channel tile instead of
+    // three and three, every buffer written only after the barrier that follows its last read.
+    // Packed weights: k-tiles [0, kt1) = W_hi, [kt1, 2 kt1) = W_lo.
+    const int nsteps = X3 ? 3 * kt1 : p.nkt;
     if constexpr (UNPOOL) {
-        C8_LOAD_U(0)
+        C8_LOAD_U(X3 ? CCh : 0, 0)
         C8_DMA_W(0, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         C8_STORE_U(0)
     } else {
-        C8_DMA_X(0, 0)
+        C8_DMA_X(X3 ? CCh : 0, 0)
         C8_DMA_W(0, 0)
     }
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nkt;
-        // k-tile kt has landed: every wave retires its own DMA pieces (and, UNPOOL, its LDS writes),
-        // then the barrier publishes them -- and tells that every wave is done READING buffer
-        // buf ^ 1 (k-tile kt - 1), which the next k-tile's DMA overwrites from here on
+    int xc = 0, xr = 0;                // X3: channel tile, product of the step
+    for (int kt = 0; kt < nsteps; ++kt) {
+        const int pb = X3 ? (xr ? 1 : 0) : (kt & 1);                          // patch buffer read by this step
+        const int wb = X3 ? (xr == 1 ? ((xc & 1) ^ 1) : (xc & 1)) : (kt & 1);   // weight buffer
+        const bool more = X3 ? xc + 1 < kt1 : kt + 1 < nsteps;
+        // the step's operands have landed: every wave retires its own DMA pieces (and, UNPOOL, its LDS
+        // writes), then the barrier publishes them -- and tells that every wave is done READING what
+        // the previous step read, which the DMA issued from here on may overwrite
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if constexpr (!UNPOOL) {
+        int stored = -1;               // UNPOOL: patch buffer the registers loaded here go to
+        if constexpr (X3) {
+            if (xr == 0) {
+                if constexpr (UNPOOL) { C8_LOAD_U(2 * xc, 2 * xc) stored = 1; } else { C8_DMA_X(2 * xc, 1) }
+                C8_DMA_W(kt1 + xc, (xc & 1) ^ 1)
+            } else if (xr == 1) {
+                if (more) {
+                    if constexpr (UNPOOL) { C8_LOAD_U(CCh + 2 * (xc + 1), 2 * (xc + 1)) stored = 0; }
+                    else { C8_DMA_X(CCh + 2 * (xc + 1), 0) }
+                }
+            } else if (more) {
+                C8_DMA_W(xc + 1, (xc & 1) ^ 1)
+            }
+        } else if constexpr (!UNPOOL) {
             if (more && !(p.debug & 16)) {     // (debug 16: timing experiment, no DMA issued at all)
-                C8_DMA_X(kt + 1, buf ^ 1)
-                C8_DMA_W(kt + 1, buf ^ 1)
+                C8_DMA_X(2 * (kt + 1), pb ^ 1)
+                C8_DMA_W(kt + 1, wb ^ 1)
             }
         } else {
             if (more) {
-                C8_LOAD_U(kt + 1)
-                C8_DMA_W(kt + 1, buf ^ 1)
+                C8_LOAD_U(2 * (kt + 1), 2 * (kt + 1))
+                C8_DMA_W(kt + 1, wb ^ 1)
+                stored = pb ^ 1;
             }
         }
         // operands of tap t+1 are read from LDS while the MFMAs of tap t run (two register sets)
@@ -336,10 +356,10 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
             constexpr int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[set][i] = Ws[buf][(tap * 2 + lh) * BM + i * 32 + l31];
+                a[set][i] = Ws[wb][(tap * 2 + lh) * BM + i * 32 + l31];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bq[set][j] = Ps[buf][lh * half + bpos[j] + ky * PWs + kx];
+                bq[set][j] = Ps[pb][lh * half + bpos[j] + ky * PWs + kx];
         };
         lds_operands(ic<0>{}, ic<0>{});
         static_for<0, 9>([&](auto TAP) __attribute__((always_inline)) {
@@ -360,14 +380,14 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
             __builtin_amdgcn_sched_barrier(0);             // keep that order tap by tap
         });
         if constexpr (UNPOOL) {
-            if (more) {
-                // buffer buf ^ 1 is free since the barrier above (k-tile kt - 1 was read before it)
-                C8_STORE_U(buf ^ 1)
-            }
+            // (the target buffer is not read by this step and was last read before the barrier above)
+            if (stored >= 0) { C8_STORE_U(stored) }
+        }
+        if constexpr (X3) {
+            if (++xr == 3) { xr = 0; ++xc; }
         }
     }
 #undef C8_SRC
-#undef C8_KS
 #undef C8_DMA_X
 #undef C8_DMA_W
 #undef C8_LOAD_U
@@ -757,7 +777,7 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
     if ((octot + 64) * opl * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;   // (x3 pair: 2 x 2 bytes)
     if (((int64_t)d->Cout + 64) * d->AH * d->AW * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const int bm = d->Cout > 32 ? 64 : 32, mpad = (d->Cout + bm - 1) / bm * bm;
-    const int nkt = (d->C1 + d->C2) / 16 * (x3 ? 3 : 1);
+    const int nkt = (d->C1 + d->C2) / 16 * (x3 ? 2 : 1);      // packed weight k-tiles
     if ((int64_t)nkt * 18 * mpad * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     if (plan) {
         // FLAT where a 32-column tiling would leave more than a quarter of its MFMAs on padding and
@@ -876,7 +896,7 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0; p.pad = d->pad;
     p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
     p.x3 = (d->flags & IISEG_CONV_X3) ? 1 : 0;
-    p.nkt = (d->C1 + d->C2) / 16 * (p.x3 ? 3 : 1);
+    p.nkt = (d->C1 + d->C2) / 16 * (p.x3 ? 2 : 1);             // packed weight k-tiles
     const int bm = d->Cout > 32 ? 64 : 32;
     p.Mpad = (d->Cout + bm - 1) / bm * bm;
     // dense C8 output: the Cout channels padded to whole 16-channel groups

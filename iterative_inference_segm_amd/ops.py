@@ -675,17 +675,16 @@ class Conv:
             dp.OH, dp.OW = 8, 8
             Wsrc, so, sc = self.W, self.so, self.sc
             if x3:
-                # three k-groups of whole 16-channel k-tiles [W_hi | W_lo | W_hi], to meet the
-                # kernel's [x_lo | x_hi | x_hi]; the split values are bf16 numbers, the pack's
-                # rounding leaves them as they are
+                # two k-groups of whole 16-channel k-tiles [W_hi | W_lo]; the split values are bf16
+                # numbers, the pack's rounding leaves them as they are
                 Cp = (self.Cin + 15) // 16 * 16
                 Wo = self.W if self.layout == 'oihw' else self.W.permute(1, 0, 2, 3)
                 Wp = torch.zeros((self.Cout, Cp, 3, 3), dtype=torch.float32, device=self.W.device)
                 Wp[:, :self.Cin] = Wo
                 Wh = Wp.to(torch.bfloat16).to(torch.float32)
                 Wl = (Wp - Wh).to(torch.bfloat16).to(torch.float32)
-                Wsrc = torch.cat([Wh, Wl, Wh], dim=1).contiguous()
-                dp.C1, so, sc = 3 * Cp, 3 * Cp * 9, 9
+                Wsrc = torch.cat([Wh, Wl], dim=1).contiguous()
+                dp.C1, so, sc = 2 * Cp, 2 * Cp * 9, 9
             self._W16c8 = torch.empty(lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(dp)) // 2,
                                       dtype=torch.bfloat16, device=self.W.device)
             check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(Wsrc), so, sc,

@@ -59,11 +59,15 @@ def test_extra_dae_dict_key_does_not_reach_the_name_builder(tmp_path):
 
 
 @pytest.mark.gpu
-def test_synthetic_evaluation_end_to_end(built_lib, tmp_path):
+@pytest.mark.parametrize('default_mma', ['f32', 'bf16x3'])
+def test_synthetic_evaluation_end_to_end(built_lib, tmp_path, monkeypatch, default_mma):
     """2 batches of 2 images (64x48), reduced DAE width, 3 steps: summary numbers agree with the
-    float64 oracle run of the same evaluation; files of the reference are written."""
+    float64 oracle run of the same evaluation; files of the reference are written.  Also with
+    IISEG_MMA=bf16x3 (the DAE loop on bf16 hi / lo pairs): same tolerances."""
     import torch
     import iterative_inference as ii
+    from iterative_inference_segm_amd import ops as _ops
+    monkeypatch.setattr(_ops, 'DEFAULT_MMA', default_mma)
     from oracle import dae as odae, fcn8 as ofcn8, metrics as ometrics, refine as orefine
     from iterative_inference_segm_amd import synthetic as S
     from iterative_inference_segm_amd.data_loader import load_data
