@@ -8,7 +8,8 @@
   c2_grad: configs[1] in the true-gradient mode (extension): forward + hand-written backward per step
   fcn8dae: FCN-8 + the 'fcn8'-kind DAE (models/fcn8_dae.py, the default kind of inference()), concat_h =
       [input, pool3, pool4], real widths, 224x224, batch 32, 10 steps (~119 + 10 x ~125 GFLOP per image)
-An optional third argument selects the matrix-operand mode of the fp32 rows: f32 (default) | bf16 | bf16c8.
+An optional third argument selects the matrix-operand mode of the fp32 rows: f32 (default) | bf16 | bf16c8 |
+bf16x3 (the standard DAE's loop on bf16 hi / lo pairs, the segmentation net in fp32).
 Usage: python scripts/bench_configs.py [c3|c2_f64|c4|c5|c5ctx|c2_grad|fcn8dae] [reps] [mma]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,12 +44,13 @@ if which in ('c4', 'c5', 'c5ctx', 'c2_grad', 'fcn8dae'):
         from iterative_inference_segm_amd.contextmod import ContextModDAE
         B, gflop, steps, concat_h = 64, float('nan'), 50, ['input']
         dae = ContextModDAE(S.make_contextmod_params(), 11)
-    net = FCN8(S.make_fcn8_params(), 11, layer=concat_h + ['probs_dimshuffle'], mma=mma)
+    net = FCN8(S.make_fcn8_params(), 11, layer=concat_h + ['probs_dimshuffle'],
+               mma=None if mma == 'bf16x3' else mma)
 elif which == 'c3':
     from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
     B, dt, gflop = 32, torch.float32, 254.6
     net = FCDenseNet(S.make_densenet_params(layer_plan()), 11, layer=['pool4'],
-                     mma='bf16' if mma == 'bf16c8' else mma)
+                     mma={'bf16c8': 'bf16', 'bf16x3': None}.get(mma, mma))
     dae = StandardDAE(S.make_dae_params(h_channels=(464,)), 11, padding=0, mma=mma)
 else:
     from iterative_inference_segm_amd.fcn8 import FCN8
