@@ -34,6 +34,8 @@ typedef enum iiseg_status {
 } iiseg_status;
 
 const char* iiseg_strerror(int status);
+/* the HIP runtime's name for the error behind the last IISEG_ERR_LAUNCH of this library */
+const char* iiseg_last_hip_error(void);
 /* ABI version, bumped on any signature change. */
 int iiseg_abi_version(void);
 /* Name of the GPU architecture the library was compiled for ("gfx950"). */

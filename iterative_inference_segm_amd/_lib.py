@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -40,6 +40,7 @@ _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_d
 # name -> (restype, argtypes); mirrors include/iiseg.h one to one
 SIGNATURES = {
     'iiseg_strerror': (C.c_char_p, [C.c_int]),
+    'iiseg_last_hip_error': (C.c_char_p, []),
     'iiseg_abi_version': (C.c_int, []),
     'iiseg_target_arch': (C.c_char_p, []),
     'iiseg_conv_ktab_entries': (C.c_int, [C.POINTER(ConvDesc)]),
@@ -147,6 +148,10 @@ def load():
         raise RuntimeError(
             'libiiseg_hip.so is missing (%s). Build it with '
             '`python -m iterative_inference_segm_amd.build`; there is no CPU fallback.' % LIB_PATH)
+    # torch first: the library shares torch's HIP runtime (streams and device pointers cross the
+    # boundary).  Loaded before torch it brought up a runtime of its own, whose first launch on a GPU
+    # box said "no ROCm-capable device is detected" (__graft_entry__.build() followed by smoke()).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -162,4 +167,6 @@ def load():
 def check(status, what):
     if status != 0:
         msg = load().iiseg_strerror(status).decode()
+        if status == -4:                       # IISEG_ERR_LAUNCH: say what the HIP runtime said
+            msg += ': ' + load().iiseg_last_hip_error().decode()
         raise RuntimeError('%s failed: %s (iiseg_status %d)' % (what, msg, status))

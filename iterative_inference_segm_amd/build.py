@@ -80,11 +80,15 @@ def build(force=False, verbose=False):
 
     version = _hipcc_version(hipcc)
     keys = {}
+    root = os.path.dirname(HERE)
+    key_flags = [f.replace(root, '.') for f in flags]
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
-        key = keys[src] = _digest([s] + headers, extra=flags + [version])
+        # (the key names the include directories relative to the tree: the same tree under another
+        # root -- the GPU box's scratch copy -- reuses its objects)
+        key = keys[src] = _digest([s] + headers, extra=key_flags + [version])
         if force or _stale(o, key):
             cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:

@@ -13,5 +13,9 @@ extern "C" const char* iiseg_strerror(int status) {
     }
 }
 
-extern "C" int iiseg_abi_version(void) { return 27; }
+extern "C" const char* iiseg_last_hip_error(void) {
+    return hipGetErrorString((hipError_t)iiseg_hip_error_slot());
+}
+
+extern "C" int iiseg_abi_version(void) { return 28; }
 extern "C" const char* iiseg_target_arch(void) { return "gfx950"; }

@@ -3,8 +3,17 @@
 #include <hip/hip_runtime.h>
 #include "iiseg.h"
 
+// The HIP error of the last failed launch of this library (one instance across its translation
+// units); iiseg_last_hip_error() names it.
+inline int& iiseg_hip_error_slot() {
+    static int code = 0;
+    return code;
+}
 static inline int iiseg_check_launch() {
-    return hipGetLastError() == hipSuccess ? IISEG_OK : IISEG_ERR_LAUNCH;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return IISEG_OK;
+    iiseg_hip_error_slot() = (int)e;
+    return IISEG_ERR_LAUNCH;
 }
 
 // 64-wide wavefront reductions (CDNA: wave = 64 lanes)
