@@ -592,6 +592,8 @@ def worker(args):
                                               dx3 / args.steps * 1e3, PEAK_TFLOPS_BF16_MFMA / 3)
             legx3['roofline']['peak_note'] = ('2500 / 3: dense bf16 MFMA peak over the three products '
                                               'of a split-operand term (FLOPs counted once)')
+        if not args.no_two_streams:
+            legx3['concurrent_streams'] = concurrent_leg('bf16x3')
         line['bf16x3'] = legx3
         del iix3
         torch.cuda.empty_cache()

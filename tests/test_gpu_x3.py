@@ -330,3 +330,104 @@ def test_x3_engine_work_eliminations_are_bit_identical(built_lib):
         rb = ii_b.refine(ob[:-1], ob[-1], 0.2, 5, eps=1e-4, graph=False, first_reconstruction=True)
         for a, b in zip(ra, rb):
             assert np.array_equal(host(a), host(b)), 'refined result differs, batch %d' % i
+
+
+def test_conv_x3_random_geometries(ops):
+    """40 seeded random launches of iiseg_conv_c8 with IISEG_CONV_X3 against the oracle, bit for bit on
+    integer data whose lo halves are populated (activations in even cases, weights in odd ones):
+    random channel counts, map sizes 5..70, paddings 1..6, batch 1..9, full maps and random windows
+    with placement into a larger pair tensor, skip-add in both formats, ReLU, DePool2D input, fused /
+    two-pass pool + mask bytes.  All tilings come up."""
+    import ctypes
+    from iterative_inference_segm_amd._lib import ConvDesc, CONV_X3
+    rng = np.random.default_rng(4048)
+    n_flat = 0
+    for case in range(40):
+        B = int(rng.integers(1, 10))
+        Cin = 16 * int(rng.integers(1, 5))
+        Cout = 8 * int(rng.integers(1, 13))
+        H, W = int(rng.integers(5, 71)), int(rng.integers(5, 71))
+        pad = int(rng.choice([1, 1, 1, 2, 6]))
+        relu = bool(rng.integers(0, 2))
+        unpool = case % 4 == 3
+        if unpool:
+            H, W = max(H, 6), max(W, 6)
+        wide_x = case % 2 == 0
+        Wt = small_ints(rng, Cout, Cin, 3, 3) if wide_x else wide_ints(rng, Cout, Cin, 3, 3, small=1, big=300)
+        b = small_ints(rng, Cout, lo=-3, hi=4)
+        conv = ops.Conv(Wt, b, pad=pad, relu=relu, mma='bf16x3')
+        act = (lambda *s: wide_ints(rng, *s, small=2, big=300)) if wide_x else \
+            (lambda *s: small_ints(rng, *s, lo=-2, hi=3))
+        kw = {}
+        if unpool:
+            pre = small_ints(rng, B, Cin, H, W, lo=0, hi=3)
+            pooled, bits = _masks(pre)
+            up = act(B, Cin, H // 2, W // 2)
+            x = onn.depool_eqmask(up, pre, pooled)
+            m = np.zeros((B, ops.c8_chunks(Cin), H // 2, W // 2, 8), dtype=np.uint8)
+            m[:] = bits.reshape(B, Cin // 8, 8, H // 2, W // 2).transpose(0, 1, 3, 4, 2)
+            x8 = ops.nchw_to_c8(dev(up), x3=True)
+            kw.update(mask_in=torch.from_numpy(m).cuda(), unpool_hw=(H, W))
+        else:
+            x = act(B, Cin, H, W)
+            x8 = ops.nchw_to_c8(dev(x), x3=True)
+        ref = onn.conv2d(x, Wt, b, pad=pad, relu=False)
+        fh, fw = ref.shape[2], ref.shape[3]
+        if case % 3 == 1:
+            y0, x0 = int(rng.integers(0, fh // 2 + 1)), int(rng.integers(0, fw // 2 + 1))
+            h, w = int(rng.integers(1, fh - y0 + 1)), int(rng.integers(1, fw - x0 + 1))
+        else:
+            y0, x0, h, w = 0, 0, fh, fw
+        window = (y0, x0, h, w)
+        add = None
+        if case % 5 in (2, 4):
+            add = wide_ints(rng, B, Cout, fh + 3, fw + 2, big=2000)
+            ref = ref + add[:, :, 1:1 + fh, 2:2 + fw]
+            a8 = ops.nchw_to_c8(dev(add), x3=True)
+            if case % 5 == 4:
+                n = a8.shape[1] // 2
+                a8 = (a8[:, :n].float() + a8[:, n:].float()).contiguous()
+            kw.update(add=a8, add_off=(1 + y0, 2 + x0))
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert np.abs(ref).max() < 2 ** 16, (case, np.abs(ref).max())     # exact as a pair
+        if case % 2 == 0:
+            out = torch.zeros((B, 2 * ops.c8_chunks(Cout), fh, fw, 8), dtype=torch.bfloat16, device='cuda')
+            out[:, :ops.c8_chunks(Cout)] = -9.0
+            got8 = conv(x8, window=window, out=out, place=(y0, x0), **kw)
+            want = np.full((B, Cout, fh, fw), -9.0)
+            want[:, :, y0:y0 + h, x0:x0 + w] = ref[:, :, y0:y0 + h, x0:x0 + w]
+        else:
+            got8 = conv(x8, window=window, **kw)
+            want = ref[:, :, y0:y0 + h, x0:x0 + w]
+        got = from_pair(ops, got8, Cout)
+        assert np.array_equal(got, want), (case, B, Cin, Cout, H, W, pad, window, unpool,
+                                           np.abs(got - want).max())
+        d = ConvDesc()
+        d.B, d.C1, d.C2, d.H, d.W = B, Cin, 0, H, W
+        d.Cout, d.KH, d.KW, d.pad, d.dil = Cout, 3, 3, pad, 1
+        d.oy0, d.ox0, d.OH, d.OW = window
+        d.flags = CONV_X3
+        n_flat += int(conv.lib.iiseg_conv_c8_is_flat(ctypes.byref(d)))
+        if add is None and fh >= 4 and fw >= 4:
+            pw = conv.pool_window(H, W, window)
+            if pw is not None and pw[2] >= 2 and pw[3] >= 2:
+                pre_full = np.maximum(onn.conv2d(x, Wt, b, pad=pad, relu=False), 0) if relu else \
+                    onn.conv2d(x, Wt, b, pad=pad, relu=False)
+                pooled, bits = _masks(pre_full)
+                p8 = torch.zeros((B, 2 * ops.c8_chunks(Cout), fh // 2, fw // 2, 8), dtype=torch.bfloat16,
+                                 device='cuda')
+                m8 = torch.zeros((B, ops.c8_chunks(Cout), fh // 2, fw // 2, 8), dtype=torch.uint8,
+                                 device='cuda')
+                conv(x8, window=pw, pool_out=p8, mask_out=m8, store_out=False,
+                     **{k: v for k, v in kw.items() if k in ('mask_in', 'unpool_hw')})
+                qy0, qx0 = pw[0] // 2, pw[1] // 2
+                qh = min((pw[0] + pw[2]) // 2, fh // 2) - qy0
+                qw = min((pw[1] + pw[3]) // 2, fw // 2) - qx0
+                gp, gm = from_pair(ops, p8, Cout), mask_from_c8(m8)[:, :Cout]
+                assert np.array_equal(gp[:, :, qy0:qy0 + qh, qx0:qx0 + qw],
+                                      pooled[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'pool')
+                assert np.array_equal(gm[:, :, qy0:qy0 + qh, qx0:qx0 + qw],
+                                      bits[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'mask')
+    print('random X3 launches: %d of 40 on the flat tiling' % n_flat)
+    assert 5 <= n_flat <= 38
