@@ -337,7 +337,15 @@ def main():
     parser.add_argument('--update', choices=['residual', 'gradient'], default='residual',
                         help="'residual': the reference's y += step*(r - y) (default); 'gradient': "
                              "descend the true gradient of ||r(y|h) - y||^2 (extension)")
+    parser.add_argument('--mma', choices=['f32', 'bf16', 'bf16c8', 'bf16x3'], default=None,
+                        help="matrix-pipe operand mode of the float32 path (same as IISEG_MMA): 'f32' "
+                             "(default, the path with the 1e-4 claims), 'bf16' / 'bf16c8' (16-bit "
+                             "operands, statistical parity), 'bf16x3' (the DAE loop on bf16 hi / lo "
+                             "pairs: fp32-class, DESIGN 3.8)")
     args = parser.parse_args()
+    if args.mma is not None and not args.dry_run:
+        from iterative_inference_segm_amd import ops as _ops
+        _ops.DEFAULT_MMA = args.mma
 
     inference(args.dataset, args.segmentation_net, float(args.step), int(args.num_iter),
               which_set=args.which_set, savepath=args.savepath, loadpath=args.loadpath,
