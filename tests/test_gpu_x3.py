@@ -2,7 +2,7 @@
 Activations and weights are bf16 hi / lo pairs (16 significant bits), a layer accumulates
 x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32.  On integer data with at most 16 significant bits every
 step is exact, so results must agree BIT FOR BIT with the float64 oracle: that pins the pair layout,
-the three k-groups, the split of outputs / pooled maps, the pair form of the skip addend and of the
+the three products of a channel tile, the split of outputs / pooled maps, the pair form of the skip addend and of the
 DePool2D input; real-valued data then gives the error model (1e-5 class, against 4e-3 for one bf16
 operand), and the end-to-end tests hold the mode to the 1e-4 of `north_star` on the damped set."""
 import numpy as np
