@@ -298,6 +298,11 @@ int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled,
 /* The helpers of the IISEG_CONV_X3 mode: fp32 NCHW <-> hi / lo pair (B, 2 C8n, H, W, 8), and the
  * pool of a C8 fp32 piece `pre` (B, C8n, PH, PW, 8) into a pooled hi / lo pair (B, 2 C8n, H/2, W/2, 8)
  * + the (B, C8n, H/2, W/2, 8) mask bytes (same comparisons as iiseg_pool_mask_c8 with pre_f32). */
+/* iiseg_conv_c8_split_weights: the filter of an IISEG_CONV_X3 layer, w[co][c][3][3] (element strides
+ * stride_o / stride_c as in iiseg_conv_pack_f32) -> out (Cout, 2 Cp, 3, 3) floats = [W_hi | W_lo] with
+ * Cp = Cin rounded up to 16, ready for iiseg_conv_halo_bf16_pack with C1 = 2 Cp. */
+int iiseg_conv_c8_split_weights(void* stream, const float* w, int64_t stride_o, int64_t stride_c,
+                                int Cout, int Cin, float* out);
 int iiseg_nchw_to_c8x3(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
 int iiseg_c8x3_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8n);
 int iiseg_pool_mask_c8x3(void* stream, const void* pre, void* pooled, uint8_t* mask, int B, int C8n,

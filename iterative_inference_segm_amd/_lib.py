@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -83,6 +83,7 @@ SIGNATURES = {
     'iiseg_nchw_to_c8': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8': (C.c_int, [_vp, _vp, _i32, _vp, _vp] + [_i32] * 11),
+    'iiseg_conv_c8_split_weights': (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     'iiseg_nchw_to_c8x3': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8x3_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8x3': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 12),

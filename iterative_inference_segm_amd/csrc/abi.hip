@@ -17,5 +17,5 @@ extern "C" const char* iiseg_last_hip_error(void) {
     return hipGetErrorString((hipError_t)iiseg_hip_error_slot());
 }
 
-extern "C" int iiseg_abi_version(void) { return 28; }
+extern "C" int iiseg_abi_version(void) { return 29; }
 extern "C" const char* iiseg_target_arch(void) { return "gfx950"; }

@@ -712,6 +712,25 @@ __global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restri
     }
 }
 
+// IISEG_CONV_X3 weights: w[co][c][3][3] (strides so, sc) -> out (Cout, 2 Cp, 3, 3) fp32 = [W_hi | W_lo],
+// W_hi = bf16(w) and W_lo = bf16(w - W_hi) as floats, channels >= Cin of each group zero -- the filter
+// iiseg_conv_halo_bf16_pack then packs unchanged (every value is a bf16 number)
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ w, int64_t so, int64_t sc,
+                                                            float* __restrict__ out, int Cin, int Cp,
+                                                            int64_t total) {
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int tap = (int)(t % 9);
+        const int64_t r = t / 9;
+        const int c = (int)(r % Cp);
+        const int64_t co = r / Cp;
+        const float v = c < Cin ? w[co * so + c * sc + tap] : 0.f;
+        const float hi = (float)(__bf16)v;
+        const float lo = (float)(__bf16)(v - hi);
+        out[(co * 2 * Cp + c) * 9 + tap] = hi;
+        out[(co * 2 * Cp + Cp + c) * 9 + tap] = lo;
+    }
+}
+
 constexpr int FLAT_PCAP = 480;
 
 // FLAT tiling: patch rows a 256-pixel tile can need (worst case over tile positions).  Tile t starts
@@ -914,6 +933,18 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     if (out_kind == 3) return launch_c8<32, true>(s, p, plan, unpool);
     if (bm == 64) return launch_c8<64, false>(s, p, plan, unpool);
     return launch_c8<32, false>(s, p, plan, unpool);
+}
+
+extern "C" int iiseg_conv_c8_split_weights(void* stream, const float* w, int64_t stride_o,
+                                           int64_t stride_c, int Cout, int Cin, float* out) {
+    if (!w || !out) return IISEG_ERR_NULL;
+    if (Cout <= 0 || Cin <= 0) return IISEG_ERR_SHAPE;
+    const int Cp = (Cin + 15) / 16 * 16;
+    const int64_t total = (int64_t)Cout * Cp * 9;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
+                       stride_c, out, Cin, Cp, total);
+    return iiseg_check_launch();
 }
 
 extern "C" int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, int C, int H, int W,

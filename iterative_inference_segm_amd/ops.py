@@ -678,12 +678,10 @@ class Conv:
                 # two k-groups of whole 16-channel k-tiles [W_hi | W_lo]; the split values are bf16
                 # numbers, the pack's rounding leaves them as they are
                 Cp = (self.Cin + 15) // 16 * 16
-                Wo = self.W if self.layout == 'oihw' else self.W.permute(1, 0, 2, 3)
-                Wp = torch.zeros((self.Cout, Cp, 3, 3), dtype=torch.float32, device=self.W.device)
-                Wp[:, :self.Cin] = Wo
-                Wh = Wp.to(torch.bfloat16).to(torch.float32)
-                Wl = (Wp - Wh).to(torch.bfloat16).to(torch.float32)
-                Wsrc = torch.cat([Wh, Wl], dim=1).contiguous()
+                Wsrc = torch.empty((self.Cout, 2 * Cp, 3, 3), dtype=torch.float32, device=self.W.device)
+                check(lib.iiseg_conv_c8_split_weights(_stream(), _ptr(self.W), self.so, self.sc,
+                                                      self.Cout, self.Cin, _ptr(Wsrc)),
+                      'iiseg_conv_c8_split_weights')
                 dp.C1, so, sc = 2 * Cp, 2 * Cp * 9, 9
             self._W16c8 = torch.empty(lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(dp)) // 2,
                                       dtype=torch.bfloat16, device=self.W.device)
