@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         // {load, add, store} body per chunk is one memory round trip per chunk -- eight in a row
         // (hoisted per 32-channel block i: one register set of 4 x TN pieces serves both add formats)
         const bool has_add1 = p.add_kind == 1, has_add2 = p.add_kind == 2;
+        const float rfloor = p.relu ? 0.f : -__builtin_inff();
         constexpr int GH = TN == 4 ? 2 : 4;      // chunks whose loads are hoisted together (registers)
 #pragma unroll
         for (int ig = 0; ig < TM * (4 / GH); ++ig) {
@@ -522,10 +523,9 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                     } else if (has_add2) {
                         v[j] += __builtin_bit_cast(f32x4, adr[g][j]);
                     }
-                    if (p.relu) {
-                        v[j][0] = fmaxf(v[j][0], 0.f); v[j][1] = fmaxf(v[j][1], 0.f);
-                        v[j][2] = fmaxf(v[j][2], 0.f); v[j][3] = fmaxf(v[j][3], 0.f);
-                    }
+                    // (ReLU without a branch per piece: max with 0 or with -inf)
+                    v[j][0] = fmaxf(v[j][0], rfloor); v[j][1] = fmaxf(v[j][1], rfloor);
+                    v[j][2] = fmaxf(v[j][2], rfloor); v[j][3] = fmaxf(v[j][3], rfloor);
                     const unsigned oo = opix[j] + (unsigned)(((p.out_c0 >> 3) + c8) * OPL);
                     const bool ok = eok[j] && cok;
                     if (p.out_kind == 1) {
