@@ -448,23 +448,26 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const __amdgpu_buffer_rsrc_t r_mask =
             mk_rsrc(pooling && p.mask_out ? p.mask_out + (size_t)ib * co8 * PPL * 8 : nullptr,
                     pooling && p.mask_out ? (unsigned)(co8 * PPL) * 8u : 0u);
-        // element offsets (chunks) of the lane's pixels inside chunk plane 0 of their image
-        unsigned opix[TN], apix[TN];
+        // byte offsets of the lane's pixels (its half of a chunk) inside chunk plane 0 of their image,
+        // or the out-of-bounds offset; the chunk plane goes into the instructions' scalar offset
+        unsigned ob[TN], ab[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            opix[j] = (unsigned)(eb[j] * octT * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
-            apix[j] = (unsigned)(eb[j] * co8A * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+            const unsigned opix = (unsigned)(eb[j] * octT * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
+            const unsigned apix = (unsigned)(eb[j] * co8A * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+            ob[j] = eok[j] ? opix * osz + (osz >> 1) * lh : OOB;
+            ab[j] = eok[j] ? apix * asz + (asz >> 1) * lh : OOB;
         }
         // fused pool (RECT): the wave's rows are TN / 2 row pairs, lane ^ 1 is the column partner
-        bool q_ok[TN / 2];
-        unsigned q_pix[TN / 2];
+        unsigned qb[TN / 2], qm[TN / 2];  // byte offsets of the pooled pixel's half chunk / mask dword, or OOB
 #pragma unroll
         for (int jp = 0; jp < TN / 2; ++jp) {
             const int q_wy = wy0 + wave * TN + 2 * jp, q_wx = wx0 + l31;
             const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
-            q_ok[jp] = pooling && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
-                       q_py < p.pool_H && q_px < p.pool_W;
-            q_pix[jp] = (unsigned)(q_py * p.pool_W + q_px);
+            const bool q_ok = pooling && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
+                              q_py < p.pool_H && q_px < p.pool_W;
+            qb[jp] = q_ok ? (unsigned)(q_py * p.pool_W + q_px) * 16u + 8u * lh : OOB;
+            qm[jp] = q_ok ? (unsigned)(q_py * p.pool_W + q_px) * 8u + 4u * lh : OOB;
         }
         // Every load of the epilogue first (bias, skip-add; out-of-range pieces get the out-of-bounds
         // offset instead of a branch), then the stores: a buffer load that follows a buffer store in
@@ -482,24 +485,30 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 #pragma unroll
             for (int g = g0; g < g0 + GH; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;
-                const bool cok = c8 < co8;
+                const bool cok = c8 < co8;             // wave-uniform: chunks past the padded channels
+                const int so_a = (int)((unsigned)(c8 * APL) * asz);
                 bvs[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     r_bias, (int)(4u * (unsigned)(c8 * 8 + 4 * lh)), 0, 0));
+                if (!cok) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (has_add1) {
+                    for (int j = 0; j < TN; ++j) adr[g][j] = u32x4{0u, 0u, 0u, 0u};
+                } else if (has_add1) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
                         const u32x2 a2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 16u + 8u * lh : OOB), 0, 0));
+                            r_add, (int)ab[j], so_a, 0));
                         adr[g][j][0] = a2[0]; adr[g][j][1] = a2[1];
                         if constexpr (X3) {
                             const u32x2 a3 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                                r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)((c8 + co8) * APL)) * 16u + 8u * lh : OOB), 0, 0));
+                                r_add, (int)ab[j], so_a + (int)((unsigned)(co8 * APL) * 16u), 0));
                             adr[g][j][2] = a3[0]; adr[g][j][3] = a3[1];
                         }
-                    } else if (has_add2) {
-                        adr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            r_add, (int)((eok[j] && cok) ? (apix[j] + (unsigned)(c8 * APL)) * 32u + 16u * lh : OOB), 0, 0));
                     }
+                } else if (has_add2) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        adr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            r_add, (int)ab[j], so_a, 0));
                 }
             }
 #pragma unroll
@@ -526,26 +535,31 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                     // (ReLU without a branch per piece: max with 0 or with -inf)
                     v[j][0] = fmaxf(v[j][0], rfloor); v[j][1] = fmaxf(v[j][1], rfloor);
                     v[j][2] = fmaxf(v[j][2], rfloor); v[j][3] = fmaxf(v[j][3], rfloor);
-                    const unsigned oo = opix[j] + (unsigned)(((p.out_c0 >> 3) + c8) * OPL);
-                    const bool ok = eok[j] && cok;
-                    if (p.out_kind == 1) {
+                }
+                // stores: the pixel's byte offset is per lane and fixed, the chunk plane a scalar offset
+                const int so_o = (int)((unsigned)(((p.out_c0 >> 3) + c8) * OPL) * osz);
+                if (cok && p.out_kind == 1) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
                         u32x2 w2;
                         w2[0] = pack_bf16(v[j][0], v[j][1]); w2[1] = pack_bf16(v[j][2], v[j][3]);
-                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)(ok ? oo * 16u + 8u * lh : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)ob[j], so_o, 0);
                         if constexpr (X3) {
                             u32x2 l2;
                             l2[0] = pack_bf16(v[j][0] - bf_lo(w2[0]), v[j][1] - bf_hi(w2[0]));
                             l2[1] = pack_bf16(v[j][2] - bf_lo(w2[1]), v[j][3] - bf_hi(w2[1]));
                             __builtin_amdgcn_raw_buffer_store_b64(
-                                l2, r_out, (int)(ok ? (oo + (unsigned)(oct8 * OPL)) * 16u + 8u * lh : OOB), 0, 0);
+                                l2, r_out, (int)ob[j], so_o + (int)((unsigned)(oct8 * OPL) * 16u), 0);
                         }
-                    } else if (p.out_kind == 2) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), r_out,
-                                                               (int)(ok ? oo * 32u + 16u * lh : OOB), 0, 0);
                     }
+                } else if (cok && p.out_kind == 2) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), r_out,
+                                                               (int)ob[j], so_o, 0);
                 }
                 if constexpr (!FLAT) {
-                    if (pooling) {
+                    if (pooling && cok) {
                         // 2x2 max-pool of fp32 values + DePool2D mask bits (y & 1) * 2 + (x & 1):
                         // pre == pooled (layers/mylayers.py:111-114), window = rows (j = 0, 1) x
                         // columns (lane, lane ^ 1); the even lane stores
@@ -569,18 +583,18 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         // to the column's bit position (x & 1) and merged with the partner's
                         own <<= (unsigned)(l31 & 1);
                         const unsigned mb = own | dpp_xor1(own);
-                        const unsigned po = q_pix[jp] + (unsigned)(c8 * PPL);
+                        const int so_p = (int)((unsigned)(c8 * PPL) * 16u);
                         u32x2 w2;
                         w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
-                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)((q_ok[jp] && cok) ? po * 16u + 8u * lh : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)qb[jp], so_p, 0);
                         if constexpr (X3) {
                             u32x2 l2;
                             l2[0] = pack_bf16(m[0] - bf_lo(w2[0]), m[1] - bf_hi(w2[0]));
                             l2[1] = pack_bf16(m[2] - bf_lo(w2[1]), m[3] - bf_hi(w2[1]));
                             __builtin_amdgcn_raw_buffer_store_b64(
-                                l2, r_pool, (int)((q_ok[jp] && cok) ? (po + (unsigned)(co8 * PPL)) * 16u + 8u * lh : OOB), 0, 0);
+                                l2, r_pool, (int)qb[jp], so_p + (int)((unsigned)(co8 * PPL) * 16u), 0);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)((q_ok[jp] && cok) ? po * 8u + 4u * lh : OOB), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)qm[jp], so_p >> 1, 0);
                         }
                     }
                 }
