@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         for (int ig = 0; ig < TM * (4 / GH); ++ig) {
             const int i = ig / (4 / GH), g0 = (ig % (4 / GH)) * GH;
             f32x4 bvs[4];
-            u32x4 adr[4][TN];
+            u32x4 adr[4][TN];                 // raw addend pieces (bf16 hi [, lo] halves or 4 floats)
 #pragma unroll
             for (int g = g0; g < g0 + GH; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;
@@ -489,10 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                 const int so_a = (int)((unsigned)(c8 * APL) * asz);
                 bvs[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                     r_bias, (int)(4u * (unsigned)(c8 * 8 + 4 * lh)), 0, 0));
-                if (!cok) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) adr[g][j] = u32x4{0u, 0u, 0u, 0u};
-                } else if (has_add1) {
+                if (cok && has_add1) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const u32x2 a2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
@@ -504,11 +501,34 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                             adr[g][j][2] = a3[0]; adr[g][j][3] = a3[1];
                         }
                     }
-                } else if (has_add2) {
+                } else if (cok && has_add2) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         adr[g][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                             r_add, (int)ab[j], so_a, 0));
+                }
+            }
+            // the addend as four floats per piece, whatever its format (zeros without one): the value
+            // loop below has no branch
+            f32x4 addv[4][TN];
+#pragma unroll
+            for (int g = g0; g < g0 + GH; ++g) {
+                const bool cok = ((m0 + i * 32) >> 3) + g < co8;
+                if (cok && has_add1) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        addv[g][j] = f32x4{bf_lo(adr[g][j][0]), bf_hi(adr[g][j][0]),
+                                           bf_lo(adr[g][j][1]), bf_hi(adr[g][j][1])};
+                        if constexpr (X3)      // hi + lo: the 16-bit value the producer stored
+                            addv[g][j] += f32x4{bf_lo(adr[g][j][2]), bf_hi(adr[g][j][2]),
+                                                bf_lo(adr[g][j][3]), bf_hi(adr[g][j][3])};
+                    }
+                } else if (cok && has_add2) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) addv[g][j] = __builtin_bit_cast(f32x4, adr[g][j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) addv[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
 #pragma unroll
@@ -521,17 +541,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[j][q] = acc[i][j][g * 4 + q] + bv[q];
-                    if (has_add1) {
-                        v[j][0] += bf_lo(adr[g][j][0]); v[j][1] += bf_hi(adr[g][j][0]);
-                        v[j][2] += bf_lo(adr[g][j][1]); v[j][3] += bf_hi(adr[g][j][1]);
-                        if constexpr (X3) {
-                            // hi + lo first: the pair is the 16-bit value the producer stored
-                            v[j][0] += bf_lo(adr[g][j][2]); v[j][1] += bf_hi(adr[g][j][2]);
-                            v[j][2] += bf_lo(adr[g][j][3]); v[j][3] += bf_hi(adr[g][j][3]);
-                        }
-                    } else if (has_add2) {
-                        v[j] += __builtin_bit_cast(f32x4, adr[g][j]);
-                    }
+                    v[j] += addv[g][j];
                     // (ReLU without a branch per piece: max with 0 or with -inf)
                     v[j][0] = fmaxf(v[j][0], rfloor); v[j][1] = fmaxf(v[j][1], rfloor);
                     v[j][2] = fmaxf(v[j][2], rfloor); v[j][3] = fmaxf(v[j][3], rfloor);
