@@ -283,14 +283,17 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 #define C8_STORE_U(BUF)                                                                            \
     static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
         constexpr int i = decltype(I)::value;                                                      \
-        /* byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j */         \
+        /* byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j.  The four  \
+           bits of a dword become four 0x00 / 0xff bytes (t * 255 without a multiply), v_perm_b32   \
+           doubles each byte into the 16-bit lane of its channel */                                 \
         const unsigned t0 = (xm[i][0] >> bsel[i]) & 0x01010101u;                                   \
         const unsigned t1 = (xm[i][1] >> bsel[i]) & 0x01010101u;                                   \
+        const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;                                   \
         uint4 v;                                                                                   \
-        v.x = xu[i][0] & (((t0 & 1u) * 0xffffu) | (((t0 >> 8) & 1u) * 0xffff0000u));               \
-        v.y = xu[i][1] & ((((t0 >> 16) & 1u) * 0xffffu) | (((t0 >> 24) & 1u) * 0xffff0000u));      \
-        v.z = xu[i][2] & (((t1 & 1u) * 0xffffu) | (((t1 >> 8) & 1u) * 0xffff0000u));               \
-        v.w = xu[i][3] & ((((t1 >> 16) & 1u) * 0xffffu) | (((t1 >> 24) & 1u) * 0xffff0000u));      \
+        v.x = xu[i][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);                               \
+        v.y = xu[i][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);                               \
+        v.z = xu[i][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);                               \
+        v.w = xu[i][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);                               \
         if (i * 256 + tid < 2 * half) Ps[BUF][i * 256 + tid] = v;                                  \
     });
 
