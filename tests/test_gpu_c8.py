@@ -352,3 +352,45 @@ def test_conv_c8_random_geometries(ops):
                                       bits[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'mask')
     print('random C8 launches: %d of 40 on the flat tiling' % n_flat)
     assert 5 <= n_flat <= 38
+
+
+DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 k-tiles: the deep layers)
+    (5, 256, 13, 13, 64, 1, True, None),
+    (3, 320, 22, 22, 128, 1, False, (5, 6, 10, 10)),
+    (9, 272, 10, 10, 72, 1, True, None),            # 810 pixels: a partly filled second 512-pixel tile
+    (2, 512, 31, 31, 64, 1, True, None),            # 31-wide rows: the widest patch rows of configs[1]
+]
+
+
+@pytest.mark.parametrize('case', DEEP_CASES)
+def test_conv_c8_long_k_flat_exact_on_integer_data(ops, case):
+    """Flat-tiled launches with long k-loops (256 to 512 input channels, 10^2 to 31^2 windows, tiles
+    that run across images) against the oracle, bit for bit: fp32 chunk output, bf16 output with
+    skip-add and placement."""
+    B, Cin, H, W, Cout, pad, relu, window = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x = ints(rng, B, Cin, H, W, lo=-1, hi=2)
+    Wt = ints(rng, Cout, Cin, 3, 3, lo=-1, hi=2)
+    b = ints(rng, Cout)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, mma='bf16c8')
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+    fh, fw = ref.shape[2], ref.shape[3]
+    y0, x0, h, w = window if window is not None else (0, 0, fh, fw)
+    x8 = ops.nchw_to_c8(dev(x))
+    kw = dict(window=window) if window is not None else {}
+    got32 = conv(x8, out_format='c8f32', **kw)
+    a = host(got32).astype(np.float64).transpose(0, 1, 4, 2, 3).reshape(B, -1, h, w)[:, :Cout]
+    assert np.array_equal(a, ref[:, :, y0:y0 + h, x0:x0 + w])
+    # bf16 output placed into a larger tensor, with a skip addend that keeps every value bf16-exact
+    skip = -np.round(onn.conv2d(x, Wt, b, pad=pad, relu=False)) + ints(rng, B, Cout, fh, fw, lo=-3, hi=4)
+    skip = np.clip(skip, -256, 256)
+    tot = onn.conv2d(x, Wt, b, pad=pad, relu=False) + skip
+    if relu:
+        tot = np.maximum(tot, 0)
+    assert np.abs(tot).max() <= 256
+    out = torch.full((B, ops.c8_chunks(Cout), fh, fw, 8), -9.0, dtype=torch.bfloat16, device='cuda')
+    conv(x8, add=ops.nchw_to_c8(dev(skip)), add_off=(y0, x0), window=(y0, x0, h, w), out=out,
+         place=(y0, x0))
+    want = np.full((B, Cout, fh, fw), -9.0)
+    want[:, :, y0:y0 + h, x0:x0 + w] = tot[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.array_equal(from_c8(out, Cout), want)

@@ -431,3 +431,26 @@ def test_conv_x3_random_geometries(ops):
                                       bits[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'mask')
     print('random X3 launches: %d of 40 on the flat tiling' % n_flat)
     assert 5 <= n_flat <= 38
+
+
+@pytest.mark.parametrize('case', [(5, 96, 13, 13, 64, 1, True), (3, 256, 22, 22, 128, 1, False),
+                                  (9, 128, 10, 10, 72, 1, True)])
+def test_conv_x3_long_k_flat_exact_on_integer_data(ops, case):
+    """IISEG_CONV_X3 on flat tiles with long k-loops (18 to 48 steps): bit for bit against the oracle
+    with the lo halves in the activations, then in the weights."""
+    B, Cin, H, W, Cout, pad, relu = case
+    rng = np.random.default_rng(sum(case[:6]))
+    for split in ('activations', 'weights'):
+        if split == 'activations':
+            x, Wt = wide_ints(rng, B, Cin, H, W, big=600), small_ints(rng, Cout, Cin, 3, 3)
+        else:
+            x, Wt = small_ints(rng, B, Cin, H, W, lo=-2, hi=3), wide_ints(rng, Cout, Cin, 3, 3, small=1, big=300)
+        b = small_ints(rng, Cout, lo=-3, hi=4)
+        conv = ops.Conv(Wt, b, pad=pad, relu=relu, mma='bf16x3')
+        ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+        x8 = ops.nchw_to_c8(dev(x), x3=True)
+        assert np.abs(ref).max() < 2 ** 24
+        assert np.array_equal(from_c8f32(conv(x8, out_format='c8f32'), Cout), ref)
+        got = from_pair(ops, conv(x8), Cout)
+        ok16 = np.abs(ref) < 2 ** 16
+        assert ok16.mean() > 0.9 and np.array_equal(got[ok16], ref[ok16])
