@@ -454,3 +454,29 @@ def test_conv_x3_long_k_flat_exact_on_integer_data(ops, case):
         got = from_pair(ops, conv(x8), Cout)
         ok16 = np.abs(ref) < 2 ** 16
         assert ok16.mean() > 0.9 and np.array_equal(got[ok16], ref[ok16])
+
+
+def test_x3_engine_on_360x480_frames(built_lib):
+    """configs[3]'s geometry (360x480 CamVid frames) on the damped set, 2 frames, 10 steps free-running,
+    against the float64 path.  The fp32 path meets its 224x224 criterion here too (>= 0.999 of the pixels
+    within 1e-4: measured 0.99929); the bf16x3 mode lands just below it (measured 0.99870, max 3.2e-4,
+    mean 1.4e-6, argmax agreement 0.999997) -- asserted at 0.998 and said so in DESIGN 3.8: the mode
+    is fp32-CLASS, not fp32."""
+    from iterative_inference_segm_amd import synthetic as S
+    X = S.make_images(2, 360, 480, seed=4321)
+    res = {}
+    for k, (dt, mma) in {'f64': (torch.float64, None), 'f32': (torch.float32, None),
+                         'x3': (torch.float32, 'bf16x3')}.items():
+        ii = _damped_engine(dt, mma)
+        out = ii.pred_fcn_fn(X)
+        res[k] = ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)[0].double()
+        del ii
+        torch.cuda.empty_cache()
+    floor = {'f32': 0.999, 'x3': 0.998}
+    for k in ('f32', 'x3'):
+        e = (res[k] - res['f64']).abs()
+        frac = float((e.amax(1) <= 1e-4).double().mean())
+        agree = float((res[k].argmax(1) == res['f64'].argmax(1)).double().mean())
+        print('360x480, %s vs float64 after 10 steps: pixels within 1e-4 %.5f, max %.2e, mean %.2e, argmax '
+              'agreement %.6f' % (k, frac, float(e.max()), float(e.mean()), agree))
+        assert frac >= floor[k] and float(e.mean()) <= 1e-5 and agree >= 0.9999
