@@ -480,3 +480,54 @@ def test_x3_engine_on_360x480_frames(built_lib):
         print('360x480, %s vs float64 after 10 steps: pixels within 1e-4 %.5f, max %.2e, mean %.2e, argmax '
               'agreement %.6f' % (k, frac, float(e.max()), float(e.mean()), agree))
         assert frac >= floor[k] and float(e.mean()) <= 1e-5 and agree >= 0.9999
+
+
+KNOBS = [  # concat_h, h channels, additional_pool, skip, unpool_type, padding
+    (['pool4'], (9,), 2, True, 'trackind', 100),
+    (['pool4'], (9,), 1, False, 'inverse', 100),
+    (['input'], (3,), 2, True, 'trackind', 100),
+    (['pool3', 'pool4'], (7, 9), 1, True, 'trackind', 100),
+    (['pool4'], (9,), 2, True, 'trackind', 0),
+]
+
+
+@pytest.mark.parametrize('knobs', KNOBS)
+def test_x3_dae_knobs_vs_oracle(built_lib, knobs):
+    """dae_dict knobs the bf16x3 / C8 plan supports (concat points incl. `input` and two at once,
+    additional_pool, skip, unpool_type trackind / inverse, padding 100 / 0), small standard DAE, one
+    reconstruction r(y | h) and the de it gives, against the float64 oracle on the same inputs."""
+    from oracle import dae as odae
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.dae import StandardDAE
+    concat_h, hch, ap, skip, ut, padding = knobs
+    rng = np.random.default_rng(len(concat_h) * 7 + ap)
+    Hh, Ww = (48, 64) if padding else (128, 192)      # six poolings need room without the pad-100 border
+    y = rng.random((2, 11, Hh, Ww)).astype(np.float32); y /= y.sum(1, keepdims=True)
+    hs = []
+    for name, c in zip(concat_h, hch):
+        if name == 'input':
+            hs.append(rng.random((2, c, Hh, Ww)).astype(np.float32))
+        else:
+            s = 2 ** int(name[-1])
+            q = (Hh + 2 * padding - 2) if padding else Hh
+            r = (Ww + 2 * padding - 2) if padding else Ww
+            hs.append(rng.random((2, c, q // s, r // s)).astype(np.float32))
+    multi = len(concat_h) > 1
+    dp = S.make_dae_params(h_channels=hch, concat_h=concat_h, n_filters=8, additional_pool=ap,
+                           unpool_type=ut, seed=77, out_gain=0.25, dec_gain=0.35)
+    kw = dict(concat_h=concat_h, n_filters=8, additional_pool=ap, skip=skip, unpool_type=ut,
+              padding=padding)
+    if multi:
+        kw['pad_multi_concat'] = True
+    to64 = lambda p: {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in p.items()}
+    try:
+        r_ref = odae.dae_forward(to64(dp), [h.astype(np.float64) for h in hs], y.astype(np.float64), **kw)
+    except Exception as e:       # a knob combination the reference's shapes do not admit
+        pytest.skip('oracle: %s' % e)
+    dae = StandardDAE(dp, 11, mma='bf16x3', **kw)
+    assert dae.x3 and dae.c8
+    got = host(dae(*[torch.from_numpy(h).cuda() for h in hs], torch.from_numpy(y).cuda())).astype(np.float64)
+    e = np.abs(got - r_ref)
+    frac = float((e.max(axis=1) <= 1e-4).mean())
+    print('%s: r max err %.2e mean %.2e, pixels within 1e-4 %.5f' % (knobs, e.max(), e.mean(), frac))
+    assert frac >= 0.999 and e.mean() <= 1e-5
