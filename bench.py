@@ -582,10 +582,11 @@ def worker(args):
                  'miou_iterative_inference': round(mioux3, 5),
                  'delta_miou_vs_f32': round(mioux3 - miou, 5),
                  'parity': 'fp32-class: per-layer relative RMS error 5e-6 (fp32 MFMA 4e-7, one bf16 '
-                           'operand 3e-3); damped synthetic set, 10 steps free-running, own masks: '
-                           '0.99923 of the pixels within 1e-4 of the float64 path (the fp32 path: '
-                           '0.99939), mean error 1.2e-6, argmax agreement 1.0; at 360x480 0.99870 '
-                           'against the fp32 path\'s 0.99929 '
+                           'operand 3e-3); damped synthetic set, 10 steps free-running, own masks, 64 '
+                           'images: 0.99861 of the pixels within 1e-4 of the float64 path (the fp32 '
+                           'path: 0.99930), mean error 1.4e-6, argmax agreement 0.999999 '
+                           '(profiles/r03_parity_damped_64.md); at 360x480 0.99870 against the fp32 '
+                           'path\'s 0.99929 '
                            '(tests/test_gpu_x3.py; bit-exact vs the oracle on 16-bit integer data)'}
         if not args.no_roofline:
             # priced against a third of the bf16 peak: three MFMA products per algorithmic term
