@@ -277,9 +277,16 @@ int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const double* x1
  *   pool_out    C8 bf16 (B, Cout/8, fullH/2, fullW/2, 8): 2x2 max-pool of the fp32 results, rules as
  *               iiseg_conv_pool_f32; mask_out: the DePool2D mask bytes of those windows, taken from
  *               the fp32 results before rounding (same decisions as the fp32-activation form)
- * iiseg_conv_c8_is_flat: 1 if the launch uses the flat pixel tiling (256 consecutive window pixels of
- * the whole batch per workgroup: small windows); pool_out is then not available -- store the map and
- * call iiseg_pool_mask_c8.
+ * Pixel tilings (chosen per launch from its geometry alone; every output is one fixed-order sum
+ * whichever runs it): th x tw pixel tiles of one image (256 or 512 pixels, shape chosen for the fewest
+ * tiles) or FLAT, 256 consecutive window pixels of the whole batch per workgroup (small windows).  With
+ * pool_out the pixels of a tile are ordered by 2x2 pooling windows (even tile shapes; the flat list is
+ * a list of windows), so the fused pool is available on every tiling.
+ * iiseg_conv_c8_is_flat: 1 if the launch (without pool_out) uses the flat tiling.
+ * (environment overrides for timing experiments: IISEG_C8_TILING=1|2, IISEG_C8_TALL=0|1,
+ * IISEG_C8_SHAPE=th,tw)
+ * iiseg_conv_c8_tiling: out4 = {0 rect-256 / 1 rect-512 / 2 flat, th (flat: patch rows), tw (flat:
+ * patch row stride), quad order} of the launch with (pool != 0) or without a fused pool.
  * iiseg_nchw_to_c8 / iiseg_c8_to_nchw: layout converters (fp32 NCHW <-> C8 bf16, C8n chunks/image).
  * iiseg_pool_mask_c8: 2x2 max-pool (+ mask bytes, may be NULL) of the pooled-coordinate window
  * (y0, x0, wh, ww) from a stored piece `pre` (BC8 = B * chunks, PH, PW, 8; bf16, or with pre_f32 the
@@ -287,6 +294,10 @@ int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const double* x1
  * (py0, px0) of the (H, W) map, into the full (BC8, H/2, W/2, 8) pooled / mask tensors. */
 int iiseg_conv_c8_supported(const iiseg_conv_desc* d);
 int iiseg_conv_c8_is_flat(const iiseg_conv_desc* d);
+int iiseg_conv_c8_tiling(const iiseg_conv_desc* d, int pool, int32_t* out4);
+/* Test hook (process-wide, not for production use): kind -1 = automatic (default), 0 / 1 / 2 force the
+ * rect-256 / rect-512 / flat tiling where it can run the launch; th, tw > 0 fix the RECT tile shape. */
+int iiseg_conv_c8_force_tiling(int kind, int th, int tw);
 int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const void* x2,
                   const uint8_t* mask_in, const void* wp16, const float* bias, const void* add,
                   int add_kind, void* out, int out_kind, void* pool_out, uint8_t* mask_out);

@@ -79,6 +79,8 @@ SIGNATURES = {
     'iiseg_conv_wino_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
     'iiseg_conv_c8_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_c8_is_flat': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_c8_force_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'iiseg_conv_c8_tiling': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int32)]),
     'iiseg_conv_c8': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 6 + [_i32, _vp, _i32, _vp, _vp]),
     'iiseg_nchw_to_c8': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),

@@ -311,8 +311,13 @@ class IterativeInference:
         # on.  Step 0 has just run on the CURRENT ones (it re-primes the session when the masked-level
         # set, trace / keep_pre, ... changed since the last call), so the fingerprint is taken here.
         fp = (id(sess), self._launch_fingerprint(sess))
-        if ctx.get('fingerprint') != fp:
+        # ... and for the scratch (Winograd / BN workspaces of this engine's tag) the captured
+        # launches point into: a larger launch elsewhere may have regrown one since the capture,
+        # which hands the old allocation back to the caching allocator
+        if ctx.get('fingerprint') != fp or \
+                (ctx['graph'] is not None and ctx.get('ws_ptrs') != _ops.workspace_ptrs(y.device)):
             ctx['graph'], ctx['fingerprint'] = None, fp
+            ctx.pop('keep', None)            # nothing pins the old session / scratch any longer
         r0 = _ops.crop_softmax(score, y.shape[2], y.shape[3], off=(0, 0)) if first_reconstruction \
             else None
         self._update(score, y, st, step, sess)
@@ -330,7 +335,8 @@ class IterativeInference:
                 _ops.CONV_PROFILE = prof
                 ctx['graph'] = g
                 # scratch the captured launches point at must outlive the graph
-                ctx['keep'] = (_ops._wino_ws.get(_ops._ws_key(y.device)), sess)
+                ctx['keep'] = (_ops.workspace_refs(y.device), sess)
+                ctx['ws_ptrs'] = _ops.workspace_ptrs(y.device)
         g = ctx['graph']
         while it < num_iter:
             g.replay()

@@ -24,6 +24,7 @@
 // rounded once, where an operand would be rounded anyway.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <map>
 #include <mutex>
@@ -35,6 +36,12 @@
 using namespace iiseg;
 
 namespace {
+
+// Patch capacity of every variant: 5 DMA rounds of 256 chunks = 640 chunks per 8-channel half (two
+// halves per 16-channel k-tile).  LDS per workgroup with 64 output channels: 2 x (18 KB weights +
+// 20 KB patch) = 76 KB, two workgroups per CU.
+constexpr int C8_NE = 5;
+constexpr int C8_PCAP = C8_NE * 128;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -82,8 +89,13 @@ struct C8Params {
     int pool_H, pool_W;
     int relu;
     int n_ptiles, n_mtiles, tiles_y, tiles_x;
-    int N;                        // FLAT: B * OH * OW
+    int N;                        // FLAT: B * OH * OW (quad: B * QH * QW quads)
     int PR, PWs;                  // FLAT: patch rows (capacity of a launch), patch row stride OW + 2
+    int th, tw;                   // RECT: tile rows x columns, th * tw <= 128 TN pixels
+    int quad;                     // pixel order inside a tile: 0 row-major, 1 by 2x2 pooling windows
+    int QH, QW;                   // FLAT quad: pooling windows per image (ceil(OH / 2), ceil(OW / 2))
+    unsigned pw_magic;            // ceil(2^20 / PWs): row of a patch chunk without a division
+    unsigned tw_magic;            // RECT: ceil(2^20 / (quad ? tw / 2 : tw))
     int x3;                       // split-operand mode (template X3)
     int debug;
 };
@@ -102,12 +114,10 @@ struct C8Params {
 // kind 1 are hi / lo pairs, the DePool2D masks and the pool still come from the fp32 accumulators.
 template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3>
 __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
-    constexpr int TH = 4 * TN, TW = 32;
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
-    constexpr int PCAP = FLAT ? 480 : (TH + 2) * (TW + 2);   // patch chunks per 8-channel half
-    // (buffer size = whole 256-chunk DMA rounds: every wave issues all NE pieces, lanes past the patch
-    // write zeros into the unused tail)
-    constexpr int NE = (2 * PCAP + 255) / 256;
+    // patch buffer: C8_PCAP chunks per 8-channel half, staged as up to NE rounds of 256 chunks (a
+    // wave issues only the pieces that hold patch chunks: wave-uniform test)
+    constexpr int NE = C8_NE;
     constexpr int NCHK = NE * 256;
     constexpr int TM = BM / 32;
     constexpr int WCH = 18 * BM;                             // weight chunks per k-tile
@@ -132,26 +142,40 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 
     // ---- tile geometry -----------------------------------------------------------------------
     int tb = 0, wy0 = 0, wx0 = 0;     // RECT: image, tile origin in window coordinates
-    int n0 = 0, vmin = 0;             // FLAT: first pixel of the tile, its virtual row
+    int n0 = 0, vmin = 0;             // FLAT: first pixel (quad) of the tile, its virtual row
     int PWs, half;
     if constexpr (FLAT) {
         // The windows of all images stacked: virtual output row u = b * (OH + 2) + y (two unused
         // rows per image keep the 3-row halo of neighbouring images apart); the patch holds the
-        // virtual INPUT rows [vmin, vmin + PR) x (OW + 2) columns.
-        n0 = pt * 256;
-        const int b0 = n0 / OHW, r0 = n0 - b0 * OHW;
-        vmin = b0 * (p.OH + 2) + r0 / p.OW;
+        // virtual INPUT rows [vmin, vmin + PR) x (OW + 2) columns.  A tile is 256 consecutive pixels
+        // of that list, or (quad) 64 consecutive 2x2 pooling windows of it.
+        if (p.quad) {
+            const int QHW = p.QH * p.QW;
+            n0 = pt * 64;
+            const int b0 = n0 / QHW, r0 = n0 - b0 * QHW;
+            vmin = b0 * (p.OH + 2) + 2 * (r0 / p.QW);
+        } else {
+            n0 = pt * 256;
+            const int b0 = n0 / OHW, r0 = n0 - b0 * OHW;
+            vmin = b0 * (p.OH + 2) + r0 / p.OW;
+        }
         PWs = p.PWs;
         half = p.PR * PWs;
     } else {
+        // RECT: th x tw pixels of one image (th * tw <= 128 TN; any shape whose patch fits)
         const int tpi = p.tiles_y * p.tiles_x;
         tb = pt / tpi;
         const int tr = pt - tb * tpi;
         const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
-        wy0 = ty * TH; wx0 = tx * TW;
-        PWs = TW + 2;
-        half = PCAP;
+        wy0 = ty * p.th; wx0 = tx * p.tw;
+        PWs = p.tw + 2;
+        half = (p.th + 2) * PWs;
     }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // piece i of this wave holds chunks [i * 256 + wave * 64, + 64): staged only if the patch reaches it
+    bool piece[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) piece[i] = i * 256 + wave_u * 64 < 2 * half;
 
     // ---- patch staging offsets: chunk e = i * 256 + tid -> (half h, patch row, patch column) ----
     unsigned voff[NE];                 // byte offset of the chunk in its source (k-tile 0), or OOB
@@ -162,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const int e = i * 256 + tid;
         const int h = e >= half ? 1 : 0;
         const int rr = e - h * half;
-        const int prow = rr / PWs, pcol = rr - prow * PWs;
+        const int prow = (int)(((unsigned)rr * p.pw_magic) >> 20), pcol = rr - prow * PWs;   // rr / PWs
         bool ok = e < 2 * half;
         int b, iy;
         if constexpr (FLAT) {
@@ -203,25 +227,55 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr(&Ws[0][0]) + (unsigned)wave * 1024u);
     const unsigned lds_p = __builtin_amdgcn_readfirstlane(lds_addr(&Ps[0][0]) + (unsigned)wave * 1024u);
 
-    // ---- MFMA B-operand positions of this lane's two 32-pixel columns -----------------------------
+    // ---- MFMA B-operand positions of this lane's 32-pixel columns ----------------------------------
+    // Pixel of (wave, j, l31) inside the tile: row-major (pixel n = (wave TN + j) 32 + l31 of the th x tw
+    // tile, or of the flat list), or by pooling windows (quad): window q = (wave TN / 2 + j / 2) 16 +
+    // l31 / 2, pixel (2 qy + (j & 1), 2 qx + (l31 & 1)) -- a lane's accumulators j, j + 1 are then the
+    // two rows and lane ^ 1 the other column of one 2x2 window, whatever the tile's shape.
     int bpos[TN];
     int eb[TN], ey[TN], ex[TN];        // epilogue: image, window row, window column of the lane's pixel
     bool eok[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         if constexpr (FLAT) {
-            const int n = n0 + wave * 64 + j * 32 + l31;
-            eok[j] = n < p.N;
-            const int nn = eok[j] ? n : p.N - 1;
-            eb[j] = nn / OHW;
-            const int r = nn - eb[j] * OHW;
-            ey[j] = r / p.OW; ex[j] = r - ey[j] * p.OW;
+            if (p.quad) {
+                const int q = n0 + wave * 16 + (l31 >> 1);
+                const bool qok = q < p.N;
+                const int qq = qok ? q : p.N - 1;
+                const int QHW = p.QH * p.QW;
+                eb[j] = qq / QHW;
+                const int r = qq - eb[j] * QHW;
+                const int qy = r / p.QW, qx = r - qy * p.QW;
+                ey[j] = 2 * qy + j; ex[j] = 2 * qx + (l31 & 1);
+                eok[j] = qok && ey[j] < p.OH && ex[j] < p.OW;
+            } else {
+                const int n = n0 + wave * 64 + j * 32 + l31;
+                eok[j] = n < p.N;
+                const int nn = eok[j] ? n : p.N - 1;
+                eb[j] = nn / OHW;
+                const int r = nn - eb[j] * OHW;
+                ey[j] = r / p.OW; ex[j] = r - ey[j] * p.OW;
+            }
             bpos[j] = (eb[j] * (p.OH + 2) + ey[j] - vmin) * PWs + ex[j];
         } else {
             eb[j] = 0;
-            ey[j] = wy0 + wave * TN + j; ex[j] = wx0 + l31;
-            eok[j] = ey[j] < p.OH && ex[j] < p.OW;
-            bpos[j] = (wave * TN + j) * PWs + l31;
+            int ly, lx;
+            bool inb;
+            if (p.quad) {
+                const int q = (wave * (TN / 2) + (j >> 1)) * 16 + (l31 >> 1);
+                const int hw = p.tw >> 1;
+                const int qy = (int)(((unsigned)q * p.tw_magic) >> 20), qx = q - qy * hw;      // q / hw
+                ly = 2 * qy + (j & 1); lx = 2 * qx + (l31 & 1);
+                inb = ly < p.th;
+            } else {
+                const int n = (wave * TN + j) * 32 + l31;
+                ly = (int)(((unsigned)n * p.tw_magic) >> 20); lx = n - ly * p.tw;              // n / tw
+                inb = ly < p.th;
+            }
+            if (!inb) { ly = 0; lx = 0; }
+            ey[j] = wy0 + ly; ex[j] = wx0 + lx;
+            eok[j] = inb && ey[j] < p.OH && ex[j] < p.OW;
+            bpos[j] = ly * PWs + lx;
         }
     }
 
@@ -245,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const unsigned so_u = __builtin_amdgcn_readfirstlane(so);                                  \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
-            dma16(s1 ? s_x1 : s_x2, lds_p + (unsigned)((BUF) * NCHK + i * 256) * 16u, voff[i], so_u); \
+            if (piece[i])                                                                          \
+                dma16(s1 ? s_x1 : s_x2, lds_p + (unsigned)((BUF) * NCHK + i * 256) * 16u, voff[i], so_u); \
         });                                                                                        \
     }
     // weights of packed k-tile WT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
@@ -274,15 +329,18 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const unsigned som = (unsigned)((KM) * hw2) * 8u;                                          \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
-            xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(               \
-                r_x1, (int)voff[i], (int)so, 0));                                                  \
-            xm[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                \
-                r_m, (int)voffm[i], (int)som, 0));                                                 \
+            if (piece[i]) {                                                                        \
+                xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(           \
+                    r_x1, (int)voff[i], (int)so, 0));                                              \
+                xm[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(            \
+                    r_m, (int)voffm[i], (int)som, 0));                                             \
+            }                                                                                      \
         });                                                                                        \
     }
 #define C8_STORE_U(BUF)                                                                            \
     static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
         constexpr int i = decltype(I)::value;                                                      \
+        if (!piece[i]) return;                                                                     \
         /* byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j.  The four  \
            bits of a dword become four 0x00 / 0xff bytes (t * 255 without a multiply), v_perm_b32   \
            doubles each byte into the 16-bit lane of its channel */                                 \
@@ -444,13 +502,13 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const __amdgpu_buffer_rsrc_t r_add =
             mk_rsrc(p.add ? (const char*)p.add + (size_t)ib * co8A * APL * asz : nullptr,
                     p.add ? (unsigned)((FLAT ? p.B : 1) * co8A * APL) * asz : 0u);
-        const bool pooling = !FLAT && p.pool != nullptr;
+        const bool pooling = p.pool != nullptr;       // (host: only with the quad pixel order)
         const __amdgpu_buffer_rsrc_t r_pool =
             mk_rsrc(pooling ? (const char*)p.pool + (size_t)ib * co8P * PPL * 16 : nullptr,
-                    pooling ? (unsigned)(co8P * PPL) * 16u : 0u);
+                    pooling ? (unsigned)((FLAT ? p.B : 1) * co8P * PPL) * 16u : 0u);
         const __amdgpu_buffer_rsrc_t r_mask =
             mk_rsrc(pooling && p.mask_out ? p.mask_out + (size_t)ib * co8 * PPL * 8 : nullptr,
-                    pooling && p.mask_out ? (unsigned)(co8 * PPL) * 8u : 0u);
+                    pooling && p.mask_out ? (unsigned)((FLAT ? p.B : 1) * co8 * PPL) * 8u : 0u);
         // byte offsets of the lane's pixels (its half of a chunk) inside chunk plane 0 of their image,
         // or the out-of-bounds offset; the chunk plane goes into the instructions' scalar offset
         unsigned ob[TN], ab[TN];
@@ -461,16 +519,18 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
             ob[j] = eok[j] ? opix * osz + (osz >> 1) * lh : OOB;
             ab[j] = eok[j] ? apix * asz + (asz >> 1) * lh : OOB;
         }
-        // fused pool (RECT): the wave's rows are TN / 2 row pairs, lane ^ 1 is the column partner
+        // fused pool (quad pixel order): accumulators (2 jp, 2 jp + 1) are the two rows of a pooling
+        // window, lane ^ 1 its other column; the even lane stores
         unsigned qb[TN / 2], qm[TN / 2];  // byte offsets of the pooled pixel's half chunk / mask dword, or OOB
 #pragma unroll
         for (int jp = 0; jp < TN / 2; ++jp) {
-            const int q_wy = wy0 + wave * TN + 2 * jp, q_wx = wx0 + l31;
+            const int q_wy = ey[2 * jp], q_wx = ex[2 * jp];
             const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
-            const bool q_ok = pooling && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
+            const bool q_ok = pooling && eok[2 * jp] && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
                               q_py < p.pool_H && q_px < p.pool_W;
-            qb[jp] = q_ok ? (unsigned)(q_py * p.pool_W + q_px) * 16u + 8u * lh : OOB;
-            qm[jp] = q_ok ? (unsigned)(q_py * p.pool_W + q_px) * 8u + 4u * lh : OOB;
+            const unsigned qpix = (unsigned)(q_py * p.pool_W + q_px);
+            qb[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8P * PPL) + qpix) * 16u + 8u * lh : OOB;
+            qm[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8 * PPL) + qpix) * 8u + 4u * lh : OOB;
         }
         // Every load of the epilogue first (bias, skip-add; out-of-range pieces get the out-of-bounds
         // offset instead of a branch), then the stores: a buffer load that follows a buffer store in
@@ -571,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), r_out,
                                                                (int)ob[j], so_o, 0);
                 }
-                if constexpr (!FLAT) {
+                {
                     if (pooling && cok) {
                         // 2x2 max-pool of fp32 values + DePool2D mask bits (y & 1) * 2 + (x & 1):
                         // pre == pooled (layers/mylayers.py:111-114), window = rows (j = 0, 1) x
@@ -758,32 +818,35 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restr
     }
 }
 
-constexpr int FLAT_PCAP = 480;
-
-// FLAT tiling: patch rows a 256-pixel tile can need (worst case over tile positions).  Tile t starts
-// at pixel 256 t of the stacked window list; its first / last pixel fix the virtual rows it spans.
-// The start offsets inside an image repeat with period OH*OW / gcd(256, OH*OW) tiles, so at most that
-// many (and never more than the launch has) are looked at; the result is cached per (B, OH, OW).
-int flat_patch_rows(int B, int OH, int OW) {
+// FLAT tiling: patch rows a tile can need (worst case over tile positions).  Row-major: tile t starts
+// at pixel 256 t of the stacked window list; quad: at pooling window 64 t of the stacked list of
+// QH x QW windows per image (its pixels: rows 2 qy, 2 qy + 1).  The first / last unit of a tile fix the
+// virtual rows it spans.  The start offsets inside an image repeat with period units / gcd(step, units)
+// tiles, so at most that many (and never more than the launch has) are looked at; cached.
+int flat_patch_rows(int B, int OH, int OW, bool quad) {
     static std::mutex mu;
-    static std::map<std::tuple<int, int, int>, int> cache;
-    const auto key = std::make_tuple(B, OH, OW);
+    static std::map<std::tuple<int, int, int, int>, int> cache;
+    const auto key = std::make_tuple(B, OH, OW, quad ? 1 : 0);
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = cache.find(key);
         if (it != cache.end()) return it->second;
     }
-    const int64_t ohw = (int64_t)OH * OW, N = (int64_t)B * ohw;
-    const int64_t npt = (N + 255) / 256;
-    int64_t a = 256, b = ohw;
-    while (b) { const int64_t t = a % b; a = b; b = t; }      // gcd(256, OH*OW)
-    const int64_t period = ohw / a;
+    const int UW = quad ? (OW + 1) / 2 : OW;                  // units per row, rows of units per image
+    const int UH = quad ? (OH + 1) / 2 : OH;
+    const int64_t step = quad ? 64 : 256;
+    const int64_t upi = (int64_t)UH * UW, N = (int64_t)B * upi;
+    const int64_t npt = (N + step - 1) / step;
+    int64_t a = step, b = upi;
+    while (b) { const int64_t t = a % b; a = b; b = t; }      // gcd(step, units per image)
+    const int64_t period = upi / a;
     int worst = 0;
     for (int64_t t = 0; t < npt; ++t) {
-        const int64_t n0 = t * 256, n1 = (n0 + 255 < N - 1) ? n0 + 255 : N - 1;
-        const int b0 = (int)(n0 / ohw), r0 = (int)(n0 % ohw);
-        const int b1 = (int)(n1 / ohw), r1 = (int)(n1 % ohw);
-        const int v0 = b0 * (OH + 2) + r0 / OW, v1 = b1 * (OH + 2) + r1 / OW;
+        const int64_t n0 = t * step, n1 = (n0 + step - 1 < N - 1) ? n0 + step - 1 : N - 1;
+        const int b0 = (int)(n0 / upi), r0 = (int)(n0 % upi);
+        const int b1 = (int)(n1 / upi), r1 = (int)(n1 % upi);
+        const int rs = quad ? 2 : 1;                          // pixel rows per unit row
+        const int v0 = b0 * (OH + 2) + rs * (r0 / UW), v1 = b1 * (OH + 2) + rs * (r1 / UW) + (rs - 1);
         if (v1 - v0 + 3 > worst) worst = v1 - v0 + 3;
         if (t >= period && t + 1 < npt) t = npt - 2;   // one full period seen: only the last tile is left
     }
@@ -792,13 +855,38 @@ int flat_patch_rows(int B, int OH, int OW) {
     return worst;
 }
 
+// test hook (iiseg_conv_c8_force_tiling): kind -1 automatic, 0 rect-256, 1 rect-512, 2 flat; th, tw > 0
+// fix the RECT shape (ignored when it cannot run the launch)
+int g_force_kind = -1, g_force_th = 0, g_force_tw = 0;
+
 struct C8Plan {
     bool flat;
-    bool tall;      // RECT with 16-row tiles (TN = 4)
+    bool tall;      // RECT with 512-pixel tiles (TN = 4)
+    bool quad;      // pixels of a tile ordered by 2x2 pooling windows (needed by a fused pool)
+    int th, tw;     // RECT tile shape
     int PR;
 };
 
-int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
+// RECT tile shape for a window: th x tw <= cap pixels (256 or 512) whose (th + 2) x (tw + 2) patch fits
+// C8_PCAP, fewest tiles first, then the widest rows (longer store runs).  `even`: both even (quad order).
+void rect_shape(int OH, int OW, int cap, bool even, int* th_out, int* tw_out, int64_t* tiles_out) {
+    int64_t best = -1;
+    int bth = 0, btw = 0;
+    const int stepw = even ? 2 : 1;
+    for (int tw = even ? 2 : 1; tw <= cap && tw <= ((OW + stepw - 1) / stepw) * stepw; tw += stepw) {
+        int th = cap / tw;
+        if (even) th &= ~1;
+        const int thmax = even ? ((OH + 1) & ~1) : OH;
+        if (th > thmax) th = thmax;
+        while (th > 0 && (th + 2) * (tw + 2) > C8_PCAP) th -= stepw;
+        if (th <= 0) continue;
+        const int64_t tiles = (int64_t)((OH + th - 1) / th) * ((OW + tw - 1) / tw);
+        if (best < 0 || tiles < best || (tiles == best && tw > btw)) { best = tiles; bth = th; btw = tw; }
+    }
+    *th_out = bth; *tw_out = btw; *tiles_out = best;
+}
+
+int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
     if (!d) return IISEG_ERR_NULL;
     if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & IISEG_CONV_TRANSPOSED2))
         return IISEG_ERR_UNSUPPORTED;
@@ -826,48 +914,85 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan) {
     const int nkt = (d->C1 + d->C2) / 16 * (x3 ? 2 : 1);      // packed weight k-tiles
     if ((int64_t)nkt * 18 * mpad * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     if (plan) {
-        // FLAT where a 32-column tiling would leave more than a quarter of its MFMAs on padding and
-        // the whole tensors fit 32-bit offsets; needs a single source
-        const int ty = (d->OH + 7) / 8, tx = (d->OW + 31) / 32;
-        const double fill = (double)d->OH * d->OW / ((double)ty * 8 * tx * 32);
-        plan->flat = false;
-        plan->PR = 0;
-        // 16-row tiles where the window is tall enough that they cost at most 8 % more padded rows
-        // than 8-row tiles and the launch still fills the chip several times over
-        static const int tall_env = getenv("IISEG_C8_TALL") ? atoi(getenv("IISEG_C8_TALL")) : -1;
-        const int r8 = (d->OH + 7) / 8 * 8, r16 = (d->OH + 15) / 16 * 16;
-        const int64_t wgs16 = (int64_t)d->B * (r16 / 16) * tx * ((d->Cout + 63) / 64);
-        plan->tall = r16 * 100 <= r8 * 108 && wgs16 >= 1024;
-        if (tall_env >= 0) plan->tall = tall_env != 0;
+        // Three candidates, priced by a small cost model (per-CU work: tiles are dealt to 256 CUs, a
+        // tile costs its MFMA count plus a fixed set-up / epilogue share measured at about two k-tiles
+        // of a 256-pixel tile, three of a 512-pixel one):
+        //   RECT-256 / RECT-512  th x tw pixel tiles of one image, shape chosen for the fewest tiles
+        //   FLAT                 256 consecutive pixels (64 consecutive pooling windows) of the whole batch:
+        //                        no overhang at all, but a patch of whole window rows -- small windows
+        // A fused pool needs the quad pixel order (even tile shapes / the quad flat list).
+        const bool quad = pool;
         static const int force = getenv("IISEG_C8_TILING") ? atoi(getenv("IISEG_C8_TILING")) : 0;  // 1 rect, 2 flat
-        if ((fill < 0.75 || force == 2) && force != 1 && d->C2 == 0 &&
+        static const int tall_env = getenv("IISEG_C8_TALL") ? atoi(getenv("IISEG_C8_TALL")) : -1;
+        static const char* shape_env = getenv("IISEG_C8_SHAPE");          // "th,tw": tests
+        const int64_t mt = (d->Cout + 63) / 64;
+        auto per_cu = [&](int64_t tiles, double unit) { return (double)((tiles * mt + 255) / 256) * unit; };
+        int th2, tw2, th4, tw4;
+        int64_t n2, n4;
+        rect_shape(d->OH, d->OW, 256, quad, &th2, &tw2, &n2);
+        rect_shape(d->OH, d->OW, 512, quad, &th4, &tw4, &n4);
+        const double c2 = per_cu(n2 * d->B, 2.0 * (nkt + 2.0)), c4 = per_cu(n4 * d->B, 4.0 * nkt + 6.0);
+        plan->flat = false;
+        plan->quad = quad;
+        plan->PR = 0;
+        plan->tall = c4 < c2;
+        if (tall_env >= 0) plan->tall = tall_env != 0;
+        if (g_force_kind == 0 || g_force_kind == 1) plan->tall = g_force_kind == 1;
+        plan->th = plan->tall ? th4 : th2;
+        plan->tw = plan->tall ? tw4 : tw2;
+        {
+            int a = g_force_th, b = g_force_tw;
+            if (shape_env && a <= 0) sscanf(shape_env, "%d,%d", &a, &b);
+            if (a > 0 && b > 0 && (!quad || !((a | b) & 1)) && (a + 2) * (b + 2) <= C8_PCAP && a * b <= 512) {
+                plan->th = a; plan->tw = b; plan->tall = a * b > 256;
+            }
+        }
+        // FLAT: single source, the whole tensors within 32-bit offsets, the patch within the buffer
+        if (force != 1 && g_force_kind != 0 && g_force_kind != 1 && d->C2 == 0 &&
             (int64_t)d->B * cmax * d->H * d->W * 2 < (1ll << 31) &&
             (int64_t)d->B * (octot + 64) * opl * 4 < (1ll << 31) &&
-            (int64_t)d->B * ((int64_t)d->Cout + 64) * d->AH * d->AW * 4 < (1ll << 31)) {
-            const int pr = flat_patch_rows(d->B, d->OH, d->OW);
-            if (pr * (d->OW + 2) <= FLAT_PCAP) {
-                plan->flat = true;
-                plan->tall = false;
-                plan->PR = pr;
+            (int64_t)d->B * ((int64_t)d->Cout + 64) * d->AH * d->AW * 4 < (1ll << 31) &&
+            (!pool || (int64_t)d->B * (d->Cout + 64) * (fullH / 2) * (fullW / 2) * 4 < (1ll << 31))) {
+            const int pr = flat_patch_rows(d->B, d->OH, d->OW, quad);
+            if (pr * (d->OW + 2) <= C8_PCAP) {
+                const int64_t units = quad ? (int64_t)d->B * ((d->OH + 1) / 2) * ((d->OW + 1) / 2)
+                                           : (int64_t)d->B * d->OH * d->OW;
+                const int64_t nf = (units + (quad ? 63 : 255)) / (quad ? 64 : 256);
+                // (its patch is several times a RECT tile's: priced as one more k-tile of set-up)
+                const double cf = per_cu(nf, 2.0 * (nkt + 2.5));
+                const double cr = plan->tall ? c4 : c2;
+                if (cf < cr || force == 2 || g_force_kind == 2) {
+                    plan->flat = true;
+                    plan->tall = false;
+                    plan->PR = pr;
+                }
             }
         }
     }
     return IISEG_OK;
 }
 
+unsigned magic20(int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); }
+
 template <int BM, bool OUTF32>
 int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
     p.n_mtiles = p.Mpad / BM;
-    const int th = plan.tall ? 16 : 8;
+    p.quad = plan.quad ? 1 : 0;
     if (plan.flat) {
-        p.N = p.B * p.OH * p.OW;
+        p.QH = (p.OH + 1) / 2; p.QW = (p.OW + 1) / 2;
+        p.N = plan.quad ? p.B * p.QH * p.QW : p.B * p.OH * p.OW;
         p.PR = plan.PR;
         p.PWs = p.OW + 2;
-        p.n_ptiles = (p.N + 255) / 256;
+        p.n_ptiles = plan.quad ? (p.N + 63) / 64 : (p.N + 255) / 256;
+        p.pw_magic = magic20(p.PWs);
+        p.tw_magic = 0;
     } else {
-        p.tiles_y = (p.OH + th - 1) / th;
-        p.tiles_x = (p.OW + 31) / 32;
+        p.th = plan.th; p.tw = plan.tw;
+        p.tiles_y = (p.OH + p.th - 1) / p.th;
+        p.tiles_x = (p.OW + p.tw - 1) / p.tw;
         p.n_ptiles = p.B * p.tiles_y * p.tiles_x;
+        p.pw_magic = magic20(p.tw + 2);
+        p.tw_magic = magic20(plan.quad ? p.tw / 2 : p.tw);
     }
     const int grid = p.n_ptiles * p.n_mtiles;
 #define C8_LAUNCH(TNV, FL, UN)                                                                     \
@@ -900,12 +1025,30 @@ extern "C" int iiseg_conv_c8_is_flat(const iiseg_conv_desc* d) {
     return plan.flat ? 1 : 0;
 }
 
+extern "C" int iiseg_conv_c8_force_tiling(int kind, int th, int tw) {
+    if (kind < -1 || kind > 2 || th < 0 || tw < 0) return IISEG_ERR_SHAPE;
+    g_force_kind = kind; g_force_th = th; g_force_tw = tw;
+    return IISEG_OK;
+}
+
+extern "C" int iiseg_conv_c8_tiling(const iiseg_conv_desc* d, int pool, int32_t* out4) {
+    C8Plan plan;
+    const int st = c8_check(d, &plan, pool != 0);
+    if (st) return st;
+    if (!out4) return IISEG_ERR_NULL;
+    out4[0] = plan.flat ? 2 : (plan.tall ? 1 : 0);
+    out4[1] = plan.flat ? plan.PR : plan.th;
+    out4[2] = plan.flat ? d->OW + 2 : plan.tw;
+    out4[3] = plan.quad ? 1 : 0;
+    return IISEG_OK;
+}
+
 extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const void* x2,
                              const uint8_t* mask_in, const void* wp16, const float* bias,
                              const void* add, int add_kind, void* out, int out_kind, void* pool_out,
                              uint8_t* mask_out) {
     C8Plan plan;
-    const int st = c8_check(d, &plan);
+    const int st = c8_check(d, &plan, pool_out != nullptr);
     if (st) return st;
     if (!x1 || !wp16) return IISEG_ERR_NULL;
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
@@ -927,9 +1070,9 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     }
     const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
     if (pool_out) {
-        // fused pool: RECT tiling, whole pooling windows (even origin, even extent unless the window
-        // ends at the map's last, unpaired row / column)
-        if (plan.flat || ((d->oy0 | d->ox0) & 1) || ((d->OH & 1) && d->oy0 + d->OH != fullH) ||
+        // fused pool: whole pooling windows (even origin, even extent unless the window ends at the
+        // map's last, unpaired row / column)
+        if (((d->oy0 | d->ox0) & 1) || ((d->OH & 1) && d->oy0 + d->OH != fullH) ||
             ((d->OW & 1) && d->ox0 + d->OW != fullW))
             return IISEG_ERR_UNSUPPORTED;
     }

@@ -175,8 +175,10 @@ class StandardDAE:
             enc = self.enc['conv%d_%d' % (L, self.conv_before_pool)]
             fed_by_h = self.conv_before_pool == 1 and \
                 ('input' if L == 1 else 'pool%d' % (L - 1)) in self.concat_h
-            if not fed_by_h and enc.pool_fusable() and enc.mask_ok() and \
-                    self.dec['up_conv%d' % L].mask_ok():
+            # (the levels of the fp32-NCHW form of `scores`: a Conv built for C8 input answers for the
+            # form that runs on NCHW input)
+            if not fed_by_h and enc.pool_fusable(False) and enc.mask_ok(False) and \
+                    self.dec['up_conv%d' % L].mask_ok(False):
                 levels.add(L)
         return frozenset(levels)
 
@@ -306,7 +308,7 @@ class StandardDAE:
                     # recomputed to the values it already has)
                     pw_ = None
                     if i == self.conv_before_pool and not self.bn:
-                        pw_ = conv.pool_window(t.shape[2], t.shape[3], dep if primed else None)
+                        pw_ = conv.pool_window(t.shape[2], t.shape[3], dep if primed else None, c8=False)
                     if pw_ is not None:
                         fh, fw = conv.out_hw(t.shape[2], t.shape[3])
                         if primed:

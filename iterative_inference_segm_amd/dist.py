@@ -19,6 +19,10 @@ import torch.distributed as dist
 def init_from_env(device_type=None):
     """One process per GPU; reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
     Returns (rank, world, device)."""
+    # dmabuf IPC only on this pool: RCCL's / torch's cross-process buffer sharing fails with
+    # `hipIpcGetMemHandle: invalid argument` without it.  Set here, before the first HIP call of the
+    # process, so that a launch line the caller wrote (torch.distributed.run directly) gets it too.
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -37,10 +41,22 @@ def init_from_env(device_type=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = os.environ.get('IISEG_DIST_BACKEND',
                                  'nccl' if device_type == 'cuda' else 'gloo')  # 'nccl' = RCCL on ROCm
-        if backend == 'nccl':
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            if backend == 'nccl':
+                if torch.cuda.device_count() <= local:
+                    raise RuntimeError('rank %d wants device %d, %d visible (RCCL needs one device '
+                                       'per rank)' % (rank, local, torch.cuda.device_count()))
+                dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                        device_id=device)
+            else:
+                dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        except Exception as e:       # never retried, never re-exec'd: the launcher sees a failed rank
+            import sys
+            sys.stderr.write('iiseg.dist: %s init failed on rank %d / %d: %r\n'
+                             % (backend, rank, world, e))
+            sys.stderr.flush()
+            raise SystemExit(3)
+        _STATE['device'] = device if backend == 'nccl' else None
     return rank, world, device
 
 
@@ -49,9 +65,18 @@ def shard_batches(n_batches, rank, world):
     return list(range(rank, n_batches, world))
 
 
+_STATE = {'device': None}      # the rank's GPU when the backend is RCCL
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        dev = _STATE['device']
+        if dev is not None:
+            # RCCL: name the device, or the barrier's hidden all-reduce picks "the current one" by a
+            # heuristic (and warns); gloo takes no device_ids
+            dist.barrier(device_ids=[dev.index])
+        else:
+            dist.barrier()
 
 
 class EvalAccumulator:

@@ -139,7 +139,7 @@ class FCN8:
                     kw.update(window=dep, out=session[name], place=(dep[0], dep[1]))
                 if name == names[-1] and pending is None:
                     # last conv of the block on the halo kernel: the pool rides in its epilogue
-                    pw_ = conv.pool_window(t.shape[2], t.shape[3], dep if primed else None)
+                    pw_ = conv.pool_window(t.shape[2], t.shape[3], dep if primed else None, c8=c8)
                     if pw_ is not None:
                         if primed:
                             fused_pool = session['pool%d' % (bi + 1)]
@@ -261,6 +261,8 @@ class FCN8DAE:
         assert all(el in ['pool1', 'pool2', 'pool3', 'pool4', 'input'] for el in concat_h)  # :33-34
         self.concat_h = list(concat_h)
         # (the concat points of this kind are two-source gathers: fp32 NCHW activations)
+        # (a default taken from ops.DEFAULT_MMA -- `--mma bf16c8` / IISEG_MMA -- maps the same way)
+        mma = mma or ops.DEFAULT_MMA
         self.net = FCN8(params, n_classes, layer=['score'], pad=pad, device=device, dtype=dtype,
                         mma={'bf16c8': 'bf16', 'bf16x3': 'f32'}.get(mma, mma))
         self.net.fold_border = False       # the border depends on h here: sessions only

@@ -16,6 +16,9 @@ from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2
 # When set to a list, every conv launch appends (kernel, executed_flops, start_event, end_event):
 # HIP events recorded on the launch stream right around the kernel (bench.py's roofline leg).
 CONV_PROFILE = None
+# With CONV_PROFILE: when set to a list, every C8 launch also appends its geometry (one dict per launch,
+# same order as the 'conv_c8_kernel' entries of CONV_PROFILE) -- scripts/c8_step_profile.py
+CONV_PROFILE_INFO = None
 
 _SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
 
@@ -91,6 +94,7 @@ BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
 BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '256'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
 _wino_ws64 = {}
+_bn_ws = {}     # device -> BN partial-sum workspace (stream-ordered reuse)
 
 
 # Scratch is reused by consecutive launches of ONE stream (stream-ordered).  Engines that run
@@ -125,6 +129,18 @@ def _wino_workspace(n, device):
         _wino_ws[key] = None
         ws = _wino_ws[key] = torch.empty(int(n), dtype=torch.float32, device=device)
     return ws
+
+
+def workspace_refs(device):
+    """The scratch tensors launches under the current workspace tag point into (fp32 / float64
+    Winograd workspaces, BN partial sums): a captured HIP graph keeps them alive."""
+    key = _ws_key(device)
+    return tuple(c.get(key) for c in (_wino_ws, _wino_ws64, _bn_ws))
+
+
+def workspace_ptrs(device):
+    """Their device addresses (None where not allocated): part of what a captured graph is valid for."""
+    return tuple(None if t is None else t.data_ptr() for t in workspace_refs(device))
 
 
 def _ev():
@@ -331,7 +347,7 @@ class Conv:
         masked = mask_in is not None or mask_out is not None
         B, C1 = x1.shape[0], x1.shape[1]
         if masked:
-            if not self.mask_ok():
+            if not self.mask_ok(False):
                 raise RuntimeError('DePool2D byte masks need a halo-kernel layer (Conv.mask_ok)')
             if mask_in is not None and (pre is not None or mask_in.dtype != torch.uint8 or
                                         mask_in.shape != x1.shape or unpool_hw is None or
@@ -545,32 +561,36 @@ class Conv:
             prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
         return out
 
-    def pool_fusable(self):
-        """True if this layer runs on a halo kernel whose epilogue can do the 2x2 max-pool."""
+    def pool_fusable(self, c8=None):
+        """True if this layer runs on a halo kernel whose epilogue can do the 2x2 max-pool.  `c8`:
+        whether the call will hand it a C8 tensor (None: the form the layer was built for) -- a
+        layer built with mma='bf16c8' and called on fp32 NCHW input runs the 'bf16' forms, and
+        those decide."""
         if not POOL_FUSE or self.dtype != torch.float32:
             return False
-        if self.c8:
+        if self.c8 and c8 is not False:
             return True
         if self.mma == 'bf16':
             return self.halo_bf16
         return not (self.wino or self.kernel != 'conv_halo_f32_kernel' or not 16 < self.Cout < 256)
 
-    def mask_ok(self):
+    def mask_ok(self, c8=None):
         """True if this layer can take / produce DePool2D masks as bytes (halo kernels only, and
-        only where the byte form runs the very kernel the pre / pooled form runs)."""
-        if self.c8:
+        only where the byte form runs the very kernel the pre / pooled form runs).  `c8` as in
+        `pool_fusable`."""
+        if self.c8 and c8 is not False:
             return True
         if self.dtype != torch.float32 or (self.KH, self.KW) != (3, 3) or self.dil != 1 or \
                 self.transposed or self.kernel != 'conv_halo_f32_kernel' or self.wino_bf16:
             return False
         return self.halo_bf16 if self.mma == 'bf16' else not self.wino
 
-    def pool_window(self, H, W, region=None):
+    def pool_window(self, H, W, region=None, c8=None):
         """If the 2x2 max-pool that follows this layer can be fused into its epilogue: the conv
         window (y0, x0, h, w) to launch so that every pooling window touching `region` (of the
         conv output; None = the whole map) is whole -- even origin, even extent unless it ends at
         the map's last row / column.  None if the layer does not run on the halo kernel."""
-        if not self.pool_fusable():
+        if not self.pool_fusable(c8):
             return None
         fh, fw = self.out_hw(H, W)
         if region is None:
@@ -582,6 +602,12 @@ class Conv:
         if region[1] + region[3] == fw:
             x1 = fw
         return (y0, x0, y1 - y0, x1 - x0)
+
+    def c8_tiling(self, d, pool):
+        """(kind, th, tw, quad) of a C8 launch: include/iiseg.h iiseg_conv_c8_tiling."""
+        t = (C.c_int32 * 4)()
+        check(self.lib.iiseg_conv_c8_tiling(C.byref(d), 1 if pool else 0, t), 'iiseg_conv_c8_tiling')
+        return tuple(t)
 
     def _call_c8(self, x1, x2, add, add_off, window, out, place, pool_out, mask_in, unpool_hw,
                  mask_out, store_out, out_format):
@@ -690,20 +716,9 @@ class Conv:
                   'iiseg_conv_halo_bf16_pack')
             del Wsrc
         dtp = lambda t: None if t is None else _ptr(t, t.dtype)
-        flat_pool = pool_out is not None and bool(lib.iiseg_conv_c8_is_flat(C.byref(d)))
-        tmp = None
-        if flat_pool:
-            # flat pixel tiling (small windows; no fused pool): the conv stores its window as fp32
-            # chunks, a second kernel takes max and mask bits from those -- the very comparisons of
-            # the fused epilogue, so a level's masks do not depend on the tiling its conv ran on
-            if store_out:
-                raise RuntimeError('a flat-tiled C8 layer pools from a private fp32 copy of its '
-                                   'window: call it with store_out=False')
-            tmp = torch.empty((B, oc8, OH, OW, 8), dtype=torch.float32, device=x1.device)
-            d.out_H = d.out_W = d.out_y0 = d.out_x0 = 0
-            conv_out, conv_kind, conv_pool, conv_mask = tmp, 2, None, None
-        else:
-            conv_out, conv_kind, conv_pool, conv_mask = out, kind, pool_out, mask_out
+        # (the pool rides in the conv's epilogue on every pixel tiling: with pool_out the pixels of a
+        # tile are ordered by 2x2 pooling windows)
+        conv_out, conv_kind, conv_pool, conv_mask = out, kind, pool_out, mask_out
         prof = CONV_PROFILE
         ev0 = _ev() if prof is not None else None
         check(lib.iiseg_conv_c8(_stream(), C.byref(d), dtp(x1), dtp(x2), dtp(mask_in),
@@ -712,10 +727,11 @@ class Conv:
         if prof is not None:
             prof.append(('conv_c8_kernel<x3>' if x3 else 'conv_c8_kernel', self.flops(B, OH, OW), ev0,
                          _ev()))
-        if flat_pool:
-            pool_mask_c8(tmp, pool_out, mask_out, (oy0, ox0), (fullH, fullW),
-                         (oy0 // 2, ox0 // 2, min((oy0 + OH) // 2, fullH // 2) - oy0 // 2,
-                          min((ox0 + OW) // 2, fullW // 2) - ox0 // 2), x3=x3)
+            if CONV_PROFILE_INFO is not None:
+                CONV_PROFILE_INFO.append(dict(
+                    Cin=self.Cin, Cout=self.Cout, C1=d.C1, C2=d.C2, H=H, W=W, OH=OH, OW=OW, B=B,
+                    unpool=unpool, pool=pool_out is not None, add=add_kind, kind=conv_kind,
+                    flat=self.c8_tiling(d, pool_out is not None)))
         return out
 
     def _call_halo_bf16(self, d, x1, x2, pre, pooled, add, out, pool_out, mask_in, mask_out, prof,
@@ -1110,7 +1126,6 @@ def confusion_accumulate(y, t, cm, sums, active=None):
                                _ptr(sums, torch.float64), B, Cc, H * W), 'iiseg_confusion')
 
 
-_bn_ws = {}   # device -> partial-sum workspace (stream-ordered reuse)
 
 
 def bn_stats(buf, c0, n, mean, inv_std, eps=1e-4):

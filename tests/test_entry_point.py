@@ -161,3 +161,26 @@ def test_valid_driver_per_iteration_jaccard(built_lib, tmp_path):
     assert np.allclose(res, ref, atol=2e-3, equal_nan=True)
     saved = tmp_path / 's' / 'camvid'
     assert any(f.name.startswith('iterations0.3') for f in saved.rglob('*.npz'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['fcn8', 'contextmod'])
+def test_default_mma_bf16c8_with_the_non_standard_dae_kinds(built_lib, tmp_path, monkeypatch, kind):
+    """`--mma bf16c8` / IISEG_MMA=bf16c8 with the entry point's DEFAULT dae kind ('fcn8', reference
+    iterative_inference.py:64-77) and with 'contextmod': these DAEs keep fp32 NCHW activations, so
+    their layers -- built under a C8 default -- must answer pool / mask fusion questions for the
+    form that actually runs.  The evaluation runs and agrees with the f32 default
+    run within the 16-bit mode's statistical tolerance (mIoU +-0.05)."""
+    import iterative_inference as ii
+    from iterative_inference_segm_amd import ops as _ops
+    dd = {'kind': kind, 'concat_h': ['input']}
+    res = {}
+    for mma in ('f32', 'bf16c8'):
+        monkeypatch.setattr(_ops, 'DEFAULT_MMA', mma)
+        out = ii.inference('camvid', 'fcn8', 0.1, 2, dae_dict_updates=dd,
+                           savepath=str(tmp_path / ('s' + mma)), loadpath=str(tmp_path / ('l' + mma)),
+                           weights_path=str(tmp_path / 'w'), synthetic=True, n_images=2,
+                           image_size=(64, 48), batch_size=2, verbose=False, save_npz=False)
+        res[mma] = out['ii']
+        assert out['ii']['batches'] == 1 and np.isfinite(out['ii']['loss'])
+    assert abs(res['bf16c8']['jaccard'] - res['f32']['jaccard']) <= 0.05

@@ -19,6 +19,22 @@ def ops(built_lib):
     return _ops
 
 
+# Pixel tilings forced through the test hook iiseg_conv_c8_force_tiling (kind, th, tw): automatic;
+# 256- / 512-pixel tiles in the shape the planner picks; the flat list; and fixed tile shapes (a forced
+# shape the launch cannot use -- odd with a fused pool, patch too large -- falls back to the planner's).
+TILINGS = [(-1, 0, 0), (0, 0, 0), (1, 0, 0), (2, 0, 0), (-1, 8, 32), (-1, 16, 32), (-1, 6, 38),
+           (-1, 13, 38), (-1, 10, 22), (-1, 2, 116), (-1, 34, 6)]
+
+
+@pytest.fixture(params=TILINGS, ids=lambda t: 'auto' if t == (-1, 0, 0) else 'k%d_%dx%d' % t)
+def tiling(request, built_lib):
+    from iterative_inference_segm_amd import _lib
+    lib = _lib.load()
+    assert lib.iiseg_conv_c8_force_tiling(*request.param) == 0
+    yield request.param
+    assert lib.iiseg_conv_c8_force_tiling(-1, 0, 0) == 0
+
+
 def host(t):
     torch.cuda.synchronize()
     return t.float().cpu().numpy() if t.dtype == torch.bfloat16 else t.cpu().numpy()
@@ -68,7 +84,7 @@ CASES = [  # B, Cin, H, W, Cout, pad, relu, window
 
 
 @pytest.mark.parametrize('case', CASES)
-def test_conv_c8_exact_on_integer_data(ops, case):
+def test_conv_c8_exact_on_integer_data(ops, case, tiling):
     B, Cin, H, W, Cout, pad, relu, window = case
     rng = np.random.default_rng(sum(case[:6]))
     x = ints(rng, B, Cin, H, W) if Cin < 32 else ints(rng, B, Cin, H, W, lo=-2, hi=3)
@@ -87,7 +103,7 @@ def test_conv_c8_exact_on_integer_data(ops, case):
     assert not got[:, Cout:].any()                    # padding channels stay zero
 
 
-def test_conv_c8_placement_and_skip_add(ops):
+def test_conv_c8_placement_and_skip_add(ops, tiling):
     rng = np.random.default_rng(5)
     B, Cin, Cout, H, W = 2, 32, 64, 30, 41
     x = ints(rng, B, Cin, H, W)
@@ -112,7 +128,7 @@ def test_conv_c8_placement_and_skip_add(ops):
     assert np.array_equal(a, ref)
 
 
-def test_conv_c8_class_score_layer_nchw_output(ops):
+def test_conv_c8_class_score_layer_nchw_output(ops, tiling):
     rng = np.random.default_rng(6)
     B, Cin, H, W = 2, 64, 21, 37
     x = ints(rng, B, Cin, H, W, lo=-2, hi=3)
@@ -142,8 +158,8 @@ def mask_from_c8(m):
     return a.transpose(0, 1, 4, 2, 3).reshape(B, C8 * 8, H, W)
 
 
-@pytest.mark.parametrize('shape', [(2, 32, 38, 45, 64), (4, 32, 15, 15, 64)])   # RECT fused / FLAT + pool kernel
-def test_conv_c8_pool_and_mask_bytes(ops, shape):
+@pytest.mark.parametrize('shape', [(2, 32, 38, 45, 64), (4, 32, 15, 15, 64), (3, 16, 26, 20, 128)])
+def test_conv_c8_pool_and_mask_bytes(ops, shape, tiling):
     B, Cin, H, W, Cout = shape
     rng = np.random.default_rng(H)
     x = ints(rng, B, Cin, H, W, lo=-2, hi=3)
@@ -168,7 +184,7 @@ def test_conv_c8_pool_and_mask_bytes(ops, shape):
 
 
 @pytest.mark.parametrize('shape', [(2, 32, 37, 44, 64), (6, 64, 13, 13, 32)])   # RECT / FLAT
-def test_conv_c8_depool_input_from_mask_bytes(ops, shape):
+def test_conv_c8_depool_input_from_mask_bytes(ops, shape, tiling):
     """DePool2D (layers/mylayers.py:88-115) as the conv's input staging: up (C8) + mask bytes."""
     B, Cin, H, W, Cout = shape
     rng = np.random.default_rng(W)
@@ -262,12 +278,23 @@ def test_c8_engine_close_to_float64(built_lib):
     assert np.abs(out['c8'][2] - out['f64'][2]).max() <= 5e-2
 
 
-def test_conv_c8_random_geometries(ops):
+@pytest.mark.parametrize('force', [(-1, 0, 0), (1, 0, 0), (2, 0, 0)], ids=['auto', 'rect512', 'flat'])
+def test_conv_c8_random_geometries(ops, force):
     """40 seeded random launches of iiseg_conv_c8 against the oracle, bit for bit on integer data:
     random channel counts (multiples of 16 in, multiples of 8 out), map sizes from 5 to 70, paddings 1
     to 6, batch 1 to 9, full maps and random windows with placement into a larger tensor, with and
     without skip-add (both formats), ReLU, DePool2D input, fused pool (where the window allows it).
-    Both pixel tilings come up (the flat one whenever a 32-column tiling would be < 75 % full)."""
+    Every pixel tiling comes up: the planner's choice, and the 512-pixel tiles / the flat list forced
+    wherever they can run the launch (the fused pool then runs on pooling-window-ordered tiles of each)."""
+    from iterative_inference_segm_amd import _lib
+    assert _lib.load().iiseg_conv_c8_force_tiling(*force) == 0
+    try:
+        _random_geometries(ops, force)
+    finally:
+        assert _lib.load().iiseg_conv_c8_force_tiling(-1, 0, 0) == 0
+
+
+def _random_geometries(ops, force):
     rng = np.random.default_rng(2024)
     n_flat = 0
     for case in range(40):
@@ -350,8 +377,8 @@ def test_conv_c8_random_geometries(ops):
                                       pooled[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'pool')
                 assert np.array_equal(gm[:, :, qy0:qy0 + qh, qx0:qx0 + qw],
                                       bits[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'mask')
-    print('random C8 launches: %d of 40 on the flat tiling' % n_flat)
-    assert 5 <= n_flat <= 38
+    print('random C8 launches: %d of 40 on the flat tiling (%s)' % (n_flat, force))
+    assert (1 <= n_flat <= 39) if force[0] == -1 else (n_flat == 0) if force[0] == 1 else n_flat >= 20
 
 
 DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 k-tiles: the deep layers)

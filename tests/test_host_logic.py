@@ -145,6 +145,66 @@ def test_synthetic_data_contract():
     assert np.allclose(k, k.T) and np.allclose(k[0], [0.0625, 0.1875, 0.1875, 0.0625])
 
 
+@pytest.mark.parametrize('world', [8])
+def test_bench_dry_run_world_size_8(world):
+    """The N=8 launch line of the driver, rehearsed on CPU (gloo): 8 ranks rendezvous on 127.0.0.1,
+    barrier-bracketed timing with max over ranks, the one metric all-reduce, ONE JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                        '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+                        '--master-port', '29691', os.path.join(ROOT, 'bench.py'), '--gpus', str(world),
+                        '--dry-run', '--steps', '2', '--warmup', '1'], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == world and out['batches_reduced'] == 2 * world
+
+
+def test_entry_point_dry_run_world_size_8(tmp_path):
+    """iterative_inference.py under 8 ranks (gloo, --dry_run): 20 reference batches shard 3/3/3/3/2/2/2/2,
+    one all-reduce puts all 20 into rank 0's summary."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8',
+           '--master-addr', '127.0.0.1', '--master-port', '29693',
+           os.path.join(ROOT, 'iterative_inference.py'), '--synthetic', '--dry_run', '--n_images', '40',
+           '--batch_size', '2', '--image_size', '32', '40', '-step', '0.1', '--num_iter', '3',
+           '-dae_dict', '{"kind": "standard", "concat_h": ["pool4"], "additional_pool": 2, '
+                        '"unpool_type": "trackind", "skip": true}',
+           '--savepath', str(tmp_path / 'save'), '--loadpath', str(tmp_path / 'load')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count('>>>>> ITERATIVE INFERENCE:') == 1
+    assert 'DRY RUN: 8 ranks, 20 batches reduced, rank 0 owned [0, 8, 16]' in r.stdout
+
+
+def test_rccl_init_failure_exits_nonzero_with_the_error_text():
+    """A rank whose process group cannot come up (here: the RCCL backend on a box without a GPU for
+    it) must exit non-zero with the error on stderr -- no retry, no re-exec."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(WORLD_SIZE='2', RANK='0', LOCAL_RANK='7', MASTER_ADDR='127.0.0.1', MASTER_PORT='29695',
+               IISEG_DIST_BACKEND='nccl')
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from iterative_inference_segm_amd import dist as d\n"
+            "torch.cuda.set_device = lambda *_: None\n"
+            "d.init_from_env('cuda')\n" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and 'init failed on rank 0 / 2' in r.stderr
+    import os as _os
+    assert _os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0') == '0'
+
+
 def test_bench_self_launches_two_ranks_dry_run():
     """`python bench.py --gpus 2` outside a torch.distributed environment must fan out to two
     workers by itself (the parent never touches the GPU), reduce over both ranks and print ONE
