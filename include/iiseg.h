@@ -301,6 +301,31 @@ int iiseg_conv_c8_force_tiling(int kind, int th, int tw);
 int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const void* x2,
                   const uint8_t* mask_in, const void* wp16, const float* bias, const void* add,
                   int add_kind, void* out, int out_kind, void* pool_out, uint8_t* mask_out);
+/* The same layer for AT MOST 16 OUTPUT CHANNELS (csrc/conv_c8_m16.hip: v_mfma_f32_16x16x32_bf16, M = 16
+ * channels, 16-pixel blocks, 256-pixel th x tw tiles, three workgroups per CU): the DAE's class-score
+ * layer (models/fcn_up.py:83-86) and FC-DenseNet's growth-rate-16 dense-block layers
+ * (models/FCDenseNet.py:61-146).  Single source (d->C2 == 0), d->C1 = the channels convolved (a multiple
+ * of 16): the FIRST d->C1 channels of x1, a C8 tensor of in_ctot >= d->C1 channels per image (0: d->C1).
+ *   mask_in     with IISEG_CONV_UNPOOL, as in iiseg_conv_c8
+ *   bn_a, bn_b  both NULL, or d->C1 floats each: BatchNorm + ReLU applied to the input while it is staged,
+ *               x <- max(bn_a[c] x + bn_b[c], 0) rounded to bf16 (iiseg_bn_fold_f32 makes the pair from
+ *               beta, gamma, mean, inv_std); the zero-padding ring stays zero
+ *   out         out_kind 1: C8 bf16, the 16 channels [out_c0, out_c0 + 16) of a (B, out_ctot / 8, out_H,
+ *               out_W, 8) tensor (out_ctot 0: a dense 16-channel tensor), channels past Cout zero;
+ *               out_kind 3: fp32 NCHW (B, out_ctot or Cout, out_H, out_W)
+ * weights: iiseg_conv_halo_bf16_pack for this Cout (rows padded to 32).  No add, no pool.
+ * iiseg_bn_stats_c8: batch statistics (mean, 1 / sqrt(biased var + eps); P10) of channels [c0, c0 + n) of
+ * a C8 tensor of Ctot channels (all multiples of 8), two deterministic stages in double; workspace:
+ * iiseg_bn_stats_c8_workspace_elems(n) doubles, caller-owned. */
+int iiseg_conv_c8_m16_supported(const iiseg_conv_desc* d);
+int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
+                      const uint8_t* mask_in, const float* bn_a, const float* bn_b, const void* wp16,
+                      const float* bias, void* out, int out_kind);
+int iiseg_bn_fold_f32(void* stream, const float* beta, const float* gamma, const float* mean,
+                      const float* inv_std, float* a, float* b, int n);
+int64_t iiseg_bn_stats_c8_workspace_elems(int n);
+int iiseg_bn_stats_c8(void* stream, const void* x, int B, int Ctot, int c0, int n, int H, int W,
+                      double eps, float* mean, float* inv_std, double* workspace);
 int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
 int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8n);
 int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled, uint8_t* mask,

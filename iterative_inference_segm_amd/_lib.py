@@ -82,6 +82,11 @@ SIGNATURES = {
     'iiseg_conv_c8_force_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'iiseg_conv_c8_tiling': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int32)]),
     'iiseg_conv_c8': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 6 + [_i32, _vp, _i32, _vp, _vp]),
+    'iiseg_conv_c8_m16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_c8_m16': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 6 + [_i32]),
+    'iiseg_bn_fold_f32': (C.c_int, [_vp] * 7 + [_i32]),
+    'iiseg_bn_stats_c8_workspace_elems': (C.c_int64, [_i32]),
+    'iiseg_bn_stats_c8': (C.c_int, [_vp, _vp] + [_i32] * 6 + [C.c_double, _vp, _vp, _vp]),
     'iiseg_nchw_to_c8': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8': (C.c_int, [_vp, _vp, _i32, _vp, _vp] + [_i32] * 11),

@@ -32,6 +32,7 @@
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
+#include "c8_common.h"
 
 using namespace iiseg;
 
@@ -112,22 +113,36 @@ struct C8Params {
 // x_lo W_hi, x_hi W_lo, x_hi W_hi, into ONE fp32 accumulation (the dropped x_lo W_lo term is 2^-18
 // relative).  Same MFMA loop, same tiles, same epilogue; outputs / skip addends / pooled maps of
 // kind 1 are hi / lo pairs, the DePool2D masks and the pool still come from the fp32 accumulators.
-template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3>
-__global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
+//
+// NBUF: stages of the LDS ring.  2 = the pipelined form; 1 = layers with ONE k-tile (16 input channels:
+// the first layers of both nets), where a second stage would never be filled -- half the LDS and, with
+// 256-pixel tiles, few enough registers for three workgroups per CU instead of two (these layers are
+// bound by latency and instruction issue around their 36 MFMAs, not by the matrix pipe).
+//
+// NW: waves per workgroup.  4 = the forms above; 8 (with TN = 2: again 512 pixels per workgroup, the
+// weights of a k-tile shared by eight waves) halves the work and the registers of a wave against the
+// TN = 4 form at the same LDS, so that FOUR waves share a SIMD instead of two: the shallow layers are
+// bound by what happens around their few k-tiles (prologue, DMA round trip, pool / mask epilogue) and
+// more resident waves fill those gaps.
+template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? 3 : 2)) void conv_c8_kernel(const C8Params p) {
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
+    static_assert(NW == 4 || (NW == 8 && TN == 2 && !FLAT), "eight waves: 512-pixel rect tiles");
+    constexpr int NT = 64 * NW;
+    static_assert(NBUF == 2 || (!X3 && !UNPOOL), "single-stage form: plain one-k-tile layers");
     // patch buffer: C8_PCAP chunks per 8-channel half, staged as up to NE rounds of 256 chunks (a
     // wave issues only the pieces that hold patch chunks: wave-uniform test)
-    constexpr int NE = C8_NE;
-    constexpr int NCHK = NE * 256;
+    constexpr int NCHK = C8_NE * 256;
+    constexpr int NE = (NCHK + NT - 1) / NT;
     constexpr int TM = BM / 32;
     constexpr int WCH = 18 * BM;                             // weight chunks per k-tile
-    constexpr int WPT = (WCH + 255) / 256;
+    constexpr int WPT = (WCH + NT - 1) / NT;
     static_assert(WCH % 64 == 0, "a wave's DMA piece is whole");
 
     // ONE LDS array: weight ring Ws[2][WCH], patch ring Ps[2][NCHK]
-    __shared__ __attribute__((aligned(16))) uint4 smem[2 * WCH + 2 * NCHK];
+    __shared__ __attribute__((aligned(16))) uint4 smem[NBUF * WCH + NBUF * NCHK];
     uint4 (*Ws)[WCH] = reinterpret_cast<uint4 (*)[WCH]>(smem);
-    uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + 2 * WCH);
+    uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + NBUF * WCH);
 
     int pt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     // piece i of this wave holds chunks [i * 256 + wave * 64, + 64): staged only if the patch reaches it
     bool piece[NE];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) piece[i] = i * 256 + wave_u * 64 < 2 * half;
+    for (int i = 0; i < NE; ++i) piece[i] = i * NT + wave_u * 64 < 2 * half;
 
     // ---- patch staging offsets: chunk e = i * 256 + tid -> (half h, patch row, patch column) ----
     unsigned voff[NE];                 // byte offset of the chunk in its source (k-tile 0), or OOB
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     int bsel[UNPOOL ? NE : 1];         // UNPOOL: bit (y & 1) * 2 + (x & 1) of the mask byte
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int e = i * 256 + tid;
+        const int e = i * NT + tid;
         const int h = e >= half ? 1 : 0;
         const int rr = e - h * half;
         const int prow = (int)(((unsigned)rr * p.pw_magic) >> 20), pcol = rr - prow * PWs;   // rr / PWs
@@ -279,13 +294,24 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         }
     }
 
+    // The accumulators start from the bias (C/D layout of the 32x32 MFMA: register r of a lane is
+    // channel (r & 3) + 8 (r >> 2) + 4 lh of its 32-channel block; channels past Cout read 0): the
+    // epilogue has no bias pass, and these loads return under the first DMA wait.
     f32x16 acc[TM][TN];
+    {
+        const __amdgpu_buffer_rsrc_t r_bias0 = mk_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    r_bias0, (int)(4u * (unsigned)(m0 + i * 32 + g * 8 + 4 * lh)), 0, 0));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][j][g * 4 + q] = bv[q];
+            }
+    }
 
     // A staging step moves the 16 channels that start at chunk KC of the source (tile-uniform: C1 % 16
     // == 0; chunks >= CC1 are the second source of a concat) and the packed weight k-tile WT.
@@ -300,14 +326,14 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             if (piece[i])                                                                          \
-                dma16(s1 ? s_x1 : s_x2, lds_p + (unsigned)((BUF) * NCHK + i * 256) * 16u, voff[i], so_u); \
+                dma16(s1 ? s_x1 : s_x2, lds_p + (unsigned)((BUF) * NCHK + i * NT) * 16u, voff[i], so_u); \
         });                                                                                        \
     }
     // weights of packed k-tile WT, channels [m0, m0 + BM): rows (tap, h) of BM chunks each
     unsigned woff[WPT];
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        const int f = j * 256 + tid;
+        const int f = j * NT + tid;
         woff[j] = f < WCH ? 16u * (unsigned)((f / BM) * p.Mpad + m0 + f % BM) : OOB;
     }
 #define C8_DMA_W(WT, BUF)                                                                          \
@@ -315,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((WT) * 18 * p.Mpad) * 16u); \
         static_for<0, WPT>([&](auto J) __attribute__((always_inline)) {                            \
             constexpr int j = decltype(J)::value;                                                  \
-            if ((j + 1) * 256 <= WCH || j * 256 + wave * 64 < WCH)                                 \
-                dma16(s_w, lds_w + (unsigned)((BUF) * WCH + j * 256) * 16u, woff[j], so_w);        \
+            if ((j + 1) * NT <= WCH || j * NT + wave * 64 < WCH)                                   \
+                dma16(s_w, lds_w + (unsigned)((BUF) * WCH + j * NT) * 16u, woff[j], so_w);         \
         });                                                                                        \
     }
     // UNPOOL: up chunk (chunk KC of `up`) + mask bytes (chunk KM of the mask) into registers, selected
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const unsigned som = (unsigned)((KM) * hw2) * 8u;                                          \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
-            if (piece[i]) {                                                                        \
+            if (i < 3 || piece[i]) {   /* (no branch around the pieces every launch has) */       \
                 xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(           \
                     r_x1, (int)voff[i], (int)so, 0));                                              \
                 xm[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(            \
@@ -340,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 #define C8_STORE_U(BUF)                                                                            \
     static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
         constexpr int i = decltype(I)::value;                                                      \
-        if (!piece[i]) return;                                                                     \
+        if (i >= 3 && !piece[i]) return;                                                           \
         /* byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j.  The four  \
            bits of a dword become four 0x00 / 0xff bytes (t * 255 without a multiply), v_perm_b32   \
            doubles each byte into the 16-bit lane of its channel */                                 \
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         v.y = xu[i][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);                               \
         v.z = xu[i][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);                               \
         v.w = xu[i][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);                               \
-        if (i * 256 + tid < 2 * half) Ps[BUF][i * 256 + tid] = v;                                  \
+        if (i * NT + tid < 2 * half) Ps[BUF][i * NT + tid] = v;                                    \
     });
 
     // The k-loop.  Plain: step kt = k-tile kt, both rings alternate (buffer kt & 1), the step's top
@@ -458,7 +484,6 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
     // C/D layout of the 32x32 MFMA: column = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * lh:
     // register group g = r >> 2 holds channels 8 g + 4 lh + (0..3) = one half of chunk g.
     if ((p.debug & 8) && acc[0][0][0] != 12345.f) return;
-    const __amdgpu_buffer_rsrc_t r_bias = mk_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
     const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
     const int ib = FLAT ? 0 : tb;                 // image folded into the descriptor base (RECT)
     if constexpr (OUTF32) {
@@ -467,11 +492,6 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
         const __amdgpu_buffer_rsrc_t r_out =
             mk_rsrc((const char*)p.out + (size_t)ib * p.out_ctot * OPL * 4,
                     (unsigned)((FLAT ? p.B : 1) * p.out_ctot * OPL) * 4u);
-        float bv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                r_bias, (int)(4u * (unsigned)(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh)), 0, 0));
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const unsigned o0 = (unsigned)((eb[j] * p.out_ctot + p.out_c0) * OPL +
@@ -479,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float v = acc[0][j][r] + bv[r];
+                float v = acc[0][j][r];
                 if (p.relu) v = fmaxf(v, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(
                     __builtin_bit_cast(int, v), r_out,
@@ -543,15 +563,12 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
 #pragma unroll
         for (int ig = 0; ig < TM * (4 / GH); ++ig) {
             const int i = ig / (4 / GH), g0 = (ig % (4 / GH)) * GH;
-            f32x4 bvs[4];
             u32x4 adr[4][TN];                 // raw addend pieces (bf16 hi [, lo] halves or 4 floats)
 #pragma unroll
             for (int g = g0; g < g0 + GH; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;
                 const bool cok = c8 < co8;             // wave-uniform: chunks past the padded channels
                 const int so_a = (int)((unsigned)(c8 * APL) * asz);
-                bvs[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                    r_bias, (int)(4u * (unsigned)(c8 * 8 + 4 * lh)), 0, 0));
                 if (cok && has_add1) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
@@ -598,13 +615,12 @@ __global__ __launch_bounds__(256, 2) void conv_c8_kernel(const C8Params p) {
             for (int g = g0; g < g0 + GH; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;            // chunk of the output channels
                 const bool cok = c8 < co8;
-                const f32x4 bv = bvs[g];
                 f32x4 v[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[j][q] = acc[i][j][g * 4 + q] + bv[q];
-                    v[j] += addv[g][j];
+                    for (int q = 0; q < 4; ++q) v[j][q] = acc[i][j][g * 4 + q];
+                    if (has_add1 || has_add2) v[j] += addv[g][j];     // (wave-uniform)
                     // (ReLU without a branch per piece: max with 0 or with -inf)
                     v[j][0] = fmaxf(v[j][0], rfloor); v[j][1] = fmaxf(v[j][1], rfloor);
                     v[j][2] = fmaxf(v[j][2], rfloor); v[j][3] = fmaxf(v[j][3], rfloor);
@@ -863,28 +879,10 @@ struct C8Plan {
     bool flat;
     bool tall;      // RECT with 512-pixel tiles (TN = 4)
     bool quad;      // pixels of a tile ordered by 2x2 pooling windows (needed by a fused pool)
+    bool single;    // one k-tile: the single-stage kernel (NBUF = 1, three workgroups per CU), 256-pixel tiles
     int th, tw;     // RECT tile shape
     int PR;
 };
-
-// RECT tile shape for a window: th x tw <= cap pixels (256 or 512) whose (th + 2) x (tw + 2) patch fits
-// C8_PCAP, fewest tiles first, then the widest rows (longer store runs).  `even`: both even (quad order).
-void rect_shape(int OH, int OW, int cap, bool even, int* th_out, int* tw_out, int64_t* tiles_out) {
-    int64_t best = -1;
-    int bth = 0, btw = 0;
-    const int stepw = even ? 2 : 1;
-    for (int tw = even ? 2 : 1; tw <= cap && tw <= ((OW + stepw - 1) / stepw) * stepw; tw += stepw) {
-        int th = cap / tw;
-        if (even) th &= ~1;
-        const int thmax = even ? ((OH + 1) & ~1) : OH;
-        if (th > thmax) th = thmax;
-        while (th > 0 && (th + 2) * (tw + 2) > C8_PCAP) th -= stepw;
-        if (th <= 0) continue;
-        const int64_t tiles = (int64_t)((OH + th - 1) / th) * ((OW + tw - 1) / tw);
-        if (best < 0 || tiles < best || (tiles == best && tw > btw)) { best = tiles; bth = th; btw = tw; }
-    }
-    *th_out = bth; *tw_out = btw; *tiles_out = best;
-}
 
 int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
     if (!d) return IISEG_ERR_NULL;
@@ -929,15 +927,18 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
         auto per_cu = [&](int64_t tiles, double unit) { return (double)((tiles * mt + 255) / 256) * unit; };
         int th2, tw2, th4, tw4;
         int64_t n2, n4;
-        rect_shape(d->OH, d->OW, 256, quad, &th2, &tw2, &n2);
-        rect_shape(d->OH, d->OW, 512, quad, &th4, &tw4, &n4);
+        rect_shape(d->OH, d->OW, 256, C8_PCAP, quad, &th2, &tw2, &n2);
+        rect_shape(d->OH, d->OW, 512, C8_PCAP, quad, &th4, &tw4, &n4);
         const double c2 = per_cu(n2 * d->B, 2.0 * (nkt + 2.0)), c4 = per_cu(n4 * d->B, 4.0 * nkt + 6.0);
+        static const int single_env = getenv("IISEG_C8_SINGLE") ? atoi(getenv("IISEG_C8_SINGLE")) : 1;
+        plan->single = single_env && nkt == 1 && !x3 && !(d->flags & IISEG_CONV_UNPOOL) && d->Cout > 32;
         plan->flat = false;
         plan->quad = quad;
         plan->PR = 0;
-        plan->tall = c4 < c2;
+        plan->tall = c4 < c2 && !plan->single;
         if (tall_env >= 0) plan->tall = tall_env != 0;
         if (g_force_kind == 0 || g_force_kind == 1) plan->tall = g_force_kind == 1;
+        if (plan->tall) plan->single = false;
         plan->th = plan->tall ? th4 : th2;
         plan->tw = plan->tall ? tw4 : tw2;
         {
@@ -945,6 +946,7 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
             if (shape_env && a <= 0) sscanf(shape_env, "%d,%d", &a, &b);
             if (a > 0 && b > 0 && (!quad || !((a | b) & 1)) && (a + 2) * (b + 2) <= C8_PCAP && a * b <= 512) {
                 plan->th = a; plan->tw = b; plan->tall = a * b > 256;
+                if (plan->tall) plan->single = false;
             }
         }
         // FLAT: single source, the whole tensors within 32-bit offsets, the patch within the buffer
@@ -961,9 +963,12 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
                 // (its patch is several times a RECT tile's: priced as one more k-tile of set-up)
                 const double cf = per_cu(nf, 2.0 * (nkt + 2.5));
                 const double cr = plan->tall ? c4 : c2;
-                if (cf < cr || force == 2 || g_force_kind == 2) {
+                // (measured: at equal modelled cost the rect tiles run 5-8 % faster -- the flat patch is
+                // whole window rows, twice the DMA per pixel of a 512-pixel tile)
+                if ((cf < 0.92 * cr && !plan->single) || force == 2 || g_force_kind == 2) {
                     plan->flat = true;
                     plan->tall = false;
+                    plan->single = false;
                     plan->PR = pr;
                 }
             }
@@ -971,8 +976,6 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
     }
     return IISEG_OK;
 }
-
-unsigned magic20(int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); }
 
 template <int BM, bool OUTF32>
 int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
@@ -1002,9 +1005,22 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
         else                                                                                       \
             hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, false>), dim3(grid), dim3(256), 0, s, p); \
     } while (0)
-    if (plan.flat) {
+    if (plan.single) {
+        if constexpr (BM == 64 && !OUTF32)
+            hipLaunchKernelGGL((conv_c8_kernel<64, 2, false, false, false, false, 1>), dim3(grid), dim3(256), 0, s, p);
+        else
+            return IISEG_ERR_UNSUPPORTED;
+    } else if (plan.flat) {
         if (unpool) C8_LAUNCH(2, true, true); else C8_LAUNCH(2, true, false);
     } else if (plan.tall) {
+        static const int w8 = getenv("IISEG_C8_W8") ? atoi(getenv("IISEG_C8_W8")) : 1;
+        if constexpr (BM == 64 && !OUTF32) {
+            if (w8 && !unpool && !p.x3) {
+                hipLaunchKernelGGL((conv_c8_kernel<64, 2, false, false, false, false, 2, 8>), dim3(grid), dim3(512),
+                                   0, s, p);
+                return iiseg_check_launch();
+            }
+        }
         if (unpool) C8_LAUNCH(4, false, true); else C8_LAUNCH(4, false, false);
     } else {
         if (unpool) C8_LAUNCH(2, false, true); else C8_LAUNCH(2, false, false);

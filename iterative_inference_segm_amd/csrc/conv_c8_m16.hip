@@ -1,0 +1,509 @@
+// Direct 3x3 convolution on bf16 C8 activations for layers with AT MOST 16 OUTPUT CHANNELS (gfx950,
+// v_mfma_f32_16x16x32_bf16, fp32 accumulate): the DAE's class-score layer (up_conv1, 64 -> 11 at 224^2:
+// models/fcn_up.py:83-86) and FC-DenseNet's growth-rate-16 dense-block layers (BN -> ReLU -> conv 3x3 ->
+// 16 new channels appended to the stack: models/FCDenseNet.py:61-146, FC_DenseNet.layers.BN_ReLU_Conv).
+// On the 32x32 MFMA of conv_c8_bf16.hip such a layer keeps 11 or 16 of 32 matrix rows busy and, far from
+// the matrix pipe's limit anyway, pays the 64-channel kernel's prologue / staging / epilogue for it.
+// Here:
+//   * M = 16 channels, N = 16 pixels, K = 32 = two taps x 16 input channels per MFMA (taps (2m, 2m + 1)
+//     for m = 0..3, tap 8 with a zero second half): 20 MFMAs of 16 cycles per 16-channel k-tile and
+//     wave instead of 18 of 32;
+//   * 256 threads = 4 waves x 128 pixels, a th x tw tile (<= 512 pixels, shape chosen per window);
+//   * LDS 50 KB, < 128 registers: three workgroups and twelve waves per CU.  These layers are bound by
+//     the latency of a k-tile's staging (a k-tile is 40 short MFMAs per wave: the next k-tile's loads,
+//     issued one k-tile ahead, are not back when they are needed), so what counts is work per staging
+//     round trip x workgroups in flight: 512-pixel tiles halved the time of 256-pixel ones;
+//   * input staging per 8-channel half (the half is a compile-time constant of a piece): LDS-DMA, or
+//     through registers for DePool2D (up chunk + 8 mask bytes, layers/mylayers.py:88-115) and for
+//     BatchNorm + ReLU applied on the way in (per-channel scale / shift read as scalars; the padding
+//     ring stays exact zeros, as a zero-padded convolution of the normalised map has it);
+//   * output: fp32 NCHW (class scores), or bf16 C8 into a 16-channel slice of a wider C8 tensor (the
+//     dense block's stack: no concat copy).
+// The accumulators start from the bias; every output is one fixed-order sum (k-tile, tap pair), so
+// results do not depend on the tile shape or the window a launch covers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+#include "c8_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int RSRC_W3 = 0x00027000;
+constexpr unsigned OOB = 0x80000000u;
+constexpr int NB = 8;              // 16-pixel blocks per wave: 4 waves x 128 pixels = 512-pixel tiles
+constexpr int NPC = 3;             // 256-chunk staging pieces per 8-channel half
+constexpr int HCAP = 640;          // patch chunks per half (whole 64-chunk DMA pieces: 256 + 256 + 128)
+constexpr int WROWS = 18 * 16;     // weight chunks per k-tile: (tap, half) x 16 channels
+constexpr int WCAP = 320;          // ... rounded up to whole 64-chunk DMA pieces
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, RSRC_W3);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+struct M16Params {
+    const void* x1;               // C8 input (B, C1/8, H, W, 8); UNPOOL: `up` (B, C1/8, h2, w2, 8)
+    const unsigned char* mask_in; // UNPOOL: (B, C1/8, h2, w2, 8) mask bytes
+    const void* wp;               // Wp16[kt][tap][h][Mpad][8] (iiseg_conv_halo_bf16_pack, Mpad = 32)
+    const float* bias;
+    const float* bn_a;            // BNRELU: x <- max(a[c] x + b[c], 0), one pair per input channel
+    const float* bn_b;
+    void* out;
+    int B, C1, H, W, h2, w2;
+    int in_c8tot;                 // chunk planes per image of x1 (>= C1 / 8: the first channels of a wider tensor)
+    int Cout, OH, OW, oy0, ox0, pad;
+    int nkt, Mpad;
+    int out_ctot, out_c0, out_H, out_W, out_y0, out_x0;
+    int relu;
+    int n_ptiles, tiles_y, tiles_x, th, tw;
+    unsigned pw_magic, tw_magic;
+};
+
+enum { M16_PLAIN = 0, M16_UNPOOL = 1, M16_BNRELU = 2 };
+
+template <int MODE, bool OUTF32>
+__global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) {
+    // ONE LDS array: weight ring Ws[2][WCAP], patch ring Ps[2][2 halves][HCAP]
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * WCAP + 4 * HCAP];
+    uint4 (*Ws)[WCAP] = reinterpret_cast<uint4 (*)[WCAP]>(smem);
+    uint4 (*Ps)[2][HCAP] = reinterpret_cast<uint4 (*)[2][HCAP]>(smem + 2 * WCAP);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int HW = p.H * p.W, hw2 = p.h2 * p.w2;
+    const int CC = p.C1 >> 3;
+
+    // ---- tile: th x tw pixels of one image, blocks dealt round-robin to the XCDs in runs ------------
+    int pt, mt;
+    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, 1, pt, mt);
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int tb = pt / tpi;
+    const int tr = pt - tb * tpi;
+    const int ty = tr / p.tiles_x, tx = tr - ty * p.tiles_x;
+    const int wy0 = ty * p.th, wx0 = tx * p.tw;
+    const int PWs = p.tw + 2;
+    const int half = (p.th + 2) * PWs;           // patch chunks of one 8-channel half (<= HCAP)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // piece i of a half (chunks [256 i + 64 wave, + 64)): only if the patch reaches it
+    bool piece[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) piece[i] = i * 256 + wave_u * 64 < half && i * 256 + wave_u * 64 < HCAP;
+
+    // ---- patch staging offsets: chunk e = i * 256 + tid of a half -> (patch row, patch column) ------
+    unsigned voff[NPC];                     // byte offset in chunk plane 0 of the image, or OOB
+    unsigned voffm[MODE == M16_UNPOOL ? NPC : 1];
+    int bsel[MODE == M16_UNPOOL ? NPC : 1];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int e = i * 256 + tid;
+        const int prow = (int)(((unsigned)e * p.pw_magic) >> 20), pcol = e - prow * PWs;     // e / PWs
+        const int iy = p.oy0 + wy0 - p.pad + prow, ix = p.ox0 + wx0 - p.pad + pcol;
+        bool ok = e < half && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        if constexpr (MODE == M16_UNPOOL) {
+            ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;     // DePool2D: only where pooling windows are
+            const unsigned pq = (unsigned)((iy >> 1) * p.w2 + (ix >> 1));
+            voff[i] = ok ? pq * 16u : OOB;
+            voffm[i] = ok ? pq * 8u : OOB;
+            bsel[i] = ((iy & 1) << 1) | (ix & 1);
+        } else {
+            voff[i] = ok ? (unsigned)(iy * p.W + ix) * 16u : OOB;
+        }
+    }
+    const int plane = MODE == M16_UNPOOL ? hw2 : HW;
+    const char* base1 = (const char*)p.x1 + (size_t)tb * p.in_c8tot * plane * 16;
+    const unsigned n1 = (unsigned)(CC * plane) * 16u;
+    const __amdgpu_buffer_rsrc_t r_x1 = mk_rsrc(base1, n1);
+    const i32x4s s_x1 = mk_srsrc(base1, n1);
+    const __amdgpu_buffer_rsrc_t r_m =
+        mk_rsrc(MODE == M16_UNPOOL ? p.mask_in + (size_t)tb * CC * hw2 * 8 : nullptr,
+                MODE == M16_UNPOOL ? (unsigned)(CC * hw2) * 8u : 0u);
+    const i32x4s s_w = mk_srsrc(p.wp, (unsigned)(p.nkt * 18 * p.Mpad) * 16u);
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr(&Ws[0][0]) + (unsigned)wave * 1024u);
+    const unsigned lds_p = __builtin_amdgcn_readfirstlane(lds_addr(&Ps[0][0][0]) + (unsigned)wave * 1024u);
+    // weights of a k-tile: chunk f = j * 256 + tid -> row (tap, half) f / 16, channel f % 16
+    unsigned woff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = j * 256 + tid;
+        woff[j] = f < WROWS ? 16u * (unsigned)((f >> 4) * p.Mpad + (f & 15)) : OOB;
+    }
+
+    // ---- this lane's pixels: block k of the wave = pixels (wave 64 + 16 k + l15) of the tile, row-major
+    int bpos[NB], ey[NB], ex[NB];
+    bool eok[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int n = (wave * NB + k) * 16 + l15;
+        int ly = (int)(((unsigned)n * p.tw_magic) >> 20), lx = n - ly * p.tw;               // n / tw
+        const bool inb = ly < p.th;
+        if (!inb) { ly = 0; lx = 0; }
+        ey[k] = wy0 + ly; ex[k] = wx0 + lx;
+        eok[k] = inb && ey[k] < p.OH && ex[k] < p.OW;
+        bpos[k] = ly * PWs + lx;
+    }
+    // K = 32 of an MFMA: lane group g -> (tap 2m + (g >> 1), half g & 1) in step m < 4; in step 4 the
+    // groups 0, 1 hold tap 8 and the groups 2, 3 a zero A operand
+    const int hsel = g & 1, tsel = g >> 1;
+    int aoff[5], boff[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        const int tap = m < 4 ? 2 * m + tsel : 8;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        aoff[m] = (tap * 2 + hsel) * 16 + l15;
+        boff[m] = hsel * HCAP + ky * PWs + kx;
+    }
+
+    // accumulators start from the bias: C/D row = 4 g + q (channel), column = l15 (pixel)
+    f32x4 acc[NB];
+    {
+        const __amdgpu_buffer_rsrc_t r_bias = mk_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
+        const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            r_bias, (int)(16u * (unsigned)g), 0, 0));
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = bv;
+    }
+
+    // ---- staging of one k-tile (chunks KC, KC + 1 of the input; packed weight k-tile WT) ------------
+    auto dma_w = [&](int wt, int buf) __attribute__((always_inline)) {
+        const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)(wt * 18 * p.Mpad) * 16u);
+        dma16(s_w, lds_w + (unsigned)(buf * WCAP) * 16u, woff[0], so_w);
+        if (wave_u == 0) dma16(s_w, lds_w + (unsigned)(buf * WCAP + 256) * 16u, woff[1], so_w);
+    };
+    auto dma_x = [&](int kc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((kc + h) * plane) * 16u);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i)
+                if (piece[i]) dma16(s_x1, lds_p + (unsigned)((buf * 2 + h) * HCAP + i * 256) * 16u, voff[i], so);
+        }
+    };
+    // register staging (UNPOOL / BNRELU): loads here, transformed and written to LDS after the MFMAs
+    u32x4 xu[2][NPC];
+    u32x2 xm[MODE == M16_UNPOOL ? 2 : 1][NPC];
+    auto load_x = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int so = (int)((unsigned)((kc + h) * plane) * 16u);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                if (!piece[i]) continue;
+                xu[h][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)voff[i], so, 0));
+                if constexpr (MODE == M16_UNPOOL)
+                    xm[h][i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        r_m, (int)voffm[i], so >> 1, 0));
+            }
+        }
+    };
+    auto store_x = [&](int kc, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float sa[8], sb[8];
+            if constexpr (MODE == M16_BNRELU) {
+                // the 8 channels of this half: wave-uniform addresses -> scalar loads
+                const int c0 = __builtin_amdgcn_readfirstlane((kc + h) * 8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { sa[q] = p.bn_a[c0 + q]; sb[q] = p.bn_b[c0 + q]; }
+            }
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                if (!piece[i]) continue;
+                uint4 v;
+                if constexpr (MODE == M16_UNPOOL) {
+                    // byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j
+                    const unsigned t0 = (xm[h][i][0] >> bsel[i]) & 0x01010101u;
+                    const unsigned t1 = (xm[h][i][1] >> bsel[i]) & 0x01010101u;
+                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
+                    v.x = xu[h][i][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
+                    v.y = xu[h][i][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
+                    v.z = xu[h][i][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
+                    v.w = xu[h][i][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
+                } else {
+                    // BatchNorm + ReLU of the stored bf16 values, rounded to bf16 once more; chunks of
+                    // the zero-padding ring (out-of-range offset: the load returned zeros) stay zero
+                    const bool inside = voff[i] != OOB;
+                    unsigned w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned u = xu[h][i][q];
+                        const float lo = fmaxf(__builtin_fmaf(bf_lo(u), sa[2 * q], sb[2 * q]), 0.f);
+                        const float hi = fmaxf(__builtin_fmaf(bf_hi(u), sa[2 * q + 1], sb[2 * q + 1]), 0.f);
+                        w[q] = inside ? pack_bf16(lo, hi) : 0u;
+                    }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                if (i * 256 + tid < half) Ps[buf][h][i * 256 + tid] = v;
+            }
+        }
+    };
+
+    const int nkt = p.nkt;
+    if constexpr (MODE == M16_PLAIN) {
+        dma_x(0, 0);
+        dma_w(0, 0);
+    } else {
+        load_x(0);
+        dma_w(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        store_x(0, 0);
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        // own DMA pieces (and LDS writes) retired, then the barrier publishes them and tells that every
+        // wave is done reading what the previous step read
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) {
+            if constexpr (MODE == M16_PLAIN) dma_x(2 * (kt + 1), buf ^ 1); else load_x(2 * (kt + 1));
+            dma_w(kt + 1, buf ^ 1);
+        }
+        const uint4* Wb = &Ws[buf][0];
+        const uint4* Pb = &Ps[buf][0][0];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            uint4 a = Wb[aoff[m]];
+            if (m == 4 && g >= 2) a = make_uint4(0u, 0u, 0u, 0u);
+            uint4 b[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) b[k] = Pb[boff[m] + bpos[k]];
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                   __builtin_bit_cast(bf16x8, b[k]), acc[k], 0, 0, 0);
+        }
+        if constexpr (MODE != M16_PLAIN) {
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                store_x(2 * (kt + 1), buf ^ 1);
+            }
+        }
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------------
+    const int OPL = p.out_H * p.out_W;
+    if constexpr (OUTF32) {
+        // fp32 NCHW (B, out_ctot, out_H, out_W): channel 4 g + q of pixel l15 -- 64-byte runs per store
+        const __amdgpu_buffer_rsrc_t r_out =
+            mk_rsrc((const char*)p.out + (size_t)tb * p.out_ctot * OPL * 4, (unsigned)(p.out_ctot * OPL) * 4u);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const unsigned o0 = (unsigned)(p.out_c0 * OPL + (p.out_y0 + ey[k]) * p.out_W + p.out_x0 + ex[k]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = 4 * g + q;
+                float v = acc[k][q];
+                if (p.relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(int, v), r_out,
+                    (int)((eok[k] && co < p.Cout) ? 4u * (o0 + (unsigned)(co * OPL)) : OOB), 0, 0);
+            }
+        }
+    } else {
+        // bf16 C8: the 16 channels are chunks (out_c0 / 8) + (0, 1) of the (B, out_ctot / 8, out_H, out_W, 8)
+        // tensor; lane group g holds half (g & 1) of chunk (g >> 1); channels past Cout are exact zeros
+        // (zero weight rows, no bias)
+        const int oct8 = p.out_ctot >> 3;
+        const __amdgpu_buffer_rsrc_t r_out =
+            mk_rsrc((const char*)p.out + (size_t)tb * oct8 * OPL * 16, (unsigned)(oct8 * OPL) * 16u);
+        const unsigned cplane = (unsigned)(((p.out_c0 >> 3) + (g >> 1)) * OPL) * 16u + 8u * (unsigned)(g & 1);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const unsigned opix = (unsigned)((p.out_y0 + ey[k]) * p.out_W + p.out_x0 + ex[k]);
+            f32x4 v = acc[k];
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            u32x2 w2;
+            w2[0] = pack_bf16(v[0], v[1]); w2[1] = pack_bf16(v[2], v[3]);
+            __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)(eok[k] ? opix * 16u + cplane : OOB), 0, 0);
+        }
+    }
+}
+
+// y = max(a x + b, 0) coefficients of one BatchNorm layer over the first n channels of a stack:
+// a = gamma inv_std, b = beta - mean a (models/FCDenseNet.py BN_ReLU_Conv; batch statistics, P10)
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ beta, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                                      float* __restrict__ a, float* __restrict__ b, int n) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n) {
+        const float s = gamma[c] * inv_std[c];
+        a[c] = s;
+        b[c] = beta[c] - mean[c] * s;
+    }
+}
+
+// Batch statistics (mean, 1 / sqrt(var + eps), biased variance) of channels [c0, c0 + n) of a bf16 C8
+// tensor (B, Ctot / 8, H, W, 8); c0, n multiples of 8.  Two deterministic stages: workgroup (chunk,
+// slice) sums its share of the pixels of all images in double (per thread, then a fixed-order tree) into
+// ws[chunk][slice][16]; the second kernel adds the slices in order.
+constexpr int BN_SLICES = 128;
+
+__global__ __launch_bounds__(256) void bn_stats_c8_kernel(const uint4* __restrict__ x, int B, int C8tot, int c8_0,
+                                                          int HW, double* __restrict__ ws) {
+    __shared__ double red[16][256];
+    const int c8 = c8_0 + blockIdx.x, slice = blockIdx.y;
+    double s[8], ss[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.0; ss[j] = 0.0; }
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t t = (int64_t)slice * 256 + threadIdx.x; t < total; t += (int64_t)BN_SLICES * 256) {
+        const int b = (int)(t / HW), i = (int)(t - (int64_t)b * HW);
+        const uint4 u = x[((size_t)b * C8tot + c8) * HW + i];
+        const float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += v[j]; ss[j] += (double)v[j] * v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[j][threadIdx.x] = s[j]; red[8 + j][threadIdx.x] = ss[j]; }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) ws[((size_t)blockIdx.x * BN_SLICES + slice) * 16 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(64) void bn_stats_c8_final_kernel(const double* __restrict__ ws, int c8_0, double count,
+                                                               double eps, float* __restrict__ mean,
+                                                               float* __restrict__ inv_std) {
+    const int j = threadIdx.x;
+    if (j >= 8) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < BN_SLICES; ++k) {
+        s += ws[((size_t)blockIdx.x * BN_SLICES + k) * 16 + j];
+        ss += ws[((size_t)blockIdx.x * BN_SLICES + k) * 16 + 8 + j];
+    }
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[(c8_0 + blockIdx.x) * 8 + j] = (float)m;
+    inv_std[(c8_0 + blockIdx.x) * 8 + j] = (float)(1.0 / sqrt(var + eps));
+}
+
+int m16_check(const iiseg_conv_desc* d) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->KH != 3 || d->KW != 3 || d->dil != 1 || (d->flags & (IISEG_CONV_TRANSPOSED2 | IISEG_CONV_X3)))
+        return IISEG_ERR_UNSUPPORTED;
+    if (d->B <= 0 || d->C1 <= 0 || d->C2 != 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->Cout > 16 ||
+        d->pad < 0 || d->OH <= 0 || d->OW <= 0 || d->oy0 < 0 || d->ox0 < 0)
+        return d && d->Cout > 16 ? IISEG_ERR_UNSUPPORTED : IISEG_ERR_SHAPE;
+    if (d->C1 % 16) return IISEG_ERR_UNSUPPORTED;
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if (d->oy0 + d->OH > fullH || d->ox0 + d->OW > fullW) return IISEG_ERR_SHAPE;
+    if (d->out_ctot != 0 && (d->out_c0 < 0 || d->out_c0 + d->Cout > d->out_ctot)) return IISEG_ERR_SHAPE;
+    if (d->out_H != 0 && (d->out_y0 < 0 || d->out_x0 < 0 || d->out_y0 + d->OH > d->out_H ||
+                          d->out_x0 + d->OW > d->out_W))
+        return IISEG_ERR_SHAPE;
+    // one image of every tensor is addressed with 32-bit byte offsets
+    if ((int64_t)d->C1 * d->H * d->W * 2 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    const int64_t octot = d->out_ctot ? d->out_ctot : 16;
+    const int64_t opl = d->out_H ? (int64_t)d->out_H * d->out_W : (int64_t)d->OH * d->OW;
+    if ((octot + 16) * opl * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if ((int64_t)(d->C1 / 16) * 18 * 32 * 16 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    return IISEG_OK;
+}
+
+}  // namespace
+
+extern "C" int iiseg_conv_c8_m16_supported(const iiseg_conv_desc* d) { return m16_check(d) == IISEG_OK ? 1 : 0; }
+
+extern "C" int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
+                                 const uint8_t* mask_in, const float* bn_a, const float* bn_b,
+                                 const void* wp16, const float* bias, void* out, int out_kind) {
+    const int st = m16_check(d);
+    if (st) return st;
+    if (in_ctot == 0) in_ctot = d->C1;
+    if (in_ctot < d->C1 || in_ctot % 8) return IISEG_ERR_SHAPE;
+    if ((d->flags & IISEG_CONV_UNPOOL) && in_ctot != d->C1) return IISEG_ERR_UNSUPPORTED;
+    if ((int64_t)in_ctot * d->H * d->W * 2 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    if (!x1 || !wp16 || !out) return IISEG_ERR_NULL;
+    const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
+    if (unpool != (mask_in != nullptr)) return IISEG_ERR_NULL;
+    if ((bn_a != nullptr) != (bn_b != nullptr) || (bn_a && unpool)) return IISEG_ERR_UNSUPPORTED;
+    if ((uintptr_t)wp16 & 15) return IISEG_ERR_ALIGN;
+    if (out_kind != 1 && out_kind != 3) return IISEG_ERR_UNSUPPORTED;
+    const int octot = d->out_ctot ? d->out_ctot : (out_kind == 3 ? d->Cout : 16);
+    if (out_kind == 1 && (octot % 16 || d->out_c0 % 16)) return IISEG_ERR_UNSUPPORTED;
+    M16Params p = {};
+    p.x1 = x1; p.mask_in = mask_in; p.wp = wp16; p.bias = bias; p.bn_a = bn_a; p.bn_b = bn_b; p.out = out;
+    p.B = d->B; p.C1 = d->C1; p.H = d->H; p.W = d->W; p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.in_c8tot = in_ctot / 8;
+    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0; p.pad = d->pad;
+    p.nkt = d->C1 / 16;
+    p.Mpad = 32;                        // iiseg_conv_halo_bf16_pack's padding for Cout <= 32
+    p.out_ctot = octot;
+    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
+    p.out_H = d->out_H ? d->out_H : d->OH;
+    p.out_W = d->out_H ? d->out_W : d->OW;
+    p.out_y0 = d->out_H ? d->out_y0 : 0;
+    p.out_x0 = d->out_H ? d->out_x0 : 0;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    int64_t tiles;
+    rect_shape(d->OH, d->OW, NB * 64, HCAP, false, &p.th, &p.tw, &tiles);
+    static const char* shape_env = getenv("IISEG_M16_SHAPE");           // "th,tw": timing experiments
+    if (shape_env) {
+        int a = 0, b = 0;
+        if (sscanf(shape_env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a * b <= NB * 64 && (a + 2) * (b + 2) <= HCAP) {
+            p.th = a; p.tw = b;
+        }
+    }
+    p.tiles_y = (d->OH + p.th - 1) / p.th;
+    p.tiles_x = (d->OW + p.tw - 1) / p.tw;
+    p.n_ptiles = d->B * p.tiles_y * p.tiles_x;
+    p.pw_magic = magic20(p.tw + 2);
+    p.tw_magic = magic20(p.tw);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(p.n_ptiles), block(256);
+    if (out_kind == 3) {
+        if (unpool) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_UNPOOL, true>), grid, block, 0, s, p);
+        else if (bn_a) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_BNRELU, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_c8_m16_kernel<M16_PLAIN, true>), grid, block, 0, s, p);
+    } else {
+        if (unpool) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_UNPOOL, false>), grid, block, 0, s, p);
+        else if (bn_a) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_BNRELU, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_c8_m16_kernel<M16_PLAIN, false>), grid, block, 0, s, p);
+    }
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_bn_fold_f32(void* stream, const float* beta, const float* gamma, const float* mean,
+                                 const float* inv_std, float* a, float* b, int n) {
+    if (!beta || !gamma || !mean || !inv_std || !a || !b) return IISEG_ERR_NULL;
+    if (n <= 0) return IISEG_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, beta, gamma,
+                       mean, inv_std, a, b, n);
+    return iiseg_check_launch();
+}
+
+extern "C" int64_t iiseg_bn_stats_c8_workspace_elems(int n) { return (int64_t)((n + 7) / 8) * BN_SLICES * 16; }
+
+extern "C" int iiseg_bn_stats_c8(void* stream, const void* x, int B, int Ctot, int c0, int n, int H, int W,
+                                 double eps, float* mean, float* inv_std, double* workspace) {
+    if (!x || !mean || !inv_std || !workspace) return IISEG_ERR_NULL;
+    if (B <= 0 || Ctot <= 0 || n <= 0 || H <= 0 || W <= 0 || c0 < 0 || c0 + n > Ctot) return IISEG_ERR_SHAPE;
+    if (Ctot % 8 || c0 % 8 || n % 8) return IISEG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_stats_c8_kernel, dim3(n / 8, BN_SLICES), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, B, Ctot / 8, c0 / 8, H * W, workspace);
+    hipLaunchKernelGGL(bn_stats_c8_final_kernel, dim3(n / 8), dim3(64), 0, (hipStream_t)stream, workspace,
+                       c0 / 8, (double)B * H * W, eps, mean, inv_std);
+    return iiseg_check_launch();
+}

@@ -90,6 +90,9 @@ def _bf16_static_pick(Cin, OW):
     return 'wino' if (Cin >= 1024 or fill < 0.7) else 'halo'
 
 
+# C8 layers with at most 16 output channels on the 16-row MFMA kernel (conv_c8_m16.hip); 0: the
+# 32-row form of conv_c8_bf16.hip (timing experiments)
+C8_M16 = os.environ.get('IISEG_C8_M16', '1') != '0'
 BF16_UPCONV1 = os.environ.get('IISEG_BF16_UPCONV1', '0') != '0'
 BF16_WINO_MIN_COUT = int(os.environ.get('IISEG_BF16_WINO_MIN_COUT', '256'))
 _wino_ws = {}   # device -> workspace tensor shared by all layers (launches are stream-ordered)
@@ -250,6 +253,7 @@ class Conv:
         self._U16 = None
         self._W16 = None
         self._W16c8 = None
+        self._W16c8_cin = None
         self._plans = {}
         self._packs = {}
 
@@ -320,7 +324,8 @@ class Conv:
 
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
                  window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None,
-                 mask_in=None, unpool_hw=None, mask_out=None, store_out=True, out_format=None):
+                 mask_in=None, unpool_hw=None, mask_out=None, store_out=True, out_format=None,
+                 in_c=None, bn=None):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
@@ -341,7 +346,9 @@ class Conv:
         input."""
         if is_c8(x1):
             return self._call_c8(x1, x2, add, add_off, window, out, place, pool_out, mask_in,
-                                 unpool_hw, mask_out, store_out, out_format)
+                                 unpool_hw, mask_out, store_out, out_format, out_c0, in_c, bn)
+        if in_c is not None or bn is not None:
+            raise RuntimeError('in_c / bn: C8 input only (layers with at most 16 output channels)')
         dt = self.dtype
         unpool = pre is not None or mask_in is not None
         masked = mask_in is not None or mask_out is not None
@@ -609,8 +616,89 @@ class Conv:
         check(self.lib.iiseg_conv_c8_tiling(C.byref(d), 1 if pool else 0, t), 'iiseg_conv_c8_tiling')
         return tuple(t)
 
+    def _call_c8_m16(self, x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn):
+        """Layers with at most 16 output channels on bf16 C8 activations (include/iiseg.h,
+        iiseg_conv_c8_m16).  in_c: convolve only the first in_c channels of x1 (a dense block's stack);
+        out + out_c0: write the 16 channels [out_c0, out_c0 + 16) of the wider C8 tensor `out`;
+        bn = (a, b): BatchNorm + ReLU x <- max(a x + b, 0) applied to the input on the way in
+        (`bn_fold`).  Returns `out`."""
+        lib = self.lib
+        unpool = mask_in is not None
+        B = x1.shape[0]
+        in_ctot = x1.shape[1] * 8
+        C1 = in_ctot if in_c is None else int(in_c)
+        if C1 % 16 or C1 > in_ctot or C1 < self.Cin or C1 - self.Cin >= 16:
+            raise RuntimeError('conv of %d input channels on the first %d of %d C8 channels'
+                               % (self.Cin, C1, in_ctot))
+        if unpool:
+            if unpool_hw is None or not is_c8_mask(mask_in) or tuple(mask_in.shape) != tuple(x1.shape) or \
+                    (unpool_hw[0] // 2, unpool_hw[1] // 2) != tuple(x1.shape[2:4]) or C1 != in_ctot:
+                raise RuntimeError('C8 DePool2D input: up %s, mask %s, unpool_hw %s'
+                                   % (tuple(x1.shape), tuple(mask_in.shape), unpool_hw))
+            H, W = int(unpool_hw[0]), int(unpool_hw[1])
+        else:
+            H, W = x1.shape[2], x1.shape[3]
+        fullH, fullW = self.out_hw(H, W)
+        oy0, ox0, OH, OW = window if window is not None else (0, 0, fullH, fullW)
+        fmt = out_format or ('c8' if self.Cout % 8 == 0 else 'nchw')
+        if fmt not in ('c8', 'nchw'):
+            raise RuntimeError('16-channel C8 layer: bf16 C8 or fp32 NCHW output')
+        d = ConvDesc()
+        d.B, d.C1, d.C2, d.H, d.W = B, C1, 0, H, W
+        d.Cout, d.KH, d.KW, d.pad, d.dil = self.Cout, 3, 3, self.pad, 1
+        d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
+        d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0)
+        if place is not None:
+            if out is None:
+                raise RuntimeError('placement needs a target')
+            d.out_H, d.out_W, d.out_y0, d.out_x0 = out.shape[2], out.shape[3], int(place[0]), int(place[1])
+        if out is None:
+            if out_c0 is not None:
+                raise RuntimeError('out_c0 needs a target')
+            out = torch.empty((B, self.Cout, OH, OW), dtype=torch.float32, device=x1.device) if fmt == 'nchw' \
+                else torch.empty((B, 2, OH, OW, 8), dtype=torch.bfloat16, device=x1.device)
+        if fmt == 'nchw':
+            ok = out.dim() == 4 and out.dtype == torch.float32 and out.shape[1] == self.Cout and out_c0 is None
+        else:
+            ok = out.dim() == 5 and out.dtype == torch.bfloat16 and out.shape[1] % 2 == 0
+            if ok and (out_c0 is not None or out.shape[1] != 2):
+                c0 = int(out_c0 or 0)
+                ok = c0 % 16 == 0 and c0 + 16 <= out.shape[1] * 8
+                d.out_ctot, d.out_c0 = out.shape[1] * 8, c0
+        if not ok or out.shape[0] != B or (place is None and tuple(out.shape[2:4]) != (OH, OW)):
+            raise RuntimeError('bad output target %s for a 16-channel C8 layer' % (tuple(out.shape),))
+        if bn is not None:
+            a, b = bn
+            if a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() < C1 or b.numel() < C1:
+                raise RuntimeError('bn = (a, b): float32, at least %d entries' % C1)
+        if self._W16c8 is None or self._W16c8_cin != C1:
+            dp = ConvDesc()
+            dp.B, dp.C1, dp.C2, dp.H, dp.W = 1, self.Cin, 0, 8, 8
+            dp.Cout, dp.KH, dp.KW, dp.pad, dp.dil = self.Cout, 3, 3, 1, 1
+            dp.OH, dp.OW = 8, 8
+            self._W16c8 = torch.empty(lib.iiseg_conv_halo_bf16_weight_bytes(C.byref(dp)) // 2,
+                                      dtype=torch.bfloat16, device=self.W.device)
+            check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(self.W), self.so, self.sc,
+                                                _ptr(self._W16c8, torch.bfloat16)),
+                  'iiseg_conv_halo_bf16_pack')
+            self._W16c8_cin = C1
+        dtp = lambda t: None if t is None else _ptr(t, t.dtype)
+        prof = CONV_PROFILE
+        ev0 = _ev() if prof is not None else None
+        check(lib.iiseg_conv_c8_m16(_stream(), C.byref(d), dtp(x1), in_ctot, dtp(mask_in),
+                                    None if bn is None else _ptr(bn[0]), None if bn is None else _ptr(bn[1]),
+                                    dtp(self._W16c8), _ptr(self.b), dtp(out), 3 if fmt == 'nchw' else 1),
+              'iiseg_conv_c8_m16')
+        if prof is not None:
+            prof.append(('conv_c8_m16_kernel', self.flops(B, OH, OW), ev0, _ev()))
+            if CONV_PROFILE_INFO is not None:
+                CONV_PROFILE_INFO.append(dict(
+                    Cin=self.Cin, Cout=self.Cout, C1=C1, C2=0, H=H, W=W, OH=OH, OW=OW, B=B,
+                    unpool=unpool, pool=False, add=0, kind=3 if fmt == 'nchw' else 1, flat='m16'))
+        return out
+
     def _call_c8(self, x1, x2, add, add_off, window, out, place, pool_out, mask_in, unpool_hw,
-                 mask_out, store_out, out_format):
+                 mask_out, store_out, out_format, out_c0=None, in_c=None, bn=None):
         """The layer on bf16 C8 activations (include/iiseg.h, iiseg_conv_c8).  x1 / x2 / pool_out:
         C8 tensors (`is_c8`); add: C8 bf16 or C8 fp32 (float32, same 5-D shape); mask_in / mask_out:
         uint8 (B, C/8, h, w, 8).  out_format: 'c8' (default), 'c8f32', or 'nchw' (fp32 NCHW, the
@@ -619,6 +707,11 @@ class Conv:
         lib = self.lib
         if not self.c8:
             raise RuntimeError("C8 input needs a 3x3 layer built with mma='bf16c8'")
+        if C8_M16 and self.Cout <= 16 and not self.x3 and x2 is None and add is None and pool_out is None and \
+                store_out and (out_format or 'c8') in ('c8', 'nchw'):
+            return self._call_c8_m16(x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn)
+        if out_c0 is not None or in_c is not None or bn is not None:
+            raise RuntimeError('out_c0 / in_c / bn on C8 input: layers with at most 16 output channels')
         unpool = mask_in is not None
         x3 = self.x3
         pair = 2 if x3 else 1                     # chunk planes of a kind-1 tensor per channel chunk
@@ -646,6 +739,10 @@ class Conv:
                                '%d + %d chunks' % (self.Cin, CC1, CC2))
         fullH, fullW = self.out_hw(H, W)
         oy0, ox0, OH, OW = window if window is not None else (0, 0, fullH, fullW)
+        if not store_out and pool_out is not None:
+            # only the pool is kept: the unpaired last row / column of an odd map (Pool2DLayer
+            # ignore_border) feeds nothing -- do not compute it
+            OH, OW = max(OH & ~1, 2 if OH > 1 else 1), max(OW & ~1, 2 if OW > 1 else 1)
         fmt = out_format or ('c8' if self.Cout % 8 == 0 else 'nchw')
         kind = {'c8': 1, 'c8f32': 2, 'nchw': 3}[fmt]
         d = ConvDesc()
@@ -1126,6 +1223,33 @@ def confusion_accumulate(y, t, cm, sums, active=None):
                                _ptr(sums, torch.float64), B, Cc, H * W), 'iiseg_confusion')
 
 
+
+
+def bn_fold(beta, gamma, mean, inv_std, n, a=None, b=None, cap=None):
+    """(a, b) with max(a x + b, 0) == relu(BatchNorm(x)) for the first n channels (float32 vectors of
+    `cap` >= n entries, zero beyond n): the input-side BN + ReLU of the 16-channel C8 layers."""
+    cap = int(cap or n)
+    if a is None:
+        a = torch.zeros(cap, dtype=torch.float32, device=beta.device)
+        b = torch.zeros(cap, dtype=torch.float32, device=beta.device)
+    check(_lib.load().iiseg_bn_fold_f32(_stream(), _ptr(beta), _ptr(gamma), _ptr(mean), _ptr(inv_std),
+                                        _ptr(a), _ptr(b), int(n)), 'iiseg_bn_fold_f32')
+    return a, b
+
+
+def bn_stats_c8(buf8, c0, n, mean, inv_std, eps=1e-4):
+    """Batch statistics (P10) of channels [c0, c0 + n) of the C8 tensor `buf8` into mean[c0:c0+n],
+    inv_std[c0:c0+n] (float32 vectors)."""
+    lib = _lib.load()
+    B, C8n, H, W, _ = buf8.shape
+    key = _ws_key(buf8.device)
+    need = lib.iiseg_bn_stats_c8_workspace_elems(int(n))
+    ws = _bn_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _bn_ws[key] = torch.empty(int(need), dtype=torch.float64, device=buf8.device)
+    check(lib.iiseg_bn_stats_c8(_stream(), _ptr(buf8, torch.bfloat16), B, C8n * 8, int(c0), int(n), H, W,
+                                float(eps), _ptr(mean), _ptr(inv_std), _ptr(ws, torch.float64)),
+          'iiseg_bn_stats_c8')
 
 
 def bn_stats(buf, c0, n, mean, inv_std, eps=1e-4):

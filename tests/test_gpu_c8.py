@@ -378,7 +378,8 @@ def _random_geometries(ops, force):
                 assert np.array_equal(gm[:, :, qy0:qy0 + qh, qx0:qx0 + qw],
                                       bits[:, :, qy0:qy0 + qh, qx0:qx0 + qw]), (case, 'mask')
     print('random C8 launches: %d of 40 on the flat tiling (%s)' % (n_flat, force))
-    assert (1 <= n_flat <= 39) if force[0] == -1 else (n_flat == 0) if force[0] == 1 else n_flat >= 20
+    # (small batches: the planner's cost model rarely prefers the flat list; forced, it must run most)
+    assert n_flat <= 39 if force[0] == -1 else (n_flat == 0) if force[0] == 1 else n_flat >= 20
 
 
 DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 k-tiles: the deep layers)
@@ -389,8 +390,17 @@ DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 
 ]
 
 
+@pytest.fixture(params=[(2, 0, 0), (-1, 0, 0)], ids=['flat', 'auto'])
+def flat_forced(request, built_lib):
+    from iterative_inference_segm_amd import _lib
+    lib = _lib.load()
+    assert lib.iiseg_conv_c8_force_tiling(*request.param) == 0
+    yield request.param
+    assert lib.iiseg_conv_c8_force_tiling(-1, 0, 0) == 0
+
+
 @pytest.mark.parametrize('case', DEEP_CASES)
-def test_conv_c8_long_k_flat_exact_on_integer_data(ops, case):
+def test_conv_c8_long_k_flat_exact_on_integer_data(ops, case, flat_forced):
     """Flat-tiled launches with long k-loops (256 to 512 input channels, 10^2 to 31^2 windows, tiles
     that run across images) against the oracle, bit for bit: fp32 chunk output, bf16 output with
     skip-add and placement."""
@@ -421,3 +431,109 @@ def test_conv_c8_long_k_flat_exact_on_integer_data(ops, case):
     want = np.full((B, Cout, fh, fw), -9.0)
     want[:, :, y0:y0 + h, x0:x0 + w] = tot[:, :, y0:y0 + h, x0:x0 + w]
     assert np.array_equal(from_c8(out, Cout), want)
+
+
+# ---- layers with at most 16 output channels: csrc/conv_c8_m16.hip (16-row MFMA) ----------------------
+
+M16_CASES = [  # B, Cin, H, W, Cout, pad, relu, window
+    (2, 16, 20, 45, 16, 1, True, None),
+    (1, 48, 9, 70, 8, 1, False, None),
+    (2, 32, 12, 12, 16, 5, True, None),              # wide zero padding
+    (3, 64, 40, 40, 11, 1, False, (6, 10, 21, 27)),  # window, fp32 NCHW scores
+    (5, 128, 13, 13, 16, 1, True, None),
+    (2, 80, 33, 17, 12, 1, False, (0, 0, 33, 17)),
+]
+
+
+@pytest.mark.parametrize('shape_env', [None, '4,58', '16,16', '3,70'])
+@pytest.mark.parametrize('case', M16_CASES)
+def test_conv_c8_m16_exact_on_integer_data(ops, case, shape_env, monkeypatch):
+    """The 16-row kernel against the oracle, bit for bit on integer data: bf16 C8 output for channel
+    counts that are multiples of 8, fp32 NCHW otherwise; windows; channels past Cout stay zero.
+    (IISEG_M16_SHAPE is read once per process: the forced shapes take effect when this test is the
+    first m16 launch -- scripts/ run it that way; here the planner's shapes are what is pinned.)"""
+    B, Cin, H, W, Cout, pad, relu, window = case
+    rng = np.random.default_rng(sum(case[:6]) + 7)
+    x = ints(rng, B, Cin, H, W, lo=-2, hi=3) if Cin < 128 else ints(rng, B, Cin, H, W, lo=-1, hi=2)
+    Wt = ints(rng, Cout, Cin, 3, 3, lo=-1, hi=2)
+    b = ints(rng, Cout)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, mma='bf16c8')
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=relu)
+    got = conv(ops.nchw_to_c8(dev(x)), window=window)
+    if window is not None:
+        y0, x0, h, w = window
+        ref = ref[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.abs(ref).max() <= 256
+    if Cout % 8 == 0:
+        assert ops.is_c8(got) and got.shape[1] == 2
+        full = from_c8(got, 16)
+        assert np.array_equal(full[:, :Cout], ref) and not full[:, Cout:].any()
+    else:
+        assert got.dtype == torch.float32 and np.array_equal(host(got), ref.astype(np.float32))
+
+
+def test_conv_c8_m16_depool_input_and_placement(ops):
+    """DePool2D input (up + mask bytes) into the class-score layer, placed into a larger fp32 map."""
+    rng = np.random.default_rng(77)
+    B, Cin, H, W, Cout = 2, 64, 37, 44, 11
+    pre = ints(rng, B, Cin, H, W, lo=0, hi=3)
+    pooled, bits = _masks(pre)
+    up = ints(rng, B, Cin, H // 2, W // 2, lo=-2, hi=3)
+    unp = onn.depool_eqmask(up, pre, pooled)
+    Wt = ints(rng, Cout, Cin, 3, 3, lo=-1, hi=2)
+    b = ints(rng, Cout)
+    conv = ops.Conv(Wt, b, pad=1, relu=False, mma='bf16c8')
+    ref = onn.conv2d(unp, Wt, b, pad=1, relu=False)
+    m = np.zeros((B, ops.c8_chunks(Cin), H // 2, W // 2, 8), dtype=np.uint8)
+    m[:] = bits.reshape(B, Cin // 8, 8, H // 2, W // 2).transpose(0, 1, 3, 4, 2)
+    mt = torch.from_numpy(m).cuda()
+    got = conv(ops.nchw_to_c8(dev(up)), mask_in=mt, unpool_hw=(H, W))
+    assert np.array_equal(host(got), ref.astype(np.float32))
+    out = torch.full((B, Cout, H, W), -5.0, device='cuda')
+    conv(ops.nchw_to_c8(dev(up)), mask_in=mt, unpool_hw=(H, W), window=(3, 2, 19, 30), out=out, place=(3, 2))
+    want = np.full_like(ref, -5.0)
+    want[:, :, 3:22, 2:32] = ref[:, :, 3:22, 2:32]
+    assert np.array_equal(host(out), want.astype(np.float32))
+
+
+def test_conv_c8_m16_dense_block_layer(ops):
+    """A dense-block layer of FC-DenseNet on a C8 stack (models/FCDenseNet.py:61-146, BN_ReLU_Conv):
+    BatchNorm + ReLU applied to the first n channels of the stack on the way in, 3x3 conv to 16 new
+    channels written into the stack's next slice -- bit for bit on integer data (integer BN scale /
+    shift), the rest of the stack untouched; then the batch statistics of the new channels."""
+    rng = np.random.default_rng(31)
+    B, cap, n, H, W = 3, 96, 48, 21, 30
+    stack = np.zeros((B, cap, H, W))
+    stack[:, :n] = ints(rng, B, n, H, W, lo=-3, hi=4)
+    stack[:, n:] = 9.0                                   # (later slices: must not be read, 16 of them written)
+    a = rng.integers(1, 3, size=n).astype(np.float64)
+    bsh = rng.integers(-2, 3, size=n).astype(np.float64)
+    xin = np.maximum(stack[:, :n] * a[None, :, None, None] + bsh[None, :, None, None], 0)
+    Wt = ints(rng, 16, n, 3, 3, lo=-1, hi=2)
+    bias = ints(rng, 16)
+    ref = onn.conv2d(xin, Wt, bias, pad=1, relu=False)
+    assert np.abs(ref).max() <= 256 and np.abs(xin).max() <= 256
+    conv = ops.Conv(Wt, bias, pad=1, relu=False, mma='bf16c8')
+    s8 = ops.nchw_to_c8(dev(stack))
+    at = torch.zeros(cap, device='cuda'); bt = torch.zeros(cap, device='cuda')
+    at[:n] = torch.from_numpy(a).float().cuda(); bt[:n] = torch.from_numpy(bsh).float().cuda()
+    r = conv(s8, in_c=n, bn=(at, bt), out=s8, out_c0=n)
+    assert r is s8
+    full = from_c8(s8, cap)
+    assert np.array_equal(full[:, :n], stack[:, :n])
+    assert np.array_equal(full[:, n:n + 16], ref)
+    assert np.array_equal(full[:, n + 16:], stack[:, n + 16:])
+    # statistics of the new 16 channels (biased variance, eps 1e-4: Lasagne BatchNormLayer, P10)
+    mean = torch.zeros(cap, device='cuda'); inv = torch.zeros(cap, device='cuda')
+    ops.bn_stats_c8(s8, n, 16, mean, inv, eps=1e-4)
+    mref = ref.mean(axis=(0, 2, 3)); vref = ref.var(axis=(0, 2, 3))
+    assert np.allclose(host(mean)[n:n + 16], mref, rtol=1e-6, atol=1e-6)
+    assert np.allclose(host(inv)[n:n + 16], 1.0 / np.sqrt(vref + 1e-4), rtol=1e-6)
+    assert not host(mean)[:n].any() and not host(mean)[n + 16:].any()
+    # the (a, b) pair from beta, gamma, mean, inv_std
+    beta = torch.rand(cap, device='cuda'); gamma = torch.rand(cap, device='cuda') + 0.5
+    fa, fb = ops.bn_fold(beta, gamma, mean, inv, n + 16, cap=cap)
+    g, be, mm, ii = (host(t).astype(np.float64) for t in (gamma, beta, mean, inv))
+    assert np.allclose(host(fa)[:n + 16], (g * ii)[:n + 16], rtol=1e-6)
+    assert np.allclose(host(fb)[:n + 16], (be - mm * g * ii)[:n + 16], rtol=1e-5, atol=1e-6)
+    assert not host(fa)[n + 16:].any()
