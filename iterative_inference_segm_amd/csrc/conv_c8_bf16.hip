@@ -925,11 +925,20 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
         static const char* shape_env = getenv("IISEG_C8_SHAPE");          // "th,tw": tests
         const int64_t mt = (d->Cout + 63) / 64;
         auto per_cu = [&](int64_t tiles, double unit) { return (double)((tiles * mt + 255) / 256) * unit; };
+        // staging share of a k-tile: patch chunks staged per output pixel beyond a compact tile's 1.3 cost
+        // 2 % each by LDS-DMA, 8 % each through registers (DePool2D: select per chunk) -- fitted to
+        // conv4_3 at 40^2 (flat 0.92 of rect) and up_conv3 at 58^2 (flat 1.07 of rect)
+        const double gam = (d->flags & IISEG_CONV_UNPOOL) ? 0.08 : 0.02;
+        auto stage = [&](int patch_half, int pixels) {
+            const double ppp = 2.0 * patch_half / pixels - 1.3;
+            return 1.0 + gam * (ppp > 0 ? ppp : 0);
+        };
         int th2, tw2, th4, tw4;
         int64_t n2, n4;
         rect_shape(d->OH, d->OW, 256, C8_PCAP, quad, &th2, &tw2, &n2);
         rect_shape(d->OH, d->OW, 512, C8_PCAP, quad, &th4, &tw4, &n4);
-        const double c2 = per_cu(n2 * d->B, 2.0 * (nkt + 2.0)), c4 = per_cu(n4 * d->B, 4.0 * nkt + 6.0);
+        const double c2 = per_cu(n2 * d->B, 2.0 * (nkt * stage((th2 + 2) * (tw2 + 2), 256) + 2.0)),
+                     c4 = per_cu(n4 * d->B, 4.0 * nkt * stage((th4 + 2) * (tw4 + 2), 512) + 6.0);
         static const int single_env = getenv("IISEG_C8_SINGLE") ? atoi(getenv("IISEG_C8_SINGLE")) : 1;
         plan->single = single_env && nkt == 1 && !x3 && !(d->flags & IISEG_CONV_UNPOOL) && d->Cout > 32;
         plan->flat = false;
@@ -960,12 +969,11 @@ int c8_check(const iiseg_conv_desc* d, C8Plan* plan, bool pool = false) {
                 const int64_t units = quad ? (int64_t)d->B * ((d->OH + 1) / 2) * ((d->OW + 1) / 2)
                                            : (int64_t)d->B * d->OH * d->OW;
                 const int64_t nf = (units + (quad ? 63 : 255)) / (quad ? 64 : 256);
-                // (its patch is several times a RECT tile's: priced as one more k-tile of set-up)
-                const double cf = per_cu(nf, 2.0 * (nkt + 2.5));
+                const double cf = per_cu(nf, 2.0 * (nkt * stage(pr * (d->OW + 2), 256) + 2.5));
                 const double cr = plan->tall ? c4 : c2;
-                // (measured: at equal modelled cost the rect tiles run 5-8 % faster -- the flat patch is
-                // whole window rows, twice the DMA per pixel of a 512-pixel tile)
-                if ((cf < 0.92 * cr && !plan->single) || force == 2 || g_force_kind == 2) {
+                // (against 512-pixel tiles the flat list has to be 8 % ahead: 512 -> 512 at 37^2 runs 13 %
+                // slower flat at equal modelled cost -- twice the weight DMA and barriers per pixel)
+                if ((cf < (plan->tall ? 0.92 : 1.0) * cr && !plan->single) || force == 2 || g_force_kind == 2) {
                     plan->flat = true;
                     plan->tall = false;
                     plan->single = false;
@@ -1006,14 +1014,17 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
             hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, false>), dim3(grid), dim3(256), 0, s, p); \
     } while (0)
     if (plan.single) {
-        if constexpr (BM == 64 && !OUTF32)
+        if constexpr (BM == 64 && !OUTF32) {
             hipLaunchKernelGGL((conv_c8_kernel<64, 2, false, false, false, false, 1>), dim3(grid), dim3(256), 0, s, p);
-        else
+        } else {
             return IISEG_ERR_UNSUPPORTED;
+        }
     } else if (plan.flat) {
         if (unpool) C8_LAUNCH(2, true, true); else C8_LAUNCH(2, true, false);
     } else if (plan.tall) {
-        static const int w8 = getenv("IISEG_C8_W8") ? atoi(getenv("IISEG_C8_W8")) : 1;
+        // (eight-wave workgroups -- TN = 2, NW = 8: half the work and registers per wave, four waves per
+        // SIMD -- measured within 0.5 % of this form on every layer class, with spilled registers: opt-in)
+        static const int w8 = getenv("IISEG_C8_W8") ? atoi(getenv("IISEG_C8_W8")) : 0;
         if constexpr (BM == 64 && !OUTF32) {
             if (w8 && !unpool && !p.x3) {
                 hipLaunchKernelGGL((conv_c8_kernel<64, 2, false, false, false, false, 2, 8>), dim3(grid), dim3(512),

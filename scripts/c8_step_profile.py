@@ -33,11 +33,16 @@ for rep in range(REP):
     it = iter(info)
     for k, f, s, e in prof:
         ms = s.elapsed_time(e)
-        if not k.startswith('conv_c8_kernel'):
+        if not k.startswith('conv_c8_'):
             o = other.setdefault(k, [0.0, 0])
             o[0] += ms; o[1] += 1
             continue
         g = next(it)
+        if k.startswith('conv_c8_m16'):
+            o = other.setdefault(k, [0.0, 0])
+            o[0] += ms; o[1] += 1
+            mf = other.setdefault('(m16 GFLOP)', [0.0, 0]); mf[0] += f / 1e9
+            continue
         key = (g['Cin'], g['Cout'], g['OH'], g['OW'], g['unpool'], g['pool'], g['add'], g['kind'], g['flat'])
         if key not in rows:
             rows[key] = [0.0, 0.0, 0]
