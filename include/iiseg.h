@@ -328,6 +328,12 @@ int iiseg_bn_stats_c8(void* stream, const void* x, int B, int Ctot, int c0, int 
                       double eps, float* mean, float* inv_std, double* workspace);
 int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8n);
 int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8n);
+/* The same between a dense fp32 (B, C, H, W) tensor and the chunk planes [c8_0, c8_0 + ceil(C / 8)) of a
+ * WIDER C8 tensor of C8tot planes per image (a dense block's stack: models/FCDenseNet.py:92,119-127). */
+int iiseg_nchw_to_c8_slice(void* stream, const float* x, void* out, int B, int C, int H, int W, int C8tot,
+                           int c8_0);
+int iiseg_c8_slice_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W, int C8tot,
+                           int c8_0);
 int iiseg_pool_mask_c8(void* stream, const void* pre, int pre_f32, void* pooled, uint8_t* mask,
                        int BC8, int PH, int PW, int py0, int px0, int H, int W, int y0, int x0, int wh,
                        int ww);

@@ -87,6 +87,8 @@ SIGNATURES = {
     'iiseg_bn_fold_f32': (C.c_int, [_vp] * 7 + [_i32]),
     'iiseg_bn_stats_c8_workspace_elems': (C.c_int64, [_i32]),
     'iiseg_bn_stats_c8': (C.c_int, [_vp, _vp] + [_i32] * 6 + [C.c_double, _vp, _vp, _vp]),
+    'iiseg_nchw_to_c8_slice': (C.c_int, [_vp, _vp, _vp] + [_i32] * 6),
+    'iiseg_c8_slice_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 6),
     'iiseg_nchw_to_c8': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_c8_to_nchw': (C.c_int, [_vp, _vp, _vp] + [_i32] * 5),
     'iiseg_pool_mask_c8': (C.c_int, [_vp, _vp, _i32, _vp, _vp] + [_i32] * 11),

@@ -694,9 +694,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? 3 : 2)) void co
 
 // x (B, C, H, W) fp32 -> C8 (B, C8n, H, W, 8) bf16, channels >= C zero; X3: the hi / lo pair
 // (B, 2 C8n, H, W, 8), lo = bf16(x - hi)
+// (non-X3: `out` may be a wider C8 tensor of C8tot chunk planes per image, the C8n planes written start at
+// plane c8_0; dense: C8tot = C8n, c8_0 = 0)
 template <bool X3>
 __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict__ x, uint4* __restrict__ out,
-                                                         int C, int HW, int C8n, int64_t total) {
+                                                         int C, int HW, int C8n, int64_t total, int C8tot = 0,
+                                                         int c8_0 = 0) {
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int pix = (int)(t % HW);
         const int64_t r = t / HW;
@@ -719,22 +722,24 @@ __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict
                            pack_bf16(v[4] - bf_lo(hi.z), v[5] - bf_hi(hi.z)),
                            pack_bf16(v[6] - bf_lo(hi.w), v[7] - bf_hi(hi.w)));
         } else {
-            out[t] = hi;
+            out[C8tot ? ((b * C8tot + c8_0 + c8) * HW + pix) : t] = hi;
         }
     }
 }
 
 // C8 (B, C8n, H, W, 8) bf16 -> (B, C, H, W) fp32 (first C channels); X3: from the hi / lo pair
 // (B, 2 C8n, H, W, 8), value = hi + lo (exact in fp32)
+// (non-X3: `x` may be a wider C8 tensor of C8tot chunk planes per image, read from plane c8_0)
 template <bool X3>
 __global__ __launch_bounds__(256) void c8_to_nchw_kernel(const uint4* __restrict__ x, float* __restrict__ out,
-                                                         int C, int HW, int C8n, int64_t total) {
+                                                         int C, int HW, int C8n, int64_t total, int C8tot = 0,
+                                                         int c8_0 = 0) {
     for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int pix = (int)(t % HW);
         const int64_t r = t / HW;
         const int c8 = (int)(r % C8n);
         const int64_t b = r / C8n;
-        const uint4 u = x[X3 ? ((b * 2 * C8n + c8) * HW + pix) : t];
+        const uint4 u = x[X3 ? ((b * 2 * C8n + c8) * HW + pix) : C8tot ? ((b * C8tot + c8_0 + c8) * HW + pix) : t];
         float v[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y),
                       bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
         if constexpr (X3) {
@@ -1152,6 +1157,30 @@ extern "C" int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, 
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     hipLaunchKernelGGL(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                        (uint4*)out, C, H * W, C8n, total);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_nchw_to_c8_slice(void* stream, const float* x, void* out, int B, int C, int H, int W,
+                                      int C8tot, int c8_0) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    const int C8n = (C + 7) / 8;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || c8_0 < 0 || c8_0 + C8n > C8tot) return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)B * C8n * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint4*)out, C, H * W, C8n, total, C8tot, c8_0);
+    return iiseg_check_launch();
+}
+
+extern "C" int iiseg_c8_slice_to_nchw(void* stream, const void* x, float* out, int B, int C, int H, int W,
+                                      int C8tot, int c8_0) {
+    if (!x || !out) return IISEG_ERR_NULL;
+    const int C8n = (C + 7) / 8;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || c8_0 < 0 || c8_0 + C8n > C8tot) return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)B * C8n * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(c8_to_nchw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, out, C, H * W, C8n, total, C8tot, c8_0);
     return iiseg_check_launch();
 }
 

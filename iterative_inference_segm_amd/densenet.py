@@ -76,9 +76,41 @@ class _Stack:
         return self.buf if self.n == self.buf.shape[1] else self.buf[:, :self.n].contiguous()
 
 
+class _Stack8:
+    """The same stack as bf16 C8 chunks (B, cap / 8, H, W, 8) -- mma='bf16c8': the format the dense-block
+    layers read and write (csrc/conv_c8_m16.hip); the statistics (fp32) are those of the stored bf16
+    values, reduced once per produced slice."""
+
+    def __init__(self, B, cap, H, W, device):
+        assert cap % 16 == 0
+        self.buf = torch.empty((B, cap // 8, H, W, 8), dtype=torch.bfloat16, device=device)
+        self.mean = torch.zeros(cap, dtype=torch.float32, device=device)
+        self.inv_std = torch.zeros(cap, dtype=torch.float32, device=device)
+        self.a = torch.zeros(cap, dtype=torch.float32, device=device)     # folded BN of the consumer
+        self.b = torch.zeros(cap, dtype=torch.float32, device=device)
+        self.n = 0
+
+    def added(self, k, stats=True):
+        if stats:
+            ops.bn_stats_c8(self.buf, self.n, k, self.mean, self.inv_std, BN_EPS)
+        self.n += k
+
+
 class FCDenseNet:
     def __init__(self, params, n_classes=11, layer=('pool4',), n_layers_per_block=LAYERS_PER_BLOCK,
                  n_pool=N_POOL, growth=GROWTH, device='cuda', dtype=torch.float32, mma=None):
+        """mma: 'f32' (default) | 'bf16' (bf16 MFMA operands, fp32 NCHW activations) | 'bf16c8'
+        (configs[2] as BASELINE names it: the dense-block stacks as bf16 C8 tensors, every
+        BN_ReLU_Conv of a dense block one launch of the 16-row C8 kernel with BatchNorm + ReLU applied
+        while the input is staged; the first conv on the 64-channel C8 kernel; TransitionDown /
+        TransitionUp / the 1x1 score layer -- 11 of the 103 convolutions -- on the 'bf16' forms through
+        layout converters)."""
+        mma = mma or ops.DEFAULT_MMA
+        self.c8 = mma == 'bf16c8' and dtype == torch.float32 and growth == 16
+        if mma in ('bf16c8', 'bf16x3'):
+            mma_other = 'bf16' if mma == 'bf16c8' else 'f32'
+        else:
+            mma_other = mma
         self.layer = list(layer)
         assert all(h in ['input', 'pool1', 'pool2', 'pool3', 'pool4', 'pool5'] for h in self.layer)
         self.nlpb, self.n_pool, self.growth = list(n_layers_per_block), n_pool, growth
@@ -91,11 +123,13 @@ class FCDenseNet:
                 e['beta'], e['gamma'] = dev(p['beta']), dev(p['gamma'])
             if p['kind'] == 'tu':
                 e['conv'] = ops.Conv(p['W'], p['b'], pad=0, relu=False, layout='iohw',
-                                     transposed=True, device=device, dtype=dtype, mma=mma)
+                                     transposed=True, device=device, dtype=dtype, mma=mma_other)
             else:
                 k = p['W'].shape[2]
+                on_c8 = self.c8 and k == 3 and (p['kind'] == 'brc' or (p['kind'] == 'first' and
+                                                                       p['W'].shape[0] % 16 == 0))
                 e['conv'] = ops.Conv(p['W'], p['b'], pad=k // 2, relu=False, device=device,
-                                     dtype=dtype, mma=mma)
+                                     dtype=dtype, mma='bf16c8' if on_c8 else mma_other)
             self.layers.append(e)
 
     def __call__(self, x):
@@ -113,7 +147,80 @@ class FCDenseNet:
         t = ops.bn_relu(stack.buf, stack.n, e['beta'], e['gamma'], stack.mean, stack.inv_std)
         return e['conv'](t, out=out, out_c0=out_c0)
 
+    def _brc8(self, it, stack):
+        """Dense-block layer on the C8 stack: BN + ReLU of the first n channels on the way in, 16 new
+        channels into the next slice (models/FCDenseNet.py:88-92)."""
+        e = next(it)
+        ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, stack.n, a=stack.a, b=stack.b)
+        e['conv'](stack.buf, in_c=stack.n, bn=(stack.a, stack.b), out=stack.buf, out_c0=stack.n)
+        stack.added(self.growth)
+
+    def _forward_c8(self, x):
+        B, _, H, W = x.shape
+        g, dev = self.growth, self.device
+        it = iter(self.layers)
+        hidden = [x] if 'input' in self.layer else []
+        ints = [int(h[-1]) for h in self.layer if h != 'input']
+        first = self.layers[0]['conv']
+        n = first.Cout
+        if not first.c8:
+            raise NotImplementedError("mma='bf16c8': the first convolution's filter count must be a multiple of 16")
+        stack = _Stack8(B, n + g * self.nlpb[0], H, W, dev)
+        next(it)['conv'](ops.nchw_to_c8(x), out=stack.buf, out_c0=0)  # first conv (linear)
+        stack.added(n)
+        skips = []
+        for i in range(self.n_pool):                                  # FCDenseNet.py:81-100
+            for _ in range(self.nlpb[i]):
+                self._brc8(it, stack)
+            skips.append(stack)
+            # TransitionDown (BN -> ReLU -> 1x1 conv -> pool) on the fp32-NCHW forms
+            e = next(it)
+            n = stack.n
+            xs = ops.c8_slice_to_nchw(stack.buf, 0, n)
+            t = ops.bn_relu(xs, n, e['beta'], e['gamma'], stack.mean, stack.inv_std, out=xs)
+            t = ops.maxpool2x2(e['conv'](t))
+            del xs
+            H, W = H // 2, W // 2
+            stack = _Stack8(B, n + g * self.nlpb[i + 1], H, W, dev)
+            ops.nchw_to_c8_slice(t, stack.buf, 0)
+            stack.added(n)
+            if i + 1 in ints:
+                hidden.append(t)
+        skips = skips[::-1]
+        nblock = self.nlpb[self.n_pool]
+        block0 = stack.n
+        for _ in range(nblock):                                       # bottleneck, :107-111
+            self._brc8(it, stack)
+        for i in range(self.n_pool):                                  # :116-127
+            e = next(it)                                              # TransitionUp
+            blk = ops.c8_slice_to_nchw(stack.buf, block0, stack.n - block0)   # concat(block_to_upsample)
+            skip = skips[i]
+            uh, uw = e['conv'].out_hw(H, W)
+            H, W = min(uh, skip.buf.shape[2]), min(uw, skip.buf.shape[3])
+            if (H, W) != tuple(skip.buf.shape[2:4]):
+                raise NotImplementedError('skip larger than the upsampled map')
+            keep = e['conv'].Cout
+            nlay = self.nlpb[self.n_pool + i + 1]
+            new = _Stack8(B, keep + skip.n + g * nlay, H, W, dev)
+            up = e['conv'](blk, window=((uh - H) // 2, (uw - W) // 2, H, W))
+            ops.nchw_to_c8_slice(up, new.buf, 0)
+            new.added(keep)
+            # the skip stack behind it (plumbing: chunk planes and their statistics as they are)
+            new.buf[:, keep // 8:(keep + skip.n) // 8].copy_(skip.buf[:, :skip.n // 8])
+            new.mean[keep:keep + skip.n].copy_(skip.mean[:skip.n])
+            new.inv_std[keep:keep + skip.n].copy_(skip.inv_std[:skip.n])
+            new.added(skip.n, stats=False)
+            stack, block0 = new, new.n
+            del blk, up
+            for _ in range(nlay):
+                self._brc8(it, stack)
+        score = next(it)['conv'](ops.c8_slice_to_nchw(stack.buf, 0, stack.n))   # SoftmaxLayer's 1x1 conv
+        probs = ops.crop_softmax(score, H, W, off=(0, 0))
+        return hidden + [probs]
+
     def forward(self, x):
+        if self.c8:
+            return self._forward_c8(x)
         B, _, H, W = x.shape
         g, dt, dev = self.growth, self.dtype, self.device
         it = iter(self.layers)

@@ -710,8 +710,8 @@ class Conv:
         if C8_M16 and self.Cout <= 16 and not self.x3 and x2 is None and add is None and pool_out is None and \
                 store_out and (out_format or 'c8') in ('c8', 'nchw'):
             return self._call_c8_m16(x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn)
-        if out_c0 is not None or in_c is not None or bn is not None:
-            raise RuntimeError('out_c0 / in_c / bn on C8 input: layers with at most 16 output channels')
+        if in_c is not None or bn is not None:
+            raise RuntimeError('in_c / bn on C8 input: layers with at most 16 output channels')
         unpool = mask_in is not None
         x3 = self.x3
         pair = 2 if x3 else 1                     # chunk planes of a kind-1 tensor per channel chunk
@@ -774,7 +774,14 @@ class Conv:
             else:
                 out = torch.empty((B, oc8 * (pair if fmt == 'c8' else 1), OH, OW, 8), device=x1.device,
                                   dtype=torch.bfloat16 if fmt == 'c8' else torch.float32)
-        if out is not None:
+        if out_c0 is not None:
+            # the Cout channels written as chunk planes [out_c0 / 8, ...) of a wider C8 tensor
+            if out is None or fmt != 'c8' or x3 or not is_c8(out) or out_c0 % 16 or \
+                    out_c0 + oc8 * 8 > out.shape[1] * 8 or out.shape[0] != B or \
+                    (place is None and tuple(out.shape[2:4]) != (OH, OW)):
+                raise RuntimeError('bad C8 output slice %s @%s' % (None if out is None else tuple(out.shape), out_c0))
+            d.out_ctot, d.out_c0 = out.shape[1] * 8, int(out_c0)
+        elif out is not None:
             ok = (out.dim() == 4 and out.dtype == torch.float32 and out.shape[1] == self.Cout) \
                 if fmt == 'nchw' else \
                 (out.dim() == 5 and out.shape[1] == oc8 * (pair if fmt == 'c8' else 1) and
@@ -1010,6 +1017,30 @@ def nchw_to_c8(x, out=None, x3=False):
     fn = _lib.load().iiseg_nchw_to_c8x3 if x3 else _lib.load().iiseg_nchw_to_c8
     check(fn(_stream(), _ptr(x), C.c_void_p(out.data_ptr()), B, Cc, H, W, c8_chunks(Cc)),
           'iiseg_nchw_to_c8')
+    return out
+
+
+def nchw_to_c8_slice(x, out8, c0):
+    """fp32 NCHW (B, C, H, W) -> channels [c0, c0 + C) of the wider C8 tensor `out8` (c0 % 8 == 0; a
+    partial last chunk is zero-padded)."""
+    B, Cc, H, W = x.shape
+    if not is_c8(out8) or not out8.is_contiguous() or c0 % 8 or tuple(out8.shape[2:4]) != (H, W) or \
+            out8.shape[0] != B:
+        raise RuntimeError('nchw_to_c8_slice target %s @%d' % (tuple(out8.shape), c0))
+    check(_lib.load().iiseg_nchw_to_c8_slice(_stream(), _ptr(x), C.c_void_p(out8.data_ptr()), B, Cc, H, W,
+                                             out8.shape[1], c0 // 8), 'iiseg_nchw_to_c8_slice')
+    return out8
+
+
+def c8_slice_to_nchw(x8, c0, channels, out=None):
+    """Channels [c0, c0 + channels) of the C8 tensor `x8` -> fp32 NCHW."""
+    if not is_c8(x8) or not x8.is_contiguous() or c0 % 8:
+        raise RuntimeError('c8_slice_to_nchw needs a contiguous C8 tensor and c0 % 8 == 0')
+    B, C8n, H, W, _ = x8.shape
+    if out is None:
+        out = torch.empty((B, int(channels), H, W), dtype=torch.float32, device=x8.device)
+    check(_lib.load().iiseg_c8_slice_to_nchw(_stream(), C.c_void_p(x8.data_ptr()), _ptr(out), B, int(channels),
+                                             H, W, C8n, c0 // 8), 'iiseg_c8_slice_to_nchw')
     return out
 
 

@@ -49,8 +49,9 @@ if which in ('c4', 'c5', 'c5ctx', 'c2_grad', 'fcn8dae'):
 elif which == 'c3':
     from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
     B, dt, gflop = 32, torch.float32, 254.6
+    # (IISEG_C3_NET_MMA: the dense net's mode on its own -- 'bf16' = the round-2 form next to a C8 DAE)
     net = FCDenseNet(S.make_densenet_params(layer_plan()), 11, layer=['pool4'],
-                     mma={'bf16c8': 'bf16', 'bf16x3': None}.get(mma, mma))
+                     mma=os.environ.get('IISEG_C3_NET_MMA') or {'bf16x3': None}.get(mma, mma))
     dae = StandardDAE(S.make_dae_params(h_channels=(464,)), 11, padding=0, mma=mma)
 else:
     from iterative_inference_segm_amd.fcn8 import FCN8

@@ -397,3 +397,65 @@ def test_bf16_form_choice_is_shared_and_batch_independent(ops, monkeypatch):
     assert not np.array_equal(forced['wino'], forced['halo'])
     pick = before.get(ops._bf16_key(Cin, Cout, Cin, 0, False, H, W)) or ops._bf16_static_pick(Cin, W)
     assert np.array_equal(forced[pick], a)
+
+
+def test_config3_densenet_on_c8_stacks(built_lib):
+    """BASELINE configs[2] on the 16-bit format it names: FCDenseNet(mma='bf16c8') -- the dense blocks'
+    stacks as bf16 C8 tensors, every BN_ReLU_Conv of a dense block one launch of the 16-row C8 kernel
+    with BatchNorm + ReLU applied on the way in (models/FCDenseNet.py:61-146) -- + the DAE on C8, 224x224,
+    batch 32, 10 steps.  Statistical check of the segmentation output and the h map against the fp32
+    path (bf16 activations between ~100 batch-normalised layers: the same criterion as the 'bf16' mode's
+    test above), and the loop runs on its h."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    params = S.make_densenet_params(layer_plan())
+    dp = S.make_dae_params(h_channels=(464,))
+
+    def make(mma):
+        return IterativeInference(FCDenseNet(params, 11, layer=['pool4'], mma=mma),
+                                  StandardDAE(dp, 11, padding=0, mma=mma), 11, [11])
+    ii8, ii32 = make('bf16c8'), make(None)
+    assert ii8.fcn.c8
+    n8 = sum(1 for e in ii8.fcn.layers if e['conv'].c8)
+    assert n8 == 92                                        # 91 dense-block layers + the first conv
+    X = S.make_images(32, 224, 224, seed=303)
+    o8, o32 = ii8.pred_fcn_fn(X), ii32.pred_fcn_fn(X)
+    y8, y32 = host(o8[-1]), host(o32[-1])
+    h8, h32 = host(o8[0]), host(o32[0])
+    assert h8.shape == (32, 464, 14, 14)
+    agree = float((y8.argmax(1) == y32.argmax(1)).mean())
+    eh = rel_rms(h8, h32)
+    print('DenseNet103 on C8 stacks vs fp32: argmax agreement %.4f, mean |dy| %.2e, h rel rms %.2e'
+          % (agree, np.abs(y8 - y32).mean(), eh))
+    assert np.abs(y8.sum(1) - 1).max() <= 1e-5 and agree >= 0.9 and eh <= 0.1
+    Yii, iters, norms = ii8.refine(o8[:-1], o8[-1], 0.1, 10, early_stop=False)
+    a = host(Yii)
+    assert list(host(iters)) == [10] * 32 and a.min() >= 0 and a.max() <= 1 and np.isfinite(a).all()
+
+
+def test_densenet_c8_small_against_float64(built_lib):
+    """A small FC-DenseNet (2 pools, blocks [2, 2, 2, 2, 2]) on C8 stacks against the float64 HIP path on
+    the same weights: every stage of the C8 forward (first conv into the stack slice, dense layers with
+    input-side BN + ReLU, TransitionDown / TransitionUp through the layout converters, skip copy with
+    its statistics) within the 16-bit mode's per-layer error -- a wiring error (wrong slice, wrong
+    statistics) shows as an O(1) deviation."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    nl = [2, 2, 2, 2, 2]
+    plan = layer_plan(n_layers_per_block=nl, n_pool=2)
+    params = S.make_densenet_params(plan, seed=11)
+    X = S.make_images(4, 36, 44, seed=5)
+    n8 = FCDenseNet(params, 11, layer=['pool1', 'pool2'], n_layers_per_block=nl, n_pool=2, mma='bf16c8')
+    n64 = FCDenseNet(params, 11, layer=['pool1', 'pool2'], n_layers_per_block=nl, n_pool=2,
+                     dtype=torch.float64)
+    assert n8.c8
+    o8 = n8(torch.from_numpy(X).cuda())
+    o64 = n64(torch.from_numpy(X).cuda().double())
+    for a, b, name in zip(o8, o64, ('pool1', 'pool2', 'probs')):
+        e = rel_rms(host(a), host(b))
+        print('small DenseNet on C8 vs float64: %s rel rms %.2e' % (name, e))
+        assert e <= 3e-2, name
+    agree = float((host(o8[-1]).argmax(1) == host(o64[-1]).argmax(1)).mean())
+    assert agree >= 0.97
