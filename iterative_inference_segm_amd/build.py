@@ -36,18 +36,35 @@ def _digest(paths, extra=()):
     return h.hexdigest()
 
 
+def _file_sha(path):
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for blk in iter(lambda: f.read(1 << 20), b''):
+            h.update(blk)
+    return h.hexdigest()
+
+
 def _stale(target, key):
-    """True unless `target` exists and the key stored next to it equals `key`."""
+    """True unless `target` exists, the input key stored next to it equals `key`, AND the stored hash
+    of the product's own bytes matches the file (a truncated / corrupted object with an intact key
+    file is rebuilt, not reused)."""
     try:
         with open(target + '.key') as f:
-            return not os.path.exists(target) or f.read().strip() != key
+            words = f.read().split()
+        return not os.path.exists(target) or len(words) < 2 or words[0] != key or words[1] != _file_sha(target)
     except OSError:
         return True
 
 
 def _stamp(target, key):
     with open(target + '.key', 'w') as f:
-        f.write(key + '\n')
+        f.write(key + ' ' + _file_sha(target) + '\n')
+
+
+def library_sha256():
+    """sha256 of libiiseg_hip.so as it is on disk (printed by __graft_entry__.smoke: which binary was
+    validated)."""
+    return _file_sha(LIB)
 
 
 _HIPCC_VERSION = {}

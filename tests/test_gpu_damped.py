@@ -126,12 +126,14 @@ def test_float64_path_is_pinned_to_the_oracle_on_the_damped_set(built_lib):
                                       layer=['pool4', 'probs_dimshuffle'], temperature=temp)
     assert np.abs(host(out[-1]) - y_ref).max() <= 1e-10
     dp64 = to64(dp)
+    # ALL 10 steps of the loop, free-running (the reference of (B) is pinned end to end on the set it is
+    # used on, as test_full_size_end_to_end_strict pins it on the default set)
     yii_ref, it_ref = orefine.refine_batch(lambda hh, yy: odae.dae_forward(dp64, hh, yy), [h_ref],
-                                           y_ref, STEP, 2)
-    Yii, iters, _ = ii.refine(out[:-1], out[-1], STEP, 2)
+                                           y_ref, STEP, NSTEPS)
+    Yii, iters, _ = ii.refine(out[:-1], out[-1], STEP, NSTEPS)
     err = np.abs(host(Yii) - yii_ref).max()
-    print('damped set: float64 HIP vs oracle after 2 steps: %.3e' % err)
-    assert list(host(iters)) == list(it_ref) and err <= 1e-10
+    print('damped set: float64 HIP vs oracle after %d steps: %.3e' % (NSTEPS, err))
+    assert list(host(iters)) == list(it_ref) and err <= 1e-9
 
 
 def test_fp32_free_running_fixed_tolerance(built_lib):
@@ -165,7 +167,12 @@ def test_fp32_free_running_fixed_tolerance(built_lib):
     agree = float((got.argmax(1) == y64.argmax(1)).double().mean())
     print('(B) fp32 free-running, own masks: pixels within 1e-4 %.5f, max %.3e, mean %.3e, argmax '
           'agreement %.6f' % (frac, float(e.max()), float(e.mean()), agree))
-    assert frac >= 0.999 and float(e.max()) <= 5e-3 and float(e.mean()) <= 1e-5
+    # The CLAIM is the fraction (>= 0.999 of the pixels within 1e-4) and the mean; the pixels beyond 1e-4
+    # are where a DePool2D near-tie went the other way (accounted for bit by bit below).  Their size is
+    # bounded as a regression check only: 64 images measure max 1.26e-3 (profiles/r04_parity_damped_64.md,
+    # scripts/parity_report.py) -- asserted at 2e-3, with at most 1e-6 of the pixels beyond 1e-3.
+    assert frac >= 0.999 and float(e.mean()) <= 1e-5
+    assert float(e.max()) <= 2e-3 and float((e.amax(1) > 1e-3).double().mean()) <= 1e-6
     assert agree >= 0.9999
     total_flips = 0
     for k in range(NSTEPS):

@@ -262,40 +262,46 @@ def _damped_engine(dtype, mma=None, fcn_mma=None):
 
 
 def test_x3_engine_free_running_fixed_tolerance(built_lib):
-    """configs[1] on the damped set (tests/test_gpu_damped.py), 2 images, 10 steps of 0.1, early stop
-    off, the product path (`refine()`, own masks, HIP-graph replay).  'x3' is the mode as bench.py runs
-    it: the FCN-8 (once per batch) on its fp32 MFMA kernels, the DAE loop (10 forwards per batch) on
-    hi / lo pairs -- held to the criterion of the fp32 path's (B): >= 0.999 of the pixels within the
-    1e-4 of north_star, mean error <= 1e-5, argmax agreement with the float64 path, next to the fp32
-    path's own numbers on the same images (measured here 0.99923 vs 0.99939; over 64 images the mode
-    averages 0.9986 vs 0.9993, profiles/r03_parity_damped_64.md).  'x3all' also runs the FCN-8's 3x3 layers on pairs: its 13
-    layers and the sharpened softmax of this set put 0.7 % of the pixels beyond 1e-4 (>= 0.99
-    asserted) -- which is why the mode keeps the FCN-8 in fp32."""
+    """configs[1] on the damped set (tests/test_gpu_damped.py), the 64 images of scripts/parity_report.py,
+    10 steps of 0.1, early stop off, the product path (`refine()`, own masks, HIP-graph replay).  'x3' is
+    the mode as bench.py runs it: the FCN-8 (once per batch) on its fp32 MFMA kernels, the DAE loop (10
+    forwards per batch) on hi / lo pairs.  FIXED criteria, not the fp32 path's: >= 0.998 of the pixels within
+    the 1e-4 of north_star (measured 0.9986; the fp32 path, held to >= 0.999 on the same images, measures
+    0.9993), mean error <= 1e-5, argmax agreement >= 0.9999 with the float64 path.  'x3all' also runs the
+    FCN-8's 3x3 layers on pairs: its 13 layers and the sharpened softmax of this set put 0.7 % of the
+    pixels beyond 1e-4 (>= 0.99 asserted) -- which is why the mode keeps the FCN-8 in fp32."""
     from iterative_inference_segm_amd import synthetic as S
     TOL = 1e-4
-    X = S.make_images(2, 224, 224, seed=1234)
-    res = {}
-    for k, (dt, mma, fm) in {'f64': (torch.float64, None, None), 'f32': (torch.float32, None, None),
-                             'x3': (torch.float32, 'bf16x3', None),
-                             'x3all': (torch.float32, 'bf16x3', 'bf16x3')}.items():
-        ii = _damped_engine(dt, mma, fm)
-        out = ii.pred_fcn_fn(X)
-        r1 = ii.pred_dae_fn(*out)
-        res[k] = (r1.double(), ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)[0].double())
-        del ii
-        torch.cuda.empty_cache()
+    NIMG = 64                                   # the set of scripts/parity_report.py (8 batches of 8)
+    modes = {'f64': (torch.float64, None, None), 'f32': (torch.float32, None, None),
+             'x3': (torch.float32, 'bf16x3', None), 'x3all': (torch.float32, 'bf16x3', 'bf16x3')}
+    acc = {k: dict(within=0, px=0, mx=0.0, sm=0.0, agree=0, r1mx=0.0) for k in modes if k != 'f64'}
+    engines = {k: _damped_engine(dt, mma, fm) for k, (dt, mma, fm) in modes.items()}
+    for bi in range(NIMG // 8):
+        X = S.make_images(8, 224, 224, seed=5000 + bi)
+        res = {}
+        for k, ii in engines.items():
+            out = ii.pred_fcn_fn(X)
+            r1 = ii.pred_dae_fn(*out)
+            res[k] = (r1.double(), ii.refine(out[:-1], out[-1], 0.1, 10, early_stop=False)[0].double())
+        for k in acc:
+            e = (res[k][1] - res['f64'][1]).abs()
+            a = acc[k]
+            a['within'] += int((e.amax(1) <= TOL).sum()); a['px'] += e.shape[0] * e.shape[2] * e.shape[3]
+            a['mx'] = max(a['mx'], float(e.max())); a['sm'] += float(e.sum())
+            a['agree'] += int((res[k][1].argmax(1) == res['f64'][1].argmax(1)).sum())
+            a['r1mx'] = max(a['r1mx'], float((res[k][0] - res['f64'][0]).abs().max()))
     stats = {}
-    for k in ('f32', 'x3', 'x3all'):
-        e1 = (res[k][0] - res['f64'][0]).abs()
-        e = (res[k][1] - res['f64'][1]).abs()
-        frac = float((e.amax(1) <= TOL).double().mean())
-        agree = float((res[k][1].argmax(1) == res['f64'][1].argmax(1)).double().mean())
-        stats[k] = (float(e1.max()), float(e1.mean()), frac, float(e.max()), float(e.mean()), agree)
-        print('%s vs float64: one reconstruction max %.2e mean %.2e; after 10 steps pixels within 1e-4 '
-              '%.5f, max %.2e, mean %.2e, argmax agreement %.6f' % ((k,) + stats[k]))
-    r1max, r1mean, frac, emax, emean, agree = stats['x3']
-    assert frac >= 0.999 and emean <= 1e-5 and agree >= 0.9999
-    r1max, r1mean, frac, emax, emean, agree = stats['x3all']
+    for k, a in acc.items():
+        stats[k] = (a['within'] / a['px'], a['mx'], a['sm'] / (a['px'] * 11), a['agree'] / a['px'])
+        print('%s vs float64, %d images: one reconstruction max %.2e; after 10 steps pixels within 1e-4 '
+              '%.5f, max %.2e, mean %.2e, argmax agreement %.6f' % ((k, NIMG, a['r1mx']) + stats[k]))
+    # fixed criteria: the fp32 path >= 0.999 (measured 0.99930), the pair mode >= 0.998 (measured 0.99861:
+    # fp32-CLASS, not fp32 -- DESIGN 3.8), with the FCN-8 on pairs too >= 0.99
+    assert stats['f32'][0] >= 0.999
+    frac, emax, emean, agree = stats['x3']
+    assert frac >= 0.998 and emean <= 1e-5 and agree >= 0.9999 and emax <= 2e-3
+    frac, emax, emean, agree = stats['x3all']
     assert frac >= 0.99 and emean <= 1e-5 and agree >= 0.9999
 
 
@@ -459,10 +465,10 @@ def test_conv_x3_long_k_flat_exact_on_integer_data(ops, case):
 
 def test_x3_engine_on_360x480_frames(built_lib):
     """configs[3]'s geometry (360x480 CamVid frames) on the damped set, 2 frames, 10 steps free-running,
-    against the float64 path.  The fp32 path meets its 224x224 criterion here too (>= 0.999 of the pixels
-    within 1e-4: measured 0.99929); the bf16x3 mode lands just below it (measured 0.99870, max 3.2e-4,
-    mean 1.4e-6, argmax agreement 0.999997) -- asserted at 0.998 and said so in DESIGN 3.8: the mode
-    is fp32-CLASS, not fp32."""
+    against the float64 path, under the same two fixed criteria as at 224x224
+    (test_x3_engine_free_running_fixed_tolerance): the fp32 path >= 0.999 of the pixels within 1e-4
+    (measured 0.99929), the bf16x3 mode >= 0.998 (measured 0.99870, max 3.2e-4, mean 1.4e-6, argmax
+    agreement 0.999997) -- the mode is fp32-CLASS, not fp32."""
     from iterative_inference_segm_amd import synthetic as S
     X = S.make_images(2, 360, 480, seed=4321)
     res = {}

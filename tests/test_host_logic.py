@@ -145,6 +145,11 @@ def test_synthetic_data_contract():
     assert np.allclose(k, k.T) and np.allclose(k[0], [0.0625, 0.1875, 0.1875, 0.0625])
 
 
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
 @pytest.mark.parametrize('world', [8])
 def test_bench_dry_run_world_size_8(world):
     """The N=8 launch line of the driver, rehearsed on CPU (gloo): 8 ranks rendezvous on 127.0.0.1,
@@ -156,7 +161,7 @@ def test_bench_dry_run_world_size_8(world):
     env['OMP_NUM_THREADS'] = '1'
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
                         '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
-                        '--master-port', '29691', os.path.join(ROOT, 'bench.py'), '--gpus', str(world),
+                        '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(world),
                         '--dry-run', '--steps', '2', '--warmup', '1'], env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -174,7 +179,7 @@ def test_entry_point_dry_run_world_size_8(tmp_path):
            if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env['OMP_NUM_THREADS'] = '1'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8',
-           '--master-addr', '127.0.0.1', '--master-port', '29693',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'iterative_inference.py'), '--synthetic', '--dry_run', '--n_images', '40',
            '--batch_size', '2', '--image_size', '32', '40', '-step', '0.1', '--num_iter', '3',
            '-dae_dict', '{"kind": "standard", "concat_h": ["pool4"], "additional_pool": 2, '
