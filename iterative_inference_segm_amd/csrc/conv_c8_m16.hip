@@ -12,7 +12,9 @@
 //   * LDS 50 KB, < 128 registers: three workgroups and twelve waves per CU.  These layers are bound by
 //     the latency of a k-tile's staging (a k-tile is 40 short MFMAs per wave: the next k-tile's loads,
 //     issued one k-tile ahead, are not back when they are needed), so what counts is work per staging
-//     round trip x workgroups in flight: 512-pixel tiles halved the time of 256-pixel ones;
+//     round trip x workgroups in flight: 512-pixel tiles took 20 % off 256-pixel ones; two register sets
+//     with the loads issued two k-tiles ahead were built and measured SLOWER (0.154 vs 0.132 ms on the
+//     class-score layer: 190-210 registers, two workgroups per CU instead of three);
 //   * input staging per 8-channel half (the half is a compile-time constant of a piece): LDS-DMA, or
 //     through registers for DePool2D (up chunk + 8 mask bytes, layers/mylayers.py:88-115) and for
 //     BatchNorm + ReLU applied on the way in (per-channel scale / shift read as scalars; the padding

@@ -3,6 +3,9 @@ Usage: python3 scripts/c8_layer.py <name from scripts/bench_c8.py LAYERS> [launc
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get('AB_LIB'):
+    from iterative_inference_segm_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
 from iterative_inference_segm_amd import ops
 
 LAYERS = {
