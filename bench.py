@@ -205,10 +205,19 @@ def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
     from iterative_inference_segm_amd import ops
     torch.cuda.synchronize()
     torch.cuda._sleep(int(6e8))          # ~0.25-0.3 s of GPU time: the host runs ahead meanwhile
+    # Every kernel launch of the pass carries its own start / stop HIP events on its dispatch
+    # (include/iiseg.h iiseg_profile_begin): a launch's time is the kernel's execution time on the launch
+    # stream, as rocprofv3 reports it.  (Events recorded separately around a launch put two barrier
+    # packets between consecutive kernels: +7 % on a 0.18 ms kernel, profiles/r04_event_overhead.md.)
+    dispatch = os.environ.get('IISEG_BENCH_EVENTS', 'dispatch') == 'dispatch'
+    if dispatch:
+        ops.profile_begin()
     ops.CONV_PROFILE = prof = []
     one_step(ii, X, T, num_iter, step_size, graph=False)
     torch.cuda.synchronize()
     ops.CONV_PROFILE = None
+    if dispatch:
+        ops.profile_end()
     per = {}
     for k, f, s, e in prof:
         ent = per.setdefault(k, [0.0, 0.0, 0])
@@ -222,6 +231,8 @@ def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
     gb, prov = _traffic(kern)
     whole = all_gflop / ms_per_step          # GFLOP / ms = TFLOP/s
     return {'bound': 'mfma', 'kernel': kern, 'achieved': round(achieved, 2), 'peak': peak,
+            'timing': 'HIP events on each kernel dispatch (hipExtLaunchKernelGGL start / stop)' if dispatch
+                      else 'HIP events recorded on the stream around each launch',
             'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': gb,
             'traffic_unit': 'GB of HBM traffic per launch (rocprofv3 PMC passes)',
             'traffic_provenance': prov,

@@ -41,6 +41,17 @@ int iiseg_abi_version(void);
 /* Name of the GPU architecture the library was compiled for ("gfx950"). */
 const char* iiseg_target_arch(void);
 
+/* Launch profiling (measurement only; bench.py's roofline pass).  Between iiseg_profile_begin(capacity)
+ * and iiseg_profile_end every kernel launch of this library carries its own start / stop HIP events ON ITS
+ * DISPATCH (hipExtLaunchKernelGGL), in launch order; iiseg_profile_count() = launches so far (-1 when
+ * off); iiseg_profile_end waits for them and writes the elapsed milliseconds of up to `capacity` launches
+ * -- each kernel's execution time on the stream it was launched on, the duration rocprofv3 reports, without
+ * the barrier packets separately recorded events put between two kernels (7 % of a 0.18 ms kernel) --
+ * and returns their number.  Process-wide state: one profiling pass at a time. */
+int iiseg_profile_begin(int capacity);
+int iiseg_profile_count(void);
+int iiseg_profile_end(float* ms, int capacity);
+
 /* ---------------------------------------------------------------------------------------
  * Implicit-GEMM convolution (stride 1), fp32 MFMA.
  * Replaces: Lasagne Conv2DLayer / DilatedConv2DLayer (+ fused Elemwise bias/ReLU), i.e.

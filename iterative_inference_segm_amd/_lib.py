@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 CONV_RELU = 1
 CONV_UNPOOL = 2
@@ -42,6 +42,9 @@ SIGNATURES = {
     'iiseg_strerror': (C.c_char_p, [C.c_int]),
     'iiseg_last_hip_error': (C.c_char_p, []),
     'iiseg_abi_version': (C.c_int, []),
+    'iiseg_profile_begin': (C.c_int, [C.c_int]),
+    'iiseg_profile_count': (C.c_int, []),
+    'iiseg_profile_end': (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     'iiseg_target_arch': (C.c_char_p, []),
     'iiseg_conv_ktab_entries': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_plan': (C.c_int, [C.POINTER(ConvDesc)]),

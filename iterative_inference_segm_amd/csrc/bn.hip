@@ -110,7 +110,7 @@ int bn_affine_window(void* stream, T* x, int32_t B, int32_t C, int32_t H, int32_
     if (C > 65535 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     int gx = (wh * ww + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_affine_window_kernel<T>, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream,
+    IISEG_LAUNCH(bn_affine_window_kernel<T>, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream,
                        x, C, H, W, y0, x0, wh, ww, beta, gamma, mean, inv_std);
     return iiseg_check_launch();
 }
@@ -121,9 +121,9 @@ int bn_stats(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, in
     if (!x || !mean || !inv_std || !workspace) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || HW <= 0 || bstride < (int64_t)C * HW) return IISEG_ERR_SHAPE;
     if (C > 65535) return IISEG_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(BN_NCHUNK, C), dim3(256), 0, (hipStream_t)stream, x,
+    IISEG_LAUNCH(bn_stats_kernel<T>, dim3(BN_NCHUNK, C), dim3(256), 0, (hipStream_t)stream, x,
                        bstride, B, HW, workspace);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel<T>, dim3((C + 63) / 64), dim3(64), 0,
+    IISEG_LAUNCH(bn_stats_finalize_kernel<T>, dim3((C + 63) / 64), dim3(64), 0,
                        (hipStream_t)stream, workspace, C, (double)B * HW, eps, mean, inv_std);
     return iiseg_check_launch();
 }
@@ -136,7 +136,7 @@ int bn_relu(void* stream, const T* x, int64_t bstride, int32_t B, int32_t C, int
     if (C > 65535 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     int gx = (HW + 255) / 256;
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(bn_relu_kernel<T>, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, x,
+    IISEG_LAUNCH(bn_relu_kernel<T>, dim3(gx, C, B), dim3(256), 0, (hipStream_t)stream, x,
                        bstride, C, HW, beta, gamma, mean, inv_std, out);
     return iiseg_check_launch();
 }

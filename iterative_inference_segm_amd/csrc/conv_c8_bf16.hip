@@ -1014,13 +1014,13 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
 #define C8_LAUNCH(TNV, FL, UN)                                                                     \
     do {                                                                                           \
         if (p.x3)                                                                                  \
-            hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, true>), dim3(grid), dim3(256), 0, s, p); \
+            IISEG_LAUNCH((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, true>), dim3(grid), dim3(256), 0, s, p); \
         else                                                                                       \
-            hipLaunchKernelGGL((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, false>), dim3(grid), dim3(256), 0, s, p); \
+            IISEG_LAUNCH((conv_c8_kernel<BM, TNV, FL, UN, OUTF32, false>), dim3(grid), dim3(256), 0, s, p); \
     } while (0)
     if (plan.single) {
         if constexpr (BM == 64 && !OUTF32) {
-            hipLaunchKernelGGL((conv_c8_kernel<64, 2, false, false, false, false, 1>), dim3(grid), dim3(256), 0, s, p);
+            IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 1>), dim3(grid), dim3(256), 0, s, p);
         } else {
             return IISEG_ERR_UNSUPPORTED;
         }
@@ -1032,7 +1032,7 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
         static const int w8 = getenv("IISEG_C8_W8") ? atoi(getenv("IISEG_C8_W8")) : 0;
         if constexpr (BM == 64 && !OUTF32) {
             if (w8 && !unpool && !p.x3) {
-                hipLaunchKernelGGL((conv_c8_kernel<64, 2, false, false, false, false, 2, 8>), dim3(grid), dim3(512),
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 2, 8>), dim3(grid), dim3(512),
                                    0, s, p);
                 return iiseg_check_launch();
             }
@@ -1144,7 +1144,7 @@ extern "C" int iiseg_conv_c8_split_weights(void* stream, const float* w, int64_t
     const int Cp = (Cin + 15) / 16 * 16;
     const int64_t total = (int64_t)Cout * Cp * 9;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
+    IISEG_LAUNCH(split_weights_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
                        stride_c, out, Cin, Cp, total);
     return iiseg_check_launch();
 }
@@ -1155,8 +1155,8 @@ extern "C" int iiseg_nchw_to_c8(void* stream, const float* x, void* out, int B, 
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
-                       (uint4*)out, C, H * W, C8n, total);
+    IISEG_LAUNCH(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint4*)out, C, H * W, C8n, total, 0, 0);
     return iiseg_check_launch();
 }
 
@@ -1167,7 +1167,7 @@ extern "C" int iiseg_nchw_to_c8_slice(void* stream, const float* x, void* out, i
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || c8_0 < 0 || c8_0 + C8n > C8tot) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+    IISEG_LAUNCH(nchw_to_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
                        (uint4*)out, C, H * W, C8n, total, C8tot, c8_0);
     return iiseg_check_launch();
 }
@@ -1179,7 +1179,7 @@ extern "C" int iiseg_c8_slice_to_nchw(void* stream, const void* x, float* out, i
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || c8_0 < 0 || c8_0 + C8n > C8tot) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(c8_to_nchw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+    IISEG_LAUNCH(c8_to_nchw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)x, out, C, H * W, C8n, total, C8tot, c8_0);
     return iiseg_check_launch();
 }
@@ -1190,8 +1190,8 @@ extern "C" int iiseg_nchw_to_c8x3(void* stream, const float* x, void* out, int B
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(nchw_to_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
-                       (uint4*)out, C, H * W, C8n, total);
+    IISEG_LAUNCH(nchw_to_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (uint4*)out, C, H * W, C8n, total, 0, 0);
     return iiseg_check_launch();
 }
 
@@ -1201,8 +1201,8 @@ extern "C" int iiseg_c8_to_nchw(void* stream, const void* x, float* out, int B, 
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(c8_to_nchw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)x, out, C, H * W, C8n, total);
+    IISEG_LAUNCH(c8_to_nchw_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, out, C, H * W, C8n, total, 0, 0);
     return iiseg_check_launch();
 }
 
@@ -1212,8 +1212,8 @@ extern "C" int iiseg_c8x3_to_nchw(void* stream, const void* x, float* out, int B
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || C8n * 8 < C) return IISEG_ERR_SHAPE;
     const int64_t total = (int64_t)B * C8n * H * W;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(c8_to_nchw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       (const uint4*)x, out, C, H * W, C8n, total);
+    IISEG_LAUNCH(c8_to_nchw_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)x, out, C, H * W, C8n, total, 0, 0);
     return iiseg_check_launch();
 }
 
@@ -1230,11 +1230,11 @@ static int pool_mask_c8_impl(void* stream, const void* pre, int pre_f32, void* p
     const int64_t total = (int64_t)BC8 * wh * ww;
     const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
     if (pre_f32)
-        hipLaunchKernelGGL(pool_mask_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH(pool_mask_c8_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)pre, (uint4*)pooled, (uint2*)mask, PH, PW, py0, px0, H / 2,
                            W / 2, y0, x0, wh, ww, x3_c8n, total);
     else
-        hipLaunchKernelGGL(pool_mask_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH(pool_mask_c8_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const uint4*)pre, (uint4*)pooled, (uint2*)mask, PH, PW, py0, px0, H / 2,
                            W / 2, y0, x0, wh, ww, 0, total);
     return iiseg_check_launch();

@@ -476,13 +476,13 @@ extern "C" int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const v
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(p.n_ptiles), block(256);
     if (out_kind == 3) {
-        if (unpool) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_UNPOOL, true>), grid, block, 0, s, p);
-        else if (bn_a) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_BNRELU, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_c8_m16_kernel<M16_PLAIN, true>), grid, block, 0, s, p);
+        if (unpool) IISEG_LAUNCH((conv_c8_m16_kernel<M16_UNPOOL, true>), grid, block, 0, s, p);
+        else if (bn_a) IISEG_LAUNCH((conv_c8_m16_kernel<M16_BNRELU, true>), grid, block, 0, s, p);
+        else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, true>), grid, block, 0, s, p);
     } else {
-        if (unpool) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_UNPOOL, false>), grid, block, 0, s, p);
-        else if (bn_a) hipLaunchKernelGGL((conv_c8_m16_kernel<M16_BNRELU, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((conv_c8_m16_kernel<M16_PLAIN, false>), grid, block, 0, s, p);
+        if (unpool) IISEG_LAUNCH((conv_c8_m16_kernel<M16_UNPOOL, false>), grid, block, 0, s, p);
+        else if (bn_a) IISEG_LAUNCH((conv_c8_m16_kernel<M16_BNRELU, false>), grid, block, 0, s, p);
+        else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, false>), grid, block, 0, s, p);
     }
     return iiseg_check_launch();
 }
@@ -491,7 +491,7 @@ extern "C" int iiseg_bn_fold_f32(void* stream, const float* beta, const float* g
                                  const float* inv_std, float* a, float* b, int n) {
     if (!beta || !gamma || !mean || !inv_std || !a || !b) return IISEG_ERR_NULL;
     if (n <= 0) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, beta, gamma,
+    IISEG_LAUNCH(bn_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, beta, gamma,
                        mean, inv_std, a, b, n);
     return iiseg_check_launch();
 }
@@ -503,9 +503,9 @@ extern "C" int iiseg_bn_stats_c8(void* stream, const void* x, int B, int Ctot, i
     if (!x || !mean || !inv_std || !workspace) return IISEG_ERR_NULL;
     if (B <= 0 || Ctot <= 0 || n <= 0 || H <= 0 || W <= 0 || c0 < 0 || c0 + n > Ctot) return IISEG_ERR_SHAPE;
     if (Ctot % 8 || c0 % 8 || n % 8) return IISEG_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_stats_c8_kernel, dim3(n / 8, BN_SLICES), dim3(256), 0, (hipStream_t)stream,
+    IISEG_LAUNCH(bn_stats_c8_kernel, dim3(n / 8, BN_SLICES), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)x, B, Ctot / 8, c0 / 8, H * W, workspace);
-    hipLaunchKernelGGL(bn_stats_c8_final_kernel, dim3(n / 8), dim3(64), 0, (hipStream_t)stream, workspace,
+    IISEG_LAUNCH(bn_stats_c8_final_kernel, dim3(n / 8), dim3(64), 0, (hipStream_t)stream, workspace,
                        c0 / 8, (double)B * H * W, eps, mean, inv_std);
     return iiseg_check_launch();
 }

@@ -283,9 +283,9 @@ int launch64(hipStream_t s, ConvParams64 p, bool unpool) {
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
     if (unpool)
-        hipLaunchKernelGGL((conv_taps_f64_kernel<KH, KW, CPT, true>), dim3(grid), dim3(256), 0, s, p);
+        IISEG_LAUNCH((conv_taps_f64_kernel<KH, KW, CPT, true>), dim3(grid), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_taps_f64_kernel<KH, KW, CPT, false>), dim3(grid), dim3(256), 0, s, p);
+        IISEG_LAUNCH((conv_taps_f64_kernel<KH, KW, CPT, false>), dim3(grid), dim3(256), 0, s, p);
     return iiseg_check_launch();
 }
 
@@ -344,7 +344,7 @@ extern "C" int iiseg_conv_pack_f64(void* stream, const iiseg_conv_desc* d, const
     const int K = (d->C1 + d->C2) * d->KH * d->KW;
     const int64_t n = (int64_t)d->Kpad * d->Mpad;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_pack_f64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+    IISEG_LAUNCH(conv_pack_f64_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
                        stride_o, stride_c, wp, d->KH * d->KW, d->Cout, K, d->Kpad, d->Mpad,
                        (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0);
     return iiseg_check_launch();
@@ -394,7 +394,7 @@ extern "C" int iiseg_im2col_f64(void* stream, const double* x, double* out, int3
     const size_t n = (size_t)B * C * KH * KW * OH * OW;
     size_t g = (n + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(im2col_f64_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, out, B,
+    IISEG_LAUNCH(im2col_f64_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, out, B,
                        C, H, W, KH, KW, OH, OW);
     return iiseg_check_launch();
 }

@@ -419,13 +419,13 @@ int launch_halo(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
     if (unpool && p.mask_in)
-        hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, true, true>), dim3(grid), dim3(256),
+        IISEG_LAUNCH((conv_halo_f32_kernel<BM, TH, WM, WN, true, true>), dim3(grid), dim3(256),
                            0, s, p, tiles_y, tiles_x);
     else if (unpool)
-        hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
+        IISEG_LAUNCH((conv_halo_f32_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
                            p, tiles_y, tiles_x);
     else
-        hipLaunchKernelGGL((conv_halo_f32_kernel<BM, TH, WM, WN, false>), dim3(grid), dim3(256), 0, s,
+        IISEG_LAUNCH((conv_halo_f32_kernel<BM, TH, WM, WN, false>), dim3(grid), dim3(256), 0, s,
                            p, tiles_y, tiles_x);
     return iiseg_check_launch();
 }
@@ -701,13 +701,13 @@ int launch_halo16(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_ptiles = p.B * tiles_y * tiles_x;
     p.n_mtiles = (p.Cout + 15) / 16;
     const dim3 grid(p.n_ptiles * p.n_mtiles), block(256);
-#define H16(U, D) hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, U, D>), grid, block, 0, s, p, tiles_y, tiles_x)
+#define H16(U, D) IISEG_LAUNCH((conv_halo16_f32_kernel<TH, U, D>), grid, block, 0, s, p, tiles_y, tiles_x)
     if (p.bn_mean) {
         if (unpool || p.dil != 1 || p.C2 != 0) return IISEG_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, false, 1, true>), grid, block, 0, s, p, tiles_y,
+        IISEG_LAUNCH((conv_halo16_f32_kernel<TH, false, 1, true>), grid, block, 0, s, p, tiles_y,
                            tiles_x);
     } else if (unpool && p.mask_in) {
-        hipLaunchKernelGGL((conv_halo16_f32_kernel<TH, true, 1, false, true>), grid, block, 0, s, p,
+        IISEG_LAUNCH((conv_halo16_f32_kernel<TH, true, 1, false, true>), grid, block, 0, s, p,
                            tiles_y, tiles_x);
     } else if (unpool) H16(true, 1);
     else switch (p.dil) {

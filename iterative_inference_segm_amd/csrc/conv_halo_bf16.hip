@@ -438,13 +438,13 @@ int launch_halo_bf16(hipStream_t s, const ConvParams& cp, bool unpool) {
     p.n_mtiles = p.Mpad / BM;
     const int grid = p.n_ptiles * p.n_mtiles;
     if (unpool && p.mask_in)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, true, true>), dim3(grid), dim3(256),
+        IISEG_LAUNCH((conv_halo_bf16_kernel<BM, TH, WM, WN, true, true>), dim3(grid), dim3(256),
                            0, s, p, tiles_y, tiles_x);
     else if (unpool)
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
+        IISEG_LAUNCH((conv_halo_bf16_kernel<BM, TH, WM, WN, true>), dim3(grid), dim3(256), 0, s,
                            p, tiles_y, tiles_x);
     else
-        hipLaunchKernelGGL((conv_halo_bf16_kernel<BM, TH, WM, WN, false>), dim3(grid), dim3(256), 0, s,
+        IISEG_LAUNCH((conv_halo_bf16_kernel<BM, TH, WM, WN, false>), dim3(grid), dim3(256), 0, s,
                            p, tiles_y, tiles_x);
     return iiseg_check_launch();
 }
@@ -504,7 +504,7 @@ extern "C" int iiseg_conv_halo_bf16_pack(void* stream, const iiseg_conv_desc* d,
     const int bm = halo_bf16_bm(d->Cout), mpad = (d->Cout + bm - 1) / bm * bm;
     const int64_t n = (int64_t)nkt * 18 * mpad * 8;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(halo_pack_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+    IISEG_LAUNCH(halo_pack_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
                        stride_o, stride_c, (__bf16*)wp16, d->C1 + d->C2, d->Cout, nkt, mpad);
     return iiseg_check_launch();
 }

@@ -386,7 +386,7 @@ extern "C" int iiseg_conv_pack_f32(void* stream, const iiseg_conv_desc* d, const
     const int K = (d->C1 + d->C2) * d->KH * d->KW;
     const int64_t n = (int64_t)d->Kpad * d->Mpad;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
+    IISEG_LAUNCH(conv_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
                        stride_c, wp, reinterpret_cast<int4*>(ktab), d->C1, d->C2, d->KH, d->KW,
                        d->pad, d->dil, d->H, d->W, d->Cout, K, d->Kpad, d->Mpad,
                        (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0);
@@ -403,9 +403,9 @@ static int launch_conv(hipStream_t s, const ConvParams& cp, bool unpool) {
     static const int nog = getenv("IISEG_DEBUG_NOGATHER") ? 1 : 0;
     p.debug_nogather = nog;
     if (unpool)
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(256), dyn, s, p);
+        IISEG_LAUNCH((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), dim3(grid), dim3(256), dyn, s, p);
     else
-        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(256), dyn, s, p);
+        IISEG_LAUNCH((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), dim3(grid), dim3(256), dyn, s, p);
     return iiseg_check_launch();
 }
 

@@ -308,13 +308,13 @@ int launch_taps(hipStream_t s, const ConvParams& cp, bool unpool) {
     const int grid = p.n_ptiles * p.n_mtiles;
     static const int dma = getenv("IISEG_CONV_DMA") ? atoi(getenv("IISEG_CONV_DMA")) : 1;
     if (unpool)
-        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, true, false>),
+        IISEG_LAUNCH((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, true, false>),
                            dim3(grid), dim3(WM * WN * 64), 0, s, p);
     else if (dma)
-        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, true>),
+        IISEG_LAUNCH((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, true>),
                            dim3(grid), dim3(WM * WN * 64), 0, s, p);
     else
-        hipLaunchKernelGGL((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, false>),
+        IISEG_LAUNCH((conv_taps_f32_kernel<BM, BN, WM, WN, KH, KW, CPT, false, false>),
                            dim3(grid), dim3(WM * WN * 64), 0, s, p);
     return iiseg_check_launch();
 }

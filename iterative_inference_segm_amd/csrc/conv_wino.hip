@@ -787,7 +787,7 @@ void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
     if (lds && nt && best >= 0.8 && p.Kc % ILDS_CH == 0) {
         const int chunks = (ntt + nt - 1) / nt;
         const dim3 g2(p.B * chunks, p.Kc / ILDS_CH);
-#define WINO_ILDS(U, N) hipLaunchKernelGGL((wino_input_lds_kernel<U, N>), g2, dim3(N), 0, s, p, chunks)
+#define WINO_ILDS(U, N) IISEG_LAUNCH((wino_input_lds_kernel<U, N>), g2, dim3(N), 0, s, p, chunks)
         if (unpool) { if (nt == 256) WINO_ILDS(true, 256); else if (nt == 128) WINO_ILDS(true, 128); else WINO_ILDS(true, 64); }
         else { if (nt == 256) WINO_ILDS(false, 256); else if (nt == 128) WINO_ILDS(false, 128); else WINO_ILDS(false, 64); }
 #undef WINO_ILDS
@@ -796,14 +796,14 @@ void launch_wino_input(hipStream_t s, const WinoParams& p, bool unpool) {
     const int nc = unpool ? ICH / 2 : ICH;   // channels per thread
     const dim3 grid((p.T + 255) / 256, (p.Kc + nc - 1) / nc), block(256);
     if (!unpool) {
-        hipLaunchKernelGGL((wino_input_kernel<false, 0, 0>), grid, block, 0, s, p);
+        IISEG_LAUNCH((wino_input_kernel<false, 0, 0>), grid, block, 0, s, p);
         return;
     }
     const int py = (p.ty0 - p.pad) & 1, px = (p.tx0 - p.pad) & 1;  // patch-origin parity
-    if (py && px) hipLaunchKernelGGL((wino_input_kernel<true, 1, 1>), grid, block, 0, s, p);
-    else if (py) hipLaunchKernelGGL((wino_input_kernel<true, 1, 0>), grid, block, 0, s, p);
-    else if (px) hipLaunchKernelGGL((wino_input_kernel<true, 0, 1>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((wino_input_kernel<true, 0, 0>), grid, block, 0, s, p);
+    if (py && px) IISEG_LAUNCH((wino_input_kernel<true, 1, 1>), grid, block, 0, s, p);
+    else if (py) IISEG_LAUNCH((wino_input_kernel<true, 1, 0>), grid, block, 0, s, p);
+    else if (px) IISEG_LAUNCH((wino_input_kernel<true, 0, 1>), grid, block, 0, s, p);
+    else IISEG_LAUNCH((wino_input_kernel<true, 0, 0>), grid, block, 0, s, p);
 }
 
 }  // namespace
@@ -831,7 +831,7 @@ int iiseg_wino_output_launch(hipStream_t s, const iiseg_conv_desc* d, const floa
     p.out_W = d->out_H > 0 ? d->out_W : d->OW;
     p.out_y0 = d->out_H > 0 ? d->out_y0 : 0;
     p.out_x0 = d->out_H > 0 ? d->out_x0 : 0;
-    hipLaunchKernelGGL(wino_output_kernel, dim3((p.T + 255) / 256, (d->Cout + OCH - 1) / OCH),
+    IISEG_LAUNCH(wino_output_kernel, dim3((p.T + 255) / 256, (d->Cout + OCH - 1) / OCH),
                        dim3(256), 0, s, p);
     return iiseg_check_launch();
 }
@@ -861,7 +861,7 @@ extern "C" int iiseg_conv_wino_pack_f32(void* stream, const iiseg_conv_desc* d, 
     if (!w || !U) return IISEG_ERR_NULL;
     const int64_t n = (int64_t)g.Kc * g.Mpad;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+    IISEG_LAUNCH(wino_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
                        stride_o, stride_c, U, d->C1 + d->C2, d->Cout, g.Kc, g.Mpad);
     return iiseg_check_launch();
 }
@@ -922,7 +922,7 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         if (stages & IISEG_WINO_GEMM) {
             if (g.bm == 64) {   // narrow layers (Cout <= 64): 64-channel tiles, 4 waves of 64 x 32
                 p.n_mtiles = g.Mpad / 64;
-                hipLaunchKernelGGL((wino_fused_kernel<64, 128, 1, 4, 32, 2>),
+                IISEG_LAUNCH((wino_fused_kernel<64, 128, 1, 4, 32, 2>),
                                    dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
                 return iiseg_check_launch();
             }
@@ -940,16 +940,16 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
             if (g.Kc <= 128 || cost2 < cost0) {
                 p.n_ttiles = g.Tpad / 64;
                 if (big)
-                    hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 2, 64, 2>),
+                    IISEG_LAUNCH((wino_fused_kernel<128, 64, 2, 2, 64, 2>),
                                        dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
                 else
-                hipLaunchKernelGGL((wino_fused_kernel<128, 64, 2, 2, 32, 2>),
+                IISEG_LAUNCH((wino_fused_kernel<128, 64, 2, 2, 32, 2>),
                                    dim3(p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
             } else if (big)
-                hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 64, 2>),
+                IISEG_LAUNCH((wino_fused_kernel<128, 128, 2, 4, 64, 2>),
                                    dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
             else
-            hipLaunchKernelGGL((wino_fused_kernel<128, 128, 2, 4, 32, 2>),
+            IISEG_LAUNCH((wino_fused_kernel<128, 128, 2, 4, 32, 2>),
                                dim3(p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p);
         }
         return iiseg_check_launch();
@@ -961,7 +961,7 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         static const int nbuf = getenv("IISEG_WINO_NBUF") ? atoi(getenv("IISEG_WINO_NBUF")) : 2;
         int bm = g.bm;
         if (bm == 64) {
-            hipLaunchKernelGGL((wino_gemm_kernel<64, 128, 1, 4, 2>), dim3(grid), dim3(256), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<64, 128, 1, 4, 2>), dim3(grid), dim3(256), 0, s, p);
             bm = 0;
         }
         if (bm == 256) {
@@ -978,22 +978,22 @@ extern "C" int iiseg_conv_wino_f32(void* stream, const iiseg_conv_desc* d, const
         static const int bk32 = getenv("IISEG_WINO_GEMM_BK") ? atoi(getenv("IISEG_WINO_GEMM_BK")) == 32 : 0;
         if (bm && bk32 && g.Kc % 32 == 0 && nbuf != 3) {
             if (bm == 256)
-                hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2, 32>), dim3(grid), dim3(512), 0, s, p);
+                IISEG_LAUNCH((wino_gemm_kernel<256, 128, 4, 2, 2, 32>), dim3(grid), dim3(512), 0, s, p);
             else
-                hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2, 32>), dim3(grid2), dim3(256), 0, s, p);
+                IISEG_LAUNCH((wino_gemm_kernel<128, 128, 2, 2, 2, 32>), dim3(grid2), dim3(256), 0, s, p);
         } else
         if (bm == 0) {
         } else if (bm == 256 && nbuf == 3)
-            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 3>), dim3(grid), dim3(512), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<256, 128, 4, 2, 3>), dim3(grid), dim3(512), 0, s, p);
         else if (bm == 256)
-            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
         else if (nbuf == 3)
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 3>), dim3(grid2), dim3(256), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<128, 128, 2, 2, 3>), dim3(grid2), dim3(256), 0, s, p);
         else
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid2), dim3(256), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid2), dim3(256), 0, s, p);
     }
     if (stages & IISEG_WINO_OUTPUT)
-        hipLaunchKernelGGL(wino_output_kernel, dim3(tb, (d->Cout + OCH - 1) / OCH), dim3(256), 0, s,
+        IISEG_LAUNCH(wino_output_kernel, dim3(tb, (d->Cout + OCH - 1) / OCH), dim3(256), 0, s,
                            p);
     return iiseg_check_launch();
 }
@@ -1099,7 +1099,7 @@ int gemm_conv_geom(const iiseg_conv_desc* d, GemmConvGeom& g) {
 int iiseg_gemm_output_launch(hipStream_t s, const float* M, const float* bias, float* out, int Cout,
                              int OHW, int T, int Tpad, int Mpad, int relu) {
     const int cy = Cout < 1024 ? Cout : 1024;
-    hipLaunchKernelGGL(gemm_output_kernel, dim3((T + 255) / 256, cy), dim3(256), 0, s, M, bias, out,
+    IISEG_LAUNCH(gemm_output_kernel, dim3((T + 255) / 256, cy), dim3(256), 0, s, M, bias, out,
                        Cout, OHW, T, Tpad, Mpad, 1, relu);
     return iiseg_check_launch();
 }
@@ -1128,7 +1128,7 @@ extern "C" int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const
     float* M = workspace + (size_t)g.Kpad * g.Tpad;
     const int OH = d->OH, OW = d->OW, tb = (g.T + 255) / 256;
     if (stages & IISEG_WINO_INPUT)
-        hipLaunchKernelGGL(gemm_im2col_kernel, dim3(tb, g.Kpad < 1024 ? g.Kpad : 1024), dim3(256), 0,
+        IISEG_LAUNCH(gemm_im2col_kernel, dim3(tb, g.Kpad < 1024 ? g.Kpad : 1024), dim3(256), 0,
                            s, x, V, d->B, d->C1, d->H, d->W, d->KH, d->KW, OH, OW, g.K, g.Kpad, g.T,
                            g.Tpad);
     WinoParams p = {};
@@ -1144,13 +1144,13 @@ extern "C" int iiseg_conv_gemm_f32(void* stream, const iiseg_conv_desc* d, const
     const int grid = g.S * p.n_ttiles * p.n_mtiles;
     if (stages & IISEG_WINO_GEMM) {
         if (g.bm == 256)
-            hipLaunchKernelGGL((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<256, 128, 4, 2, 2>), dim3(grid), dim3(512), 0, s, p);
         else
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+            IISEG_LAUNCH((wino_gemm_kernel<128, 128, 2, 2, 2>), dim3(grid), dim3(256), 0, s, p);
     }
     const int cy = d->Cout < 1024 ? d->Cout : 1024;
     if (stages & IISEG_WINO_OUTPUT)
-        hipLaunchKernelGGL(gemm_output_kernel, dim3(tb, cy), dim3(256), 0, s, M, bias, out, d->Cout,
+        IISEG_LAUNCH(gemm_output_kernel, dim3(tb, cy), dim3(256), 0, s, M, bias, out, d->Cout,
                            OH * OW, g.T, g.Tpad, g.Mpad, g.S, (d->flags & IISEG_CONV_RELU) ? 1 : 0);
     return iiseg_check_launch();
 }

@@ -374,24 +374,24 @@ void launch_wino_input_bf16(hipStream_t s, const WinoBfParams& p, bool unpool) {
         const int chunks = (ntt + nt - 1) / nt;
         const dim3 g2(p.B * chunks, p.Kc / 8);
         if (unpool) {
-            if (nt == 256) hipLaunchKernelGGL((wino_input_lds_bf16_kernel<true, 256>), g2, dim3(256), 0, s, p, chunks);
-            else hipLaunchKernelGGL((wino_input_lds_bf16_kernel<true, 128>), g2, dim3(128), 0, s, p, chunks);
+            if (nt == 256) IISEG_LAUNCH((wino_input_lds_bf16_kernel<true, 256>), g2, dim3(256), 0, s, p, chunks);
+            else IISEG_LAUNCH((wino_input_lds_bf16_kernel<true, 128>), g2, dim3(128), 0, s, p, chunks);
         } else {
-            if (nt == 256) hipLaunchKernelGGL((wino_input_lds_bf16_kernel<false, 256>), g2, dim3(256), 0, s, p, chunks);
-            else hipLaunchKernelGGL((wino_input_lds_bf16_kernel<false, 128>), g2, dim3(128), 0, s, p, chunks);
+            if (nt == 256) IISEG_LAUNCH((wino_input_lds_bf16_kernel<false, 256>), g2, dim3(256), 0, s, p, chunks);
+            else IISEG_LAUNCH((wino_input_lds_bf16_kernel<false, 128>), g2, dim3(128), 0, s, p, chunks);
         }
         return;
     }
     const dim3 grid((p.T + 255) / 256, p.Kc / 8), block(256);
     if (!unpool) {
-        hipLaunchKernelGGL((wino_input_bf16_kernel<false, 0, 0>), grid, block, 0, s, p);
+        IISEG_LAUNCH((wino_input_bf16_kernel<false, 0, 0>), grid, block, 0, s, p);
         return;
     }
     const int py = (p.ty0 - p.pad) & 1, px = (p.tx0 - p.pad) & 1;  // patch-origin parity
-    if (py && px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 1>), grid, block, 0, s, p);
-    else if (py) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 1, 0>), grid, block, 0, s, p);
-    else if (px) hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 1>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((wino_input_bf16_kernel<true, 0, 0>), grid, block, 0, s, p);
+    if (py && px) IISEG_LAUNCH((wino_input_bf16_kernel<true, 1, 1>), grid, block, 0, s, p);
+    else if (py) IISEG_LAUNCH((wino_input_bf16_kernel<true, 1, 0>), grid, block, 0, s, p);
+    else if (px) IISEG_LAUNCH((wino_input_bf16_kernel<true, 0, 1>), grid, block, 0, s, p);
+    else IISEG_LAUNCH((wino_input_bf16_kernel<true, 0, 0>), grid, block, 0, s, p);
 }
 
 // ---- 2+3. the 16 GEMMs + output transform + epilogue in one kernel --------------------------------
@@ -783,18 +783,18 @@ void launch_gemm_bf16(hipStream_t s, WinoBfParams p, float* M, int n_xi) {
         // carries twice the flops of the 256 x 128 form for 1.2x its time
         p.n_ttiles = p.Tpad / 256;
         p.n_mtiles = p.Mpad / 256;
-        hipLaunchKernelGGL((wino_gemm_bf16_kernel<256, 256, 2, 4, 64, 2>),
+        IISEG_LAUNCH((wino_gemm_bf16_kernel<256, 256, 2, 4, 64, 2>),
                            dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
         return;
     }
     p.n_ttiles = p.Tpad / 128;
     if (p.Mpad % 256 == 0) {
         p.n_mtiles = p.Mpad / 256;
-        hipLaunchKernelGGL((wino_gemm_bf16_kernel<256, 128, 4, 2, 64, 3>),
+        IISEG_LAUNCH((wino_gemm_bf16_kernel<256, 128, 4, 2, 64, 3>),
                            dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
     } else {
         p.n_mtiles = p.Mpad / 128;
-        hipLaunchKernelGGL((wino_gemm_bf16_kernel<128, 128, 2, 2, 64, 3>),
+        IISEG_LAUNCH((wino_gemm_bf16_kernel<128, 128, 2, 2, 64, 3>),
                            dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p, M);
     }
 }
@@ -887,7 +887,7 @@ extern "C" int iiseg_conv_wino_bf16_pack(void* stream, const iiseg_conv_desc* d,
     if ((uintptr_t)U16 & 15) return IISEG_ERR_ALIGN;
     const int64_t n = (int64_t)g.Kc * g.Mpad;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wino_weight_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+    IISEG_LAUNCH(wino_weight_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
                        stride_o, stride_c, (__bf16*)U16, d->C1 + d->C2, d->Cout, g.Kc, g.Mpad);
     return iiseg_check_launch();
 }
@@ -951,8 +951,8 @@ extern "C" int iiseg_conv_wino_bf16(void* stream, const iiseg_conv_desc* d, cons
 #define WBF_UNPAREN(...) __VA_ARGS__
 #define WBF_FUSED_LAUNCH(ARGS, GRID, BLOCK)                                                        \
     do {                                                                                           \
-        if (minw2) hipLaunchKernelGGL((wino_fused_bf16_kernel<WBF_UNPAREN ARGS, 2>), GRID, BLOCK, 0, s, p); \
-        else hipLaunchKernelGGL((wino_fused_bf16_kernel<WBF_UNPAREN ARGS, 1>), GRID, BLOCK, 0, s, p);      \
+        if (minw2) IISEG_LAUNCH((wino_fused_bf16_kernel<WBF_UNPAREN ARGS, 2>), GRID, BLOCK, 0, s, p); \
+        else IISEG_LAUNCH((wino_fused_bf16_kernel<WBF_UNPAREN ARGS, 1>), GRID, BLOCK, 0, s, p);      \
     } while (0)
     if (stages & IISEG_WINO_GEMM) {
         if (g.bm == 64) {
@@ -1101,7 +1101,7 @@ extern "C" int iiseg_conv_gemm_bf16_pack(void* stream, const iiseg_conv_desc* d,
     if ((uintptr_t)U16 & 15) return IISEG_ERR_ALIGN;
     const int64_t n = (int64_t)g.Kc * g.Mpad;
     const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(gemm_weight_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+    IISEG_LAUNCH(gemm_weight_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
                        stride_o, stride_c, (__bf16*)U16, d->KH * d->KW, g.K, d->Cout, g.Kc, g.Mpad);
     return iiseg_check_launch();
 }
@@ -1117,7 +1117,7 @@ extern "C" int iiseg_conv_gemm_bf16(void* stream, const iiseg_conv_desc* d, cons
     uint4* V = (uint4*)workspace;
     float* M = (float*)((char*)workspace + (size_t)g.Kc * g.Tpad * 2);
     const int kcr = g.Kc >> 3;
-    hipLaunchKernelGGL(gemm_im2col_bf16_kernel, dim3((g.T + 255) / 256, kcr < 512 ? kcr : 512),
+    IISEG_LAUNCH(gemm_im2col_bf16_kernel, dim3((g.T + 255) / 256, kcr < 512 ? kcr : 512),
                        dim3(256), 0, s, x, V, d->C1, d->H, d->W, d->KH, d->KW, d->OH, d->OW, g.K,
                        g.Kc, g.T, g.Tpad);
     WinoBfParams p = {};

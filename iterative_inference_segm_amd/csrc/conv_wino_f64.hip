@@ -388,7 +388,7 @@ extern "C" int iiseg_conv_wino_pack_f64(void* stream, const iiseg_conv_desc* d, 
     if (!w || !U) return IISEG_ERR_NULL;
     const int64_t n = (int64_t)g.Kc * g.Mpad;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wino64_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
+    IISEG_LAUNCH(wino64_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o,
                        stride_c, U, d->C1 + d->C2, d->Cout, g.Kc, g.Mpad);
     return iiseg_check_launch();
 }
@@ -434,10 +434,10 @@ extern "C" int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const
     hipStream_t s = (hipStream_t)stream;
     const int tb = (g.T + 255) / 256;
     if (unpool)
-        hipLaunchKernelGGL(wino64_input_kernel<true>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
+        IISEG_LAUNCH(wino64_input_kernel<true>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL(wino64_input_kernel<false>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(wino64_gemm_kernel, dim3(16 * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(wino64_output_kernel, dim3(tb, (d->Cout + OCH64 - 1) / OCH64), dim3(256), 0, s, p);
+        IISEG_LAUNCH(wino64_input_kernel<false>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
+    IISEG_LAUNCH(wino64_gemm_kernel, dim3(16 * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+    IISEG_LAUNCH(wino64_output_kernel, dim3(tb, (d->Cout + OCH64 - 1) / OCH64), dim3(256), 0, s, p);
     return iiseg_check_launch();
 }

@@ -92,10 +92,10 @@ int deconv(void* stream, const iiseg_deconv_desc* d, const T* x, const T* w, con
     size_t g = (n + 255) / 256;
     if (g > 16384) g = 16384;
     if (d->Cout <= 16)
-        hipLaunchKernelGGL((deconv_gather_kernel<T, 16>), dim3((int)g), dim3(256), 0,
+        IISEG_LAUNCH((deconv_gather_kernel<T, 16>), dim3((int)g), dim3(256), 0,
                            (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL((deconv_gather_kernel<T, 32>), dim3((int)g), dim3(256), 0,
+        IISEG_LAUNCH((deconv_gather_kernel<T, 32>), dim3((int)g), dim3(256), 0,
                            (hipStream_t)stream, p);
     return iiseg_check_launch();
 }

@@ -74,7 +74,7 @@ int confusion(void* stream, const T* y, const T* t, const int32_t* active, int64
     if (!y || !t || !cm || !sums) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
     if (C >= MAXC || B > 65535) return IISEG_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(confusion_kernel<T>, dim3((HW + 256 * PPT - 1) / (256 * PPT), B), dim3(256), 0,
+    IISEG_LAUNCH(confusion_kernel<T>, dim3((HW + 256 * PPT - 1) / (256 * PPT), B), dim3(256), 0,
                        (hipStream_t)stream, y, t, active,
                        reinterpret_cast<unsigned long long*>(cm), sums, C, HW);
     return iiseg_check_launch();

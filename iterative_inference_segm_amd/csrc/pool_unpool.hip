@@ -154,7 +154,7 @@ int maxpool(void* stream, const T* x, T* out, int32_t BC, int32_t H, int32_t W) 
     if (!x || !out) return IISEG_ERR_NULL;
     if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
     const int h = H / 2, w = W / 2;
-    hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid_for((size_t)BC * h * w)), dim3(256), 0,
+    IISEG_LAUNCH(maxpool2x2_kernel<T>, dim3(grid_for((size_t)BC * h * w)), dim3(256), 0,
                        (hipStream_t)stream, x, out, BC, H, W, h, w);
     return iiseg_check_launch();
 }
@@ -164,7 +164,7 @@ int unpool(void* stream, const T* up, const T* pre, const T* pooled, T* out, int
            int32_t W) {
     if (!up || !pre || !pooled || !out) return IISEG_ERR_NULL;
     if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(unpool_eqmask_kernel<T>, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
+    IISEG_LAUNCH(unpool_eqmask_kernel<T>, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
                        (hipStream_t)stream, up, pre, pooled, out, BC, H, W, H / 2, W / 2);
     return iiseg_check_launch();
 }
@@ -176,7 +176,7 @@ int maxpool_window(void* stream, const T* x, T* out, int32_t BC, int32_t H, int3
     if (BC <= 0 || H < 2 || W < 2 || y0 < 0 || x0 < 0 || wh <= 0 || ww <= 0 || y0 + wh > H / 2 ||
         x0 + ww > W / 2)
         return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(maxpool2x2_window_kernel<T>, dim3(grid_for((size_t)BC * wh * ww)), dim3(256),
+    IISEG_LAUNCH(maxpool2x2_window_kernel<T>, dim3(grid_for((size_t)BC * wh * ww)), dim3(256),
                        0, (hipStream_t)stream, x, out, BC, H, W, H / 2, W / 2, y0, x0, wh, ww);
     return iiseg_check_launch();
 }
@@ -188,7 +188,7 @@ int unpool_window(void* stream, const T* up, const T* pre, const T* pooled, T* o
     if (BC <= 0 || H < 2 || W < 2 || y0 < 0 || x0 < 0 || wh <= 0 || ww <= 0 || y0 + wh > H ||
         x0 + ww > W)
         return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(unpool_eqmask_window_kernel<T>, dim3(grid_for((size_t)BC * wh * ww)),
+    IISEG_LAUNCH(unpool_eqmask_window_kernel<T>, dim3(grid_for((size_t)BC * wh * ww)),
                        dim3(256), 0, (hipStream_t)stream, up, pre, pooled, out, BC, H, W, H / 2,
                        W / 2, y0, x0, wh, ww);
     return iiseg_check_launch();
@@ -199,7 +199,7 @@ int depool_bwd(void* stream, const T* gout, const T* pre, const T* pooled, T* gu
                int32_t H, int32_t W) {
     if (!gout || !pre || !pooled || !gup) return IISEG_ERR_NULL;
     if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(depool_bwd_kernel<T>, dim3(grid_for((size_t)BC * (H / 2) * (W / 2))), dim3(256),
+    IISEG_LAUNCH(depool_bwd_kernel<T>, dim3(grid_for((size_t)BC * (H / 2) * (W / 2))), dim3(256),
                        0, (hipStream_t)stream, gout, pre, pooled, gup, BC, H, W, H / 2, W / 2);
     return iiseg_check_launch();
 }
@@ -209,7 +209,7 @@ int pool_relu_bwd(void* stream, const T* gpool, const T* pre, const T* pooled, T
                   int32_t H, int32_t W) {
     if (!gpool || !pre || !pooled || !gz) return IISEG_ERR_NULL;
     if (BC <= 0 || H < 2 || W < 2) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(pool_relu_bwd_kernel<T>, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
+    IISEG_LAUNCH(pool_relu_bwd_kernel<T>, dim3(grid_for((size_t)BC * H * W)), dim3(256), 0,
                        (hipStream_t)stream, gpool, pre, pooled, gz, BC, H, W, H / 2, W / 2);
     return iiseg_check_launch();
 }

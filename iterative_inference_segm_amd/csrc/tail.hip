@@ -220,10 +220,10 @@ int crop_softmax(void* stream, const T* score, const T* minuend, T* out, int32_t
     if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
-        hipLaunchKernelGGL((crop_softmax_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH((crop_softmax_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, minuend, out, C, SH, SW, sy0, sx0, H, W);
     else
-        hipLaunchKernelGGL((crop_softmax_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH((crop_softmax_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, minuend, out, C, SH, SW, sy0, sx0, H, W);
     return iiseg_check_launch();
 }
@@ -239,11 +239,11 @@ int refine_update(void* stream, const T* score, T* y, const int32_t* active, dou
     if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
-        hipLaunchKernelGGL((refine_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH((refine_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step, (uint4*)y8,
                            C8n);
     else
-        hipLaunchKernelGGL((refine_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH((refine_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, y, active, partial, C, SH, SW, sy0, sx0, H, W, step, (uint4*)y8,
                            C8n);
     return iiseg_check_launch();
@@ -258,10 +258,10 @@ int sqerr_softmax_bwd(void* stream, const T* score, const T* y, T* gscore, int32
     if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
-        hipLaunchKernelGGL((sqerr_softmax_bwd_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH((sqerr_softmax_bwd_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, y, gscore, C, SH, SW, sy0, sx0, H, W);
     else
-        hipLaunchKernelGGL((sqerr_softmax_bwd_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
+        IISEG_LAUNCH((sqerr_softmax_bwd_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream,
                            score, y, gscore, C, SH, SW, sy0, sx0, H, W);
     return iiseg_check_launch();
 }
@@ -276,10 +276,10 @@ int grad_update(void* stream, const T* score, const T* gthrough, T* y, const int
     if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
-        hipLaunchKernelGGL((grad_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
+        IISEG_LAUNCH((grad_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
                            gthrough, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
     else
-        hipLaunchKernelGGL((grad_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
+        IISEG_LAUNCH((grad_update_kernel<32, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
                            gthrough, y, active, partial, C, SH, SW, sy0, sx0, H, W, step);
     return iiseg_check_launch();
 }
@@ -350,7 +350,7 @@ extern "C" int iiseg_refine_finalize(void* stream, const double* partial, int32_
                                      int32_t HW, double eps) {
     if (!partial || !active || !iters || !last_norm) return IISEG_ERR_NULL;
     if (B <= 0 || nblk <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(refine_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0,
+    IISEG_LAUNCH(refine_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0,
                        (hipStream_t)stream, partial, active, iters, last_norm, B, nblk, HW, eps);
     return iiseg_check_launch();
 }
@@ -382,7 +382,7 @@ template <typename T>
 int add_noise(void* stream, const T* x, const T* eps, T sigma, T* out, int64_t n) {
     if (!x || !eps || !out) return IISEG_ERR_NULL;
     if (n <= 0) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(axpy_kernel<T>, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x,
+    IISEG_LAUNCH(axpy_kernel<T>, dim3(ew_grid((size_t)n)), dim3(256), 0, (hipStream_t)stream, x,
                        eps, sigma, out, (size_t)n);
     return iiseg_check_launch();
 }
@@ -390,7 +390,7 @@ template <typename T>
 int dropout_apply(void* stream, T* x, const T* keep, T p, int64_t n) {
     if (!x || !keep) return IISEG_ERR_NULL;
     if (n <= 0 || !(p >= 0) || !(p < 1)) return IISEG_ERR_SHAPE;
-    hipLaunchKernelGGL(scale_mask_kernel<T>, dim3(ew_grid((size_t)n)), dim3(256), 0,
+    IISEG_LAUNCH(scale_mask_kernel<T>, dim3(ew_grid((size_t)n)), dim3(256), 0,
                        (hipStream_t)stream, x, keep, (T)1 / ((T)1 - p), (size_t)n);
     return iiseg_check_launch();
 }

@@ -52,10 +52,10 @@ DEFAULT_MMA = os.environ.get('IISEG_MMA', 'f32')
 # Winograd kernels (conv_wino_bf16.hip); below, the direct bf16 kernel won every measured case
 #  and also fuses the pool and the DePool2D byte masks
 BF16_WINO_MIN_CIN = int(os.environ.get('IISEG_BF16_WINO_MIN_CIN', '256'))
-# Both 16-bit forms possible for a layer (Winograd / direct): the choice is DETERMINISTIC -- a committed
-# table of measured winners per launch geometry (bf16_picks.json, written by scripts/tune_bf16.py on an
-# MI355X; keys without the batch size) and, for a geometry the table does not hold, a static rule on
-# the geometry alone (`_bf16_static_pick`).  Two processes, two ranks, two runs make the same choices,
+# Both 16-bit forms possible for a layer (Winograd / direct): the choice is DETERMINISTIC -- an optional
+# table of measured winners per launch geometry (bf16_picks.json beside this file, keys without the
+# batch size; NONE is shipped: the static rule decides everywhere) and, for a geometry the table does
+# not hold, a static rule on the geometry alone (`_bf16_static_pick`).  Two processes, two ranks, two runs make the same choices,
 # so bf16 outputs are reproducible and identical across the ranks of a data-parallel evaluation, and a
 # loop-invariant border and its recomputed window come from the same form.  IISEG_BF16_TUNE=1 (the
 # generating script only) times both forms for keys the table lacks and records them in BF16_PICKS.
@@ -146,8 +146,45 @@ def workspace_ptrs(device):
     return tuple(None if t is None else t.data_ptr() for t in workspace_refs(device))
 
 
+# Dispatch timing (bench.py's roofline pass, `profile_begin` / `profile_end`): the two "events" around a
+# conv call are positions in the library's launch sequence, and the time between them is the sum of the
+# execution times of the kernels launched in between -- each measured by the start / stop HIP events its
+# own dispatch carries (include/iiseg.h iiseg_profile_begin).  Off: torch events recorded on the stream.
+_DISPATCH_TIMING = [False]
+PROFILE_MS = []
+
+
+class _LaunchMark:
+    def __init__(self, n):
+        self.n = n
+
+    def elapsed_time(self, other):
+        return float(sum(PROFILE_MS[self.n:other.n]))
+
+
+def profile_begin(capacity=16384):
+    check(_lib.load().iiseg_profile_begin(int(capacity)), 'iiseg_profile_begin')
+    _DISPATCH_TIMING[0] = True
+    del PROFILE_MS[:]
+
+
+def profile_end():
+    """Ends the pass and fills PROFILE_MS (one entry per launch of the library, in launch order)."""
+    _DISPATCH_TIMING[0] = False
+    cap = 16384
+    buf = (C.c_float * cap)()
+    n = _lib.load().iiseg_profile_end(buf, cap)
+    if n < 0:
+        raise RuntimeError('iiseg_profile_end: %d' % n)
+    PROFILE_MS[:] = list(buf[:n])
+    return n
+
+
 def _ev():
-    """A HIP event recorded on the launch stream right now (bench.py's roofline leg)."""
+    """A mark on the launch stream right now (bench.py's roofline leg): a HIP event recorded on it, or,
+    under dispatch timing, the position in the library's launch sequence."""
+    if _DISPATCH_TIMING[0]:
+        return _LaunchMark(_lib.load().iiseg_profile_count())
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
     return ev

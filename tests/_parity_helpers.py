@@ -78,16 +78,15 @@ def assert_within_reference_sensitivity(ii32, ii64, o32, o64, steps, step=0.1, f
     With the default (random, non-contractive) DAE weights the loop amplifies any perturbation: the
     float64 path fed with y0 * (1 + 1e-7 u), below float32 resolution, leaves the 1e-4 band on most
     pixels after 10 steps (profiles/r02_sensitivity.md).  So for more than one step nothing with a
-    fixed number can be asserted about ANY float32 implementation, and nothing is: what is ASSERTED
-    here has fixed, a-priori thresholds --
+    fixed ABSOLUTE number can be asserted about ANY float32 implementation; what is ASSERTED here --
       * the inputs of the loop (FCN-8 / DenseNet outputs, no masks involved): y0 within 1e-4, h within
         1e-4 relative to its range;
-      * ONE free-running step: argmax agreement >= 0.999 and mean |err| <= 1e-4 against the float64 path.
-    For every requested step count the deviation of the fp32 path is then PRINTED next to the float64
-    path's own deviation when its inputs are perturbed at the MEASURED input error of the fp32 path
-    (max |y0_fp32 - y0_f64| absolute on the probability map, max |h_fp32 - h_f64| relative to h's range
-    -- no chosen constant), as the record of how the loop behaves; `factor` is kept for signature
-    compatibility and ignored."""
+      * ONE free-running step: argmax agreement >= 0.999 and mean |err| <= 1e-4 against the float64 path;
+      * EVERY requested step count: the deviation of the fp32 path RELATIVE to the float64 path's own
+        deviation when its inputs are perturbed at the MEASURED input error of the fp32 path (max
+        |y0_fp32 - y0_f64| absolute on the probability map, max |h_fp32 - h_f64| relative to h's range --
+        no chosen constant): mean deviation <= 2 x, argmax agreement >= that - 0.05.
+    Both are printed; `factor` is kept for signature compatibility and ignored."""
     H32, Y32, H64, Y64 = o32[:-1], o32[-1], o64[:-1], o64[-1]
     eps_y = float((Y32.double() - Y64).abs().max())
     eps_h = [float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(H32, H64)]
@@ -110,5 +109,10 @@ def assert_within_reference_sensitivity(ii32, ii64, o32, o64, steps, step=0.1, f
                                  s_got[1], s_got[2]))
         if n == 1:
             assert s_got[0] >= 0.999 and s_got[1] <= TOL, (label, s_got)
+        # EVERY step count, on these (the bench's) weights: the fp32 path stays within the reference
+        # function's own sensitivity -- its mean deviation at most twice, and its argmax agreement at
+        # most 0.05 below, what the float64 path shows against itself when only its inputs move by the
+        # fp32 path's measured input error (measured ratios 0.13 .. 1.0 over all configs and step counts)
+        assert s_got[1] <= 2.0 * max(s_ref[1], 1e-7) and s_got[0] >= s_ref[0] - 0.05, (label, n, s_ref, s_got)
         out.append((n, s_ref, s_got))
     return out

@@ -370,7 +370,7 @@ def test_config3_densenet_runs_in_bf16(built_lib):
 
 def test_bf16_form_choice_is_shared_and_batch_independent(ops, monkeypatch):
     """Where both 16-bit forms can run a layer the choice is a function of the launch geometry alone
-    (committed table ops.BF16_PICKS, else the static rule): two Conv objects of the same shape make
+    (an optional table ops.BF16_PICKS -- none is shipped -- else the static rule): two Conv objects of the same shape make
     the same choice (two engines, two ranks, two runs agree bit for bit), and so does the same layer
     on another batch size (an image alone == in a batch).  Nothing is timed at run time: the table
     is not written to.  Both forms are reachable (forced) and differ in their bits, i.e. the

@@ -596,3 +596,40 @@ def test_mask_bytes_are_refused_off_the_halo_kernels(ops):
     up = dev(rnd(rng, 1, 32, 4, 4))
     with pytest.raises(RuntimeError):
         conv(up, mask_in=torch.zeros((1, 32, 4, 4), dtype=torch.uint8, device='cuda'), unpool_hw=(8, 8))
+
+
+def test_dispatch_timing_of_launches(built_lib):
+    """Launch profiling (include/iiseg.h iiseg_profile_begin / _end): every launch of the library between
+    the two calls carries start / stop events on its dispatch; the per-launch times are positive, their
+    count is the number of launches, and their sum is not larger than a bracket of separately recorded
+    events around the same launches (which also holds the gaps between the kernels)."""
+    import torch
+    from iterative_inference_segm_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.iiseg_profile_count() == -1
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.rand(4, 64, 60, 60, device='cuda', generator=g)
+    W = torch.randn(64, 64, 3, 3, device='cuda', generator=g) * 0.05
+    conv = ops.Conv(W, None, pad=1, relu=True)
+    conv(x); conv(x)
+    torch.cuda.synchronize()
+    ops.profile_begin()
+    ops.CONV_PROFILE = prof = []
+    try:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            conv(x)
+        p = ops.maxpool2x2(x)
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_PROFILE = None
+        n = ops.profile_end()
+    assert lib.iiseg_profile_count() == -1
+    assert n == 6 and len(ops.PROFILE_MS) == 6 and all(t > 0 for t in ops.PROFILE_MS)
+    per_conv = [s.elapsed_time(e) for _, _, s, e in prof]
+    assert len(per_conv) == 5 and all(t > 0 for t in per_conv)
+    assert abs(sum(per_conv) - sum(ops.PROFILE_MS[:5])) < 1e-6
+    assert sum(ops.PROFILE_MS) <= e0.elapsed_time(e1) * 1.05
+    assert tuple(p.shape) == (4, 64, 30, 30)
