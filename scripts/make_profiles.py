@@ -132,7 +132,7 @@ def pmc3(prof, out, commit, legs):
         return per
     union = {}
     with open(out, 'w') as f:
-        f.write('# r03 -- rocprofv3 PMC passes (scripts/profile_r03.sh; one bench batch + load-time work '
+        f.write('# ' + os.path.basename(out)[:3] + ' -- rocprofv3 PMC passes (scripts/profile_' + os.path.basename(out)[:3] + '.sh; one bench batch + load-time work '
                 'per leg)\n\nEvery counter set in its own pass with --kernel-trace only, within the gfx950 '
                 'slots (SQ 8, TCC 4: FETCH_SIZE 3, WRITE_SIZE 2; GRBM 2).  FETCH_SIZE / WRITE_SIZE in KiB; '
                 'reads doubled (gfx950 tallies 128-byte requests at 64 bytes -- calibrated for 16-byte-per-lane '
