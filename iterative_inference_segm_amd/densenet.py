@@ -124,6 +124,17 @@ class FCDenseNet:
             if p['kind'] == 'tu':
                 e['conv'] = ops.Conv(p['W'], p['b'], pad=0, relu=False, layout='iohw',
                                      transposed=True, device=device, dtype=dtype, mma=mma_other)
+                if self.c8 and p['W'].shape[0] % 16 == 0 and p['W'].shape[1] % 16 == 0 and \
+                        tuple(p['W'].shape[2:]) == (3, 3):
+                    # C8 form of the 3x3 stride-2 'valid' transposed convolution (Deconv2DLayer W[in,out,3,3],
+                    # P3: out[c, 2 i + a] += x[o, i] W[o, c, 2 - a], oracle/nn.py deconv2d)  ==  a plain
+                    # 'valid' 3x3 correlation of the zero-inserted map z[2 i + 2] = x[i] (size 2 H + 3) with
+                    # the filter's in / out axes swapped: out[oy] = sum_k z[oy + k] W[k] (the two flips
+                    # cancel).  Three of four products multiply a zero -- on a kernel that runs 15 x the
+                    # fp32 static-tap kernel's rate on this shape.
+                    Wf = np.ascontiguousarray(np.asarray(p['W']).transpose(1, 0, 2, 3))
+                    e['conv8'] = ops.Conv(Wf, p['b'], pad=0, relu=False, device=device, dtype=dtype,
+                                          mma='bf16c8')
             else:
                 k = p['W'].shape[2]
                 on_c8 = self.c8 and k == 3 and (p['kind'] == 'brc' or (p['kind'] == 'first' and
@@ -193,8 +204,8 @@ class FCDenseNet:
             self._brc8(it, stack)
         for i in range(self.n_pool):                                  # :116-127
             e = next(it)                                              # TransitionUp
-            blk = ops.c8_slice_to_nchw(stack.buf, block0, stack.n - block0)   # concat(block_to_upsample)
             skip = skips[i]
+            h_in, w_in = H, W
             uh, uw = e['conv'].out_hw(H, W)
             H, W = min(uh, skip.buf.shape[2]), min(uw, skip.buf.shape[3])
             if (H, W) != tuple(skip.buf.shape[2:4]):
@@ -202,8 +213,20 @@ class FCDenseNet:
             keep = e['conv'].Cout
             nlay = self.nlpb[self.n_pool + i + 1]
             new = _Stack8(B, keep + skip.n + g * nlay, H, W, dev)
-            up = e['conv'](blk, window=((uh - H) // 2, (uw - W) // 2, H, W))
-            ops.nchw_to_c8_slice(up, new.buf, 0)
+            blk = up = None
+            if 'conv8' in e and block0 % 8 == 0:
+                # concat(block_to_upsample) = chunk planes [block0 / 8, n / 8) of the stack, zero-inserted
+                # (plumbing: a strided device copy), then the C8 kernel straight into the new stack's slice,
+                # center-cropped to the skip's size
+                z = torch.zeros((B, (stack.n - block0) // 8, 2 * h_in + 3, 2 * w_in + 3, 8),
+                                dtype=torch.bfloat16, device=dev)
+                z[:, :, 2:2 * h_in + 1:2, 2:2 * w_in + 1:2].copy_(stack.buf[:, block0 // 8:stack.n // 8])
+                e['conv8'](z, window=((uh - H) // 2, (uw - W) // 2, H, W), out=new.buf, out_c0=0)
+                del z
+            else:
+                blk = ops.c8_slice_to_nchw(stack.buf, block0, stack.n - block0)
+                up = e['conv'](blk, window=((uh - H) // 2, (uw - W) // 2, H, W))
+                ops.nchw_to_c8_slice(up, new.buf, 0)
             new.added(keep)
             # the skip stack behind it (plumbing: chunk planes and their statistics as they are)
             new.buf[:, keep // 8:(keep + skip.n) // 8].copy_(skip.buf[:, :skip.n // 8])
