@@ -10,6 +10,19 @@ from iterative_inference_segm_amd import ops
 
 LAYERS = {
     'fcn.conv1_2': (64, 64, 422, 1, (96, 230), 'pool'),
+    'fcn.conv2_1': (64, 128, 211, 1, (47, 117), 'plain'),
+    'fcn.conv2_2': (128, 128, 211, 1, (46, 120), 'pool'),
+    'fcn.conv3_1': (128, 256, 105, 1, (22, 62), 'plain'),
+    'fcn.conv3_2': (256, 256, 105, 1, (21, 64), 'plain'),
+    'fcn.conv3_3': (256, 256, 105, 1, (20, 66), 'pool'),
+    'fcn.conv4_1': (256, 512, 52, 1, (9, 35), 'plain'),
+    'fcn.conv4_2': (512, 512, 52, 1, (8, 37), 'plain'),
+    'fcn.conv4_3': (512, 512, 52, 1, (6, 40), 'pool'),
+    'fcn.conv5_1': (512, 512, 26, 1, (2, 22), 'plain'),
+    'fcn.conv5_2': (512, 512, 26, 1, (1, 24), 'plain'),
+    'fcn.conv5_3': (512, 512, 26, 1, (0, 26), 'pool'),
+    'dae.conv5_1y': (512, 1024, 26, 1, (3, 20), 'pool'),
+    'dae.up_conv4': (512, 256, 52, 1, (11, 31), 'unpool'),
     'dae.conv1_1': (16, 64, 224, 100, (98, 226), 'pool'),
     'dae.conv2_1': (64, 128, 211, 1, (48, 116), 'pool'),
     'dae.conv3_1': (128, 256, 105, 1, (22, 62), 'pool'),
