@@ -124,8 +124,15 @@ struct C8Params {
 // TN = 4 form at the same LDS, so that FOUR waves share a SIMD instead of two: the shallow layers are
 // bound by what happens around their few k-tiles (prologue, DMA round trip, pool / mask epilogue) and
 // more resident waves fill those gaps.
-template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? 3 : 2)) void conv_c8_kernel(const C8Params p) {
+//
+// POOLONLY: the epilogue of an encoder layer whose output is ONLY its 2x2 max-pool (+ DePool2D mask bytes):
+// no skip-add, no store of the pre-pool map, no output-format cases -- straight-line code.  The generic
+// epilogue decides all of that at run time per chunk; on the pooled 1- to 8-k-tile layers, which are bound by
+// instruction issue, those scalar branches and the addend plumbing are a fifth of a wave's instructions.
+// Same values, same comparisons, same stores as the generic epilogue.
+template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4, bool POOLONLY = false>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (POOLONLY ? 4 : 3) : 2)) void conv_c8_kernel(const C8Params p) {
+    static_assert(!POOLONLY || (!OUTF32 && !X3 && !UNPOOL), "pool-only epilogue: plain encoder layers");
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
     static_assert(NW == 4 || (NW == 8 && TN == 2 && !FLAT), "eight waves: 512-pixel rect tiles");
     constexpr int NT = 64 * NW;
@@ -486,7 +493,54 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? 3 : 2)) void co
     if ((p.debug & 8) && acc[0][0][0] != 12345.f) return;
     const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
     const int ib = FLAT ? 0 : tb;                 // image folded into the descriptor base (RECT)
-    if constexpr (OUTF32) {
+    if constexpr (POOLONLY) {
+        const int co8 = ((p.Cout + 15) >> 4) << 1;
+        const __amdgpu_buffer_rsrc_t r_pool =
+            mk_rsrc((const char*)p.pool + (size_t)ib * co8 * PPL * 16, (unsigned)((FLAT ? p.B : 1) * co8 * PPL) * 16u);
+        const __amdgpu_buffer_rsrc_t r_mask =
+            mk_rsrc(p.mask_out ? p.mask_out + (size_t)ib * co8 * PPL * 8 : nullptr,
+                    p.mask_out ? (unsigned)((FLAT ? p.B : 1) * co8 * PPL) * 8u : 0u);
+        unsigned qb[TN / 2], qm[TN / 2];
+#pragma unroll
+        for (int jp = 0; jp < TN / 2; ++jp) {
+            const int q_wy = ey[2 * jp], q_wx = ex[2 * jp];
+            const int q_py = (p.oy0 + q_wy) >> 1, q_px = (p.ox0 + q_wx) >> 1;
+            const bool q_ok = eok[2 * jp] && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
+                              q_py < p.pool_H && q_px < p.pool_W;
+            const unsigned qpix = (unsigned)(q_py * p.pool_W + q_px);
+            qb[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8 * PPL) + qpix) * 16u + 8u * lh : OOB;
+            qm[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8 * PPL) + qpix) * 8u + 4u * lh : OOB;
+        }
+        const float rfloor = p.relu ? 0.f : -__builtin_inff();
+        const unsigned xsh = (unsigned)(l31 & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c8 = ((m0 + i * 32) >> 3) + g;
+                if (c8 >= co8) continue;               // wave-uniform: chunks past the padded channels
+                const int so_p = (int)((unsigned)(c8 * PPL) * 16u);
+#pragma unroll
+                for (int jp = 0; jp < TN / 2; ++jp) {
+                    f32x4 m;
+                    unsigned own = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a0 = fmaxf(acc[i][2 * jp][g * 4 + q], rfloor);
+                        const float a1 = fmaxf(acc[i][2 * jp + 1][g * 4 + q], rfloor);
+                        const float mv = fmaxf(a0, a1);
+                        m[q] = fmaxf(mv, dpp_xor1(mv));
+                        own |= ((a0 == m[q] ? 1u : 0u) | (a1 == m[q] ? 4u : 0u)) << (8 * q);
+                    }
+                    own <<= xsh;
+                    const unsigned mb = own | dpp_xor1(own);
+                    u32x2 w2;
+                    w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)qb[jp], so_p, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)qm[jp], so_p >> 1, 0);
+                }
+            }
+    } else if constexpr (OUTF32) {
         // class-score layer: NCHW fp32, Cout <= 32
         static_assert(TM == 1, "NCHW output: one 32-channel block");
         const __amdgpu_buffer_rsrc_t r_out =
@@ -1011,6 +1065,22 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
         p.tw_magic = magic20(plan.quad ? p.tw / 2 : p.tw);
     }
     const int grid = p.n_ptiles * p.n_mtiles;
+    // plain encoder layer whose only output is its pool: the straight-line epilogue
+    static const int poolonly_env = getenv("IISEG_C8_POOLONLY") ? atoi(getenv("IISEG_C8_POOLONLY")) : 1;
+    const bool poolonly = poolonly_env && !OUTF32 && BM == 64 && p.pool && !p.out && !p.add && !p.x3 && !unpool;
+    if constexpr (BM == 64 && !OUTF32) {
+        if (poolonly) {
+            if (plan.single)
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 1, 4, true>), dim3(grid), dim3(256), 0, s, p);
+            else if (plan.flat)
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, true, false, false, false, 2, 4, true>), dim3(grid), dim3(256), 0, s, p);
+            else if (plan.tall)
+                IISEG_LAUNCH((conv_c8_kernel<64, 4, false, false, false, false, 2, 4, true>), dim3(grid), dim3(256), 0, s, p);
+            else
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 2, 4, true>), dim3(grid), dim3(256), 0, s, p);
+            return iiseg_check_launch();
+        }
+    }
 #define C8_LAUNCH(TNV, FL, UN)                                                                     \
     do {                                                                                           \
         if (p.x3)                                                                                  \
