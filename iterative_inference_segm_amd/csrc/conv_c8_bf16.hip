@@ -125,14 +125,19 @@ struct C8Params {
 // bound by what happens around their few k-tiles (prologue, DMA round trip, pool / mask epilogue) and
 // more resident waves fill those gaps.
 //
-// POOLONLY: the epilogue of an encoder layer whose output is ONLY its 2x2 max-pool (+ DePool2D mask bytes):
-// no skip-add, no store of the pre-pool map, no output-format cases -- straight-line code.  The generic
-// epilogue decides all of that at run time per chunk; on the pooled 1- to 8-k-tile layers, which are bound by
-// instruction issue, those scalar branches and the addend plumbing are a fifth of a wave's instructions.
+// EPI: compile-time epilogue.  0 = the generic one (every combination of output format, addend format,
+// pool, X3 decided at run time per chunk).  The frequent combinations have straight-line code of their own
+// -- on the 1- to 8-k-tile layers, which are bound by instruction issue, the generic epilogue's scalar
+// branches and addend plumbing are a fifth of a wave's instructions (conv1_1: 0.175 -> 0.124 ms):
+//   1  ONLY the 2x2 max-pool (+ DePool2D mask bytes) of the result is stored (encoder layers)
+//   2  bf16 C8 store, no addend, no pool (the plain layers of the FCN-8)
+//   3  bf16 C8 store with a bf16 C8 skip addend (the decoder layers)
 // Same values, same comparisons, same stores as the generic epilogue.
-template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4, bool POOLONLY = false>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (POOLONLY ? 4 : 3) : 2)) void conv_c8_kernel(const C8Params p) {
-    static_assert(!POOLONLY || (!OUTF32 && !X3 && !UNPOOL), "pool-only epilogue: plain encoder layers");
+enum { EPI_GENERIC = 0, EPI_POOL = 1, EPI_STORE = 2, EPI_STORE_ADD = 3 };
+template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4, int EPI = EPI_GENERIC>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GENERIC ? 4 : 3) : 2)) void conv_c8_kernel(const C8Params p) {
+    static_assert(EPI == EPI_GENERIC || (!OUTF32 && !X3), "specialised epilogues: one-operand bf16 C8 layers");
+    static_assert(EPI != EPI_POOL || !UNPOOL, "pool-only epilogue: encoder layers");
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
     static_assert(NW == 4 || (NW == 8 && TN == 2 && !FLAT), "eight waves: 512-pixel rect tiles");
     constexpr int NT = 64 * NW;
@@ -493,7 +498,58 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (POOLONLY ? 4 :
     if ((p.debug & 8) && acc[0][0][0] != 12345.f) return;
     const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
     const int ib = FLAT ? 0 : tb;                 // image folded into the descriptor base (RECT)
-    if constexpr (POOLONLY) {
+    if constexpr (EPI == EPI_STORE || EPI == EPI_STORE_ADD) {
+        const int oct8 = p.out_ctot >> 3, co8 = ((p.Cout + 15) >> 4) << 1;
+        const __amdgpu_buffer_rsrc_t r_out =
+            mk_rsrc((const char*)p.out + (size_t)ib * oct8 * OPL * 16, (unsigned)((FLAT ? p.B : 1) * oct8 * OPL) * 16u);
+        const __amdgpu_buffer_rsrc_t r_add =
+            mk_rsrc(EPI == EPI_STORE_ADD ? (const char*)p.add + (size_t)ib * co8 * APL * 16 : nullptr,
+                    EPI == EPI_STORE_ADD ? (unsigned)((FLAT ? p.B : 1) * co8 * APL) * 16u : 0u);
+        unsigned ob[TN], ab[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const unsigned opix = (unsigned)(eb[j] * oct8 * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
+            const unsigned apix = (unsigned)(eb[j] * co8 * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+            ob[j] = eok[j] ? opix * 16u + 8u * lh : OOB;
+            ab[j] = eok[j] ? apix * 16u + 8u * lh : OOB;
+        }
+        const float rfloor = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            // (every load of the block first: a buffer load cannot move above an earlier buffer store)
+            u32x2 ad[4][TN];
+            if constexpr (EPI == EPI_STORE_ADD) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c8 = ((m0 + i * 32) >> 3) + g;
+                    const int so_a = (int)((unsigned)(c8 * APL) * 16u);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        ad[g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                            r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a, 0));
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c8 = ((m0 + i * 32) >> 3) + g;
+                if (c8 >= co8) continue;               // wave-uniform: chunks past the padded channels
+                const int so_o = (int)((unsigned)(((p.out_c0 >> 3) + c8) * OPL) * 16u);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                    if constexpr (EPI == EPI_STORE_ADD)
+                        v += f32x4{bf_lo(ad[g][j][0]), bf_hi(ad[g][j][0]), bf_lo(ad[g][j][1]), bf_hi(ad[g][j][1])};
+                    v[0] = fmaxf(v[0], rfloor); v[1] = fmaxf(v[1], rfloor);
+                    v[2] = fmaxf(v[2], rfloor); v[3] = fmaxf(v[3], rfloor);
+                    u32x2 w2;
+                    w2[0] = pack_bf16(v[0], v[1]); w2[1] = pack_bf16(v[2], v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)ob[j], so_o, 0);
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_POOL) {
         const int co8 = ((p.Cout + 15) >> 4) << 1;
         const __amdgpu_buffer_rsrc_t r_pool =
             mk_rsrc((const char*)p.pool + (size_t)ib * co8 * PPL * 16, (unsigned)((FLAT ? p.B : 1) * co8 * PPL) * 16u);
@@ -1065,21 +1121,42 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
         p.tw_magic = magic20(plan.quad ? p.tw / 2 : p.tw);
     }
     const int grid = p.n_ptiles * p.n_mtiles;
-    // plain encoder layer whose only output is its pool: the straight-line epilogue
-    static const int poolonly_env = getenv("IISEG_C8_POOLONLY") ? atoi(getenv("IISEG_C8_POOLONLY")) : 1;
-    const bool poolonly = poolonly_env && !OUTF32 && BM == 64 && p.pool && !p.out && !p.add && !p.x3 && !unpool;
+    // the frequent epilogue combinations have straight-line code of their own (template EPI)
+    static const int epi_env = getenv("IISEG_C8_EPI") ? atoi(getenv("IISEG_C8_EPI")) : 1;
     if constexpr (BM == 64 && !OUTF32) {
-        if (poolonly) {
-            if (plan.single)
-                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 1, 4, true>), dim3(grid), dim3(256), 0, s, p);
-            else if (plan.flat)
-                IISEG_LAUNCH((conv_c8_kernel<64, 2, true, false, false, false, 2, 4, true>), dim3(grid), dim3(256), 0, s, p);
-            else if (plan.tall)
-                IISEG_LAUNCH((conv_c8_kernel<64, 4, false, false, false, false, 2, 4, true>), dim3(grid), dim3(256), 0, s, p);
-            else
-                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 2, 4, true>), dim3(grid), dim3(256), 0, s, p);
-            return iiseg_check_launch();
+        int epi = EPI_GENERIC;
+        if (epi_env && !p.x3) {
+            if (p.pool && !p.out && !p.add && !unpool) epi = EPI_POOL;
+            else if (!p.pool && p.out && p.out_kind == 1 && !p.add && !unpool) epi = EPI_STORE;
+            else if (!p.pool && p.out && p.out_kind == 1 && p.add && p.add_kind == 1) epi = EPI_STORE_ADD;
         }
+#define C8_LAUNCH_EPI(E, UN)                                                                       \
+        do {                                                                                       \
+            if (plan.flat)                                                                         \
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, true, UN, false, false, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
+            else if (plan.tall)                                                                    \
+                IISEG_LAUNCH((conv_c8_kernel<64, 4, false, UN, false, false, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
+            else                                                                                   \
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, UN, false, false, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
+            return iiseg_check_launch();                                                           \
+        } while (0)
+        if (epi == EPI_POOL) {
+            if (plan.single) {
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 1, 4, EPI_POOL>), dim3(grid), dim3(256), 0, s, p);
+                return iiseg_check_launch();
+            }
+            C8_LAUNCH_EPI(EPI_POOL, false);
+        } else if (epi == EPI_STORE) {
+            if (plan.single) {
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 1, 4, EPI_STORE>), dim3(grid), dim3(256), 0, s, p);
+                return iiseg_check_launch();
+            }
+            C8_LAUNCH_EPI(EPI_STORE, false);
+        } else if (epi == EPI_STORE_ADD) {
+            if (unpool) C8_LAUNCH_EPI(EPI_STORE_ADD, true);
+            else C8_LAUNCH_EPI(EPI_STORE_ADD, false);
+        }
+#undef C8_LAUNCH_EPI
     }
 #define C8_LAUNCH(TNV, FL, UN)                                                                     \
     do {                                                                                           \
