@@ -156,6 +156,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
     uint4 (*Ws)[WCH] = reinterpret_cast<uint4 (*)[WCH]>(smem);
     uint4 (*Ps)[NCHK] = reinterpret_cast<uint4 (*)[NCHK]>(smem + NBUF * WCH);
 
+    // pixel order of a tile: known at compile time under a specialised epilogue (pooling-window order
+    // exactly when a pool is fused)
+    const bool quad = EPI == EPI_POOL ? true : (EPI == EPI_GENERIC ? p.quad != 0 : false);
     int pt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
     const int m0 = mt * BM;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
         // rows per image keep the 3-row halo of neighbouring images apart); the patch holds the
         // virtual INPUT rows [vmin, vmin + PR) x (OW + 2) columns.  A tile is 256 consecutive pixels
         // of that list, or (quad) 64 consecutive 2x2 pooling windows of it.
-        if (p.quad) {
+        if (quad) {
             const int QHW = p.QH * p.QW;
             n0 = pt * 64;
             const int b0 = n0 / QHW, r0 = n0 - b0 * QHW;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         if constexpr (FLAT) {
-            if (p.quad) {
+            if (quad) {
                 const int q = n0 + wave * 16 + (l31 >> 1);
                 const bool qok = q < p.N;
                 const int qq = qok ? q : p.N - 1;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             eb[j] = 0;
             int ly, lx;
             bool inb;
-            if (p.quad) {
+            if (quad) {
                 const int q = (wave * (TN / 2) + (j >> 1)) * 16 + (l31 >> 1);
                 const int hw = p.tw >> 1;
                 const int qy = (int)(((unsigned)q * p.tw_magic) >> 20), qx = q - qy * hw;      // q / hw
