@@ -136,7 +136,7 @@ struct C8Params {
 enum { EPI_GENERIC = 0, EPI_POOL = 1, EPI_STORE = 2, EPI_STORE_ADD = 3 };
 template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GENERIC ? 4 : 3) : 2)) void conv_c8_kernel(const C8Params p) {
-    static_assert(EPI == EPI_GENERIC || (!OUTF32 && !X3), "specialised epilogues: one-operand bf16 C8 layers");
+    static_assert(EPI == EPI_GENERIC || !OUTF32, "specialised epilogues: bf16 C8 (or hi / lo pair) outputs");
     static_assert(EPI != EPI_POOL || !UNPOOL, "pool-only epilogue: encoder layers");
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
     static_assert(NW == 4 || (NW == 8 && TN == 2 && !FLAT), "eight waves: 512-pixel rect tiles");
@@ -502,17 +502,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
     const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW, PPL = p.pool_H * p.pool_W;
     const int ib = FLAT ? 0 : tb;                 // image folded into the descriptor base (RECT)
     if constexpr (EPI == EPI_STORE || EPI == EPI_STORE_ADD) {
+        // (X3: outputs and addends are hi / lo pairs -- hi chunks, then lo chunks, per image)
+        constexpr int PR2 = X3 ? 2 : 1;
         const int oct8 = p.out_ctot >> 3, co8 = ((p.Cout + 15) >> 4) << 1;
+        const int octT = PR2 * oct8, co8A = PR2 * co8;
         const __amdgpu_buffer_rsrc_t r_out =
-            mk_rsrc((const char*)p.out + (size_t)ib * oct8 * OPL * 16, (unsigned)((FLAT ? p.B : 1) * oct8 * OPL) * 16u);
+            mk_rsrc((const char*)p.out + (size_t)ib * octT * OPL * 16, (unsigned)((FLAT ? p.B : 1) * octT * OPL) * 16u);
         const __amdgpu_buffer_rsrc_t r_add =
-            mk_rsrc(EPI == EPI_STORE_ADD ? (const char*)p.add + (size_t)ib * co8 * APL * 16 : nullptr,
-                    EPI == EPI_STORE_ADD ? (unsigned)((FLAT ? p.B : 1) * co8 * APL) * 16u : 0u);
+            mk_rsrc(EPI == EPI_STORE_ADD ? (const char*)p.add + (size_t)ib * co8A * APL * 16 : nullptr,
+                    EPI == EPI_STORE_ADD ? (unsigned)((FLAT ? p.B : 1) * co8A * APL) * 16u : 0u);
         unsigned ob[TN], ab[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const unsigned opix = (unsigned)(eb[j] * oct8 * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
-            const unsigned apix = (unsigned)(eb[j] * co8 * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+            const unsigned opix = (unsigned)(eb[j] * octT * OPL + (p.out_y0 + ey[j]) * p.out_W + p.out_x0 + ex[j]);
+            const unsigned apix = (unsigned)(eb[j] * co8A * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
             ob[j] = eok[j] ? opix * 16u + 8u * lh : OOB;
             ab[j] = eok[j] ? apix * 16u + 8u * lh : OOB;
         }
@@ -520,16 +523,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             // (every load of the block first: a buffer load cannot move above an earlier buffer store)
-            u32x2 ad[4][TN];
+            u32x2 ad[4][TN], adl[X3 ? 4 : 1][TN];
             if constexpr (EPI == EPI_STORE_ADD) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c8 = ((m0 + i * 32) >> 3) + g;
                     const int so_a = (int)((unsigned)(c8 * APL) * 16u);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
                         ad[g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
                             r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a, 0));
+                        if constexpr (X3)
+                            adl[g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                                r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a + (int)((unsigned)(co8 * APL) * 16u), 0));
+                    }
                 }
             }
 #pragma unroll
@@ -542,20 +549,32 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
                     f32x4 v;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
-                    if constexpr (EPI == EPI_STORE_ADD)
-                        v += f32x4{bf_lo(ad[g][j][0]), bf_hi(ad[g][j][0]), bf_lo(ad[g][j][1]), bf_hi(ad[g][j][1])};
+                    if constexpr (EPI == EPI_STORE_ADD) {
+                        f32x4 a = f32x4{bf_lo(ad[g][j][0]), bf_hi(ad[g][j][0]), bf_lo(ad[g][j][1]), bf_hi(ad[g][j][1])};
+                        if constexpr (X3)      // hi + lo: the 16-bit value the producer stored
+                            a += f32x4{bf_lo(adl[g][j][0]), bf_hi(adl[g][j][0]), bf_lo(adl[g][j][1]), bf_hi(adl[g][j][1])};
+                        v += a;
+                    }
                     v[0] = fmaxf(v[0], rfloor); v[1] = fmaxf(v[1], rfloor);
                     v[2] = fmaxf(v[2], rfloor); v[3] = fmaxf(v[3], rfloor);
                     u32x2 w2;
                     w2[0] = pack_bf16(v[0], v[1]); w2[1] = pack_bf16(v[2], v[3]);
                     __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)ob[j], so_o, 0);
+                    if constexpr (X3) {
+                        u32x2 l2;
+                        l2[0] = pack_bf16(v[0] - bf_lo(w2[0]), v[1] - bf_hi(w2[0]));
+                        l2[1] = pack_bf16(v[2] - bf_lo(w2[1]), v[3] - bf_hi(w2[1]));
+                        __builtin_amdgcn_raw_buffer_store_b64(l2, r_out, (int)ob[j],
+                                                              so_o + (int)((unsigned)(oct8 * OPL) * 16u), 0);
+                    }
                 }
             }
         }
     } else if constexpr (EPI == EPI_POOL) {
         const int co8 = ((p.Cout + 15) >> 4) << 1;
+        const int co8P = X3 ? 2 * co8 : co8;       // X3: the pooled map is a hi / lo pair, the masks are not
         const __amdgpu_buffer_rsrc_t r_pool =
-            mk_rsrc((const char*)p.pool + (size_t)ib * co8 * PPL * 16, (unsigned)((FLAT ? p.B : 1) * co8 * PPL) * 16u);
+            mk_rsrc((const char*)p.pool + (size_t)ib * co8P * PPL * 16, (unsigned)((FLAT ? p.B : 1) * co8P * PPL) * 16u);
         const __amdgpu_buffer_rsrc_t r_mask =
             mk_rsrc(p.mask_out ? p.mask_out + (size_t)ib * co8 * PPL * 8 : nullptr,
                     p.mask_out ? (unsigned)((FLAT ? p.B : 1) * co8 * PPL) * 8u : 0u);
@@ -567,7 +586,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             const bool q_ok = eok[2 * jp] && !(l31 & 1) && q_wy + 1 < p.OH && q_wx + 1 < p.OW &&
                               q_py < p.pool_H && q_px < p.pool_W;
             const unsigned qpix = (unsigned)(q_py * p.pool_W + q_px);
-            qb[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8 * PPL) + qpix) * 16u + 8u * lh : OOB;
+            qb[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8P * PPL) + qpix) * 16u + 8u * lh : OOB;
             qm[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8 * PPL) + qpix) * 8u + 4u * lh : OOB;
         }
         const float rfloor = p.relu ? 0.f : -__builtin_inff();
@@ -596,6 +615,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
                     u32x2 w2;
                     w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
                     __builtin_amdgcn_raw_buffer_store_b64(w2, r_pool, (int)qb[jp], so_p, 0);
+                    if constexpr (X3) {
+                        u32x2 l2;
+                        l2[0] = pack_bf16(m[0] - bf_lo(w2[0]), m[1] - bf_hi(w2[0]));
+                        l2[1] = pack_bf16(m[2] - bf_lo(w2[1]), m[3] - bf_hi(w2[1]));
+                        __builtin_amdgcn_raw_buffer_store_b64(l2, r_pool, (int)qb[jp],
+                                                              so_p + (int)((unsigned)(co8 * PPL) * 16u), 0);
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32((int)mb, r_mask, (int)qm[jp], so_p >> 1, 0);
                 }
             }
@@ -1128,20 +1154,24 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
     static const int epi_env = getenv("IISEG_C8_EPI") ? atoi(getenv("IISEG_C8_EPI")) : 1;
     if constexpr (BM == 64 && !OUTF32) {
         int epi = EPI_GENERIC;
-        if (epi_env && !p.x3) {
+        if (epi_env) {
             if (p.pool && !p.out && !p.add && !unpool) epi = EPI_POOL;
             else if (!p.pool && p.out && p.out_kind == 1 && !p.add && !unpool) epi = EPI_STORE;
             else if (!p.pool && p.out && p.out_kind == 1 && p.add && p.add_kind == 1) epi = EPI_STORE_ADD;
         }
-#define C8_LAUNCH_EPI(E, UN)                                                                       \
+#define C8_LAUNCH_EPI_X(E, UN, XX)                                                                 \
         do {                                                                                       \
             if (plan.flat)                                                                         \
-                IISEG_LAUNCH((conv_c8_kernel<64, 2, true, UN, false, false, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, true, UN, false, XX, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
             else if (plan.tall)                                                                    \
-                IISEG_LAUNCH((conv_c8_kernel<64, 4, false, UN, false, false, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
+                IISEG_LAUNCH((conv_c8_kernel<64, 4, false, UN, false, XX, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
             else                                                                                   \
-                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, UN, false, false, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
+                IISEG_LAUNCH((conv_c8_kernel<64, 2, false, UN, false, XX, 2, 4, E>), dim3(grid), dim3(256), 0, s, p); \
             return iiseg_check_launch();                                                           \
+        } while (0)
+#define C8_LAUNCH_EPI(E, UN)                                                                       \
+        do {                                                                                       \
+            if (p.x3) C8_LAUNCH_EPI_X(E, UN, true); else C8_LAUNCH_EPI_X(E, UN, false);            \
         } while (0)
         if (epi == EPI_POOL) {
             if (plan.single) {
@@ -1160,6 +1190,7 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
             else C8_LAUNCH_EPI(EPI_STORE_ADD, false);
         }
 #undef C8_LAUNCH_EPI
+#undef C8_LAUNCH_EPI_X
     }
 #define C8_LAUNCH(TNV, FL, UN)                                                                     \
     do {                                                                                           \
