@@ -291,6 +291,7 @@ class Conv:
         self._W16 = None
         self._W16c8 = None
         self._W16c8_cin = None
+        self._form_cache = {}
         self._plans = {}
         self._packs = {}
 
@@ -490,7 +491,8 @@ class Conv:
             return self._call_halo_bf16(d, x1, x2, pre, pooled, add, out, pool_out, mask_in,
                                         mask_out, prof, B, H, W)
         if not masked and pool_out is None and self.wino and \
-                self.lib.iiseg_conv_wino_supported(C.byref(d)):
+                self.lib.iiseg_conv_wino_supported(C.byref(d)) and \
+                self._form_by_full_map(self.lib.iiseg_conv_wino_supported, d):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
         if masked:
             if pool_out is not None:
@@ -557,7 +559,8 @@ class Conv:
                 ev0 = ev1
             return out
         if dt == torch.float64 and self.wino_f64 and not self.via_im2col and \
-                self.lib.iiseg_conv_wino_f64_supported(C.byref(d)):
+                self.lib.iiseg_conv_wino_f64_supported(C.byref(d)) and \
+                self._form_by_full_map(self.lib.iiseg_conv_wino_f64_supported, d):
             return self._call_wino_f64(d, x1, x2, pre, pooled, add, out, prof, B)
         ev0 = _ev() if prof is not None else None
         if dt == torch.float64:
@@ -604,6 +607,25 @@ class Conv:
         if prof is not None:
             prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
         return out
+
+    def _form_by_full_map(self, supported, d):
+        """A layer's kernel FORM (Winograd or direct) is decided on its FULL-MAP geometry, not on the
+        window a launch covers: a form with a size limit (workspace within 32-bit offsets) that takes a
+        small window but not the full map would otherwise compute the loop-invariant border with one
+        kernel and the recomputed window with another -- and the two differ in their last bits, which the
+        exact work eliminations rule out.  Cached per input geometry."""
+        key = (id(supported), d.B, d.C1, d.C2, d.H, d.W, d.flags)
+        ok = self._form_cache.get(key)
+        if ok is None:
+            full = ConvDesc()
+            C.memmove(C.byref(full), C.byref(d), C.sizeof(ConvDesc))
+            fh, fw = self.out_hw(d.H, d.W)
+            full.oy0, full.ox0, full.OH, full.OW = 0, 0, fh, fw
+            full.out_H = full.out_W = full.out_y0 = full.out_x0 = 0
+            if full.AH:
+                full.AH, full.AW, full.ay0, full.ax0 = max(full.AH, fh), max(full.AW, fw), 0, 0
+            ok = self._form_cache[key] = bool(supported(C.byref(full)))
+        return ok
 
     def pool_fusable(self, c8=None):
         """True if this layer runs on a halo kernel whose epilogue can do the 2x2 max-pool.  `c8`:
