@@ -563,6 +563,19 @@ int iiseg_conv_pack_f64(void* stream, const iiseg_conv_desc* d, const double* w,
 int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const double* x1, const double* x2,
                    const double* pre, const double* pooled, const double* wp, const double* bias,
                    const double* add, double* out);
+/* 1 when iiseg_conv_f64 runs this (planned) request on the halo-tile kernel (conv_halo_f64.hip: plain
+ * 3x3 layers, patch staged once per 4 input channels, 16-row MFMA tiles for Cout <= 16) instead of the
+ * static-tap kernel; same packed weights, bit-identical results -- a scheduling fact, for profiles. */
+int iiseg_conv_halo_f64_supported(const iiseg_conv_desc* d);
+/* Split-K GEMM form of iiseg_conv_f64 for deep 1x1 layers computed in full into a dense output (fc6 after
+ * iiseg_im2col_f64, fc7, score_fr: models/fcn8.py:75-85): x (B, C1, H, W) is laid out once as V[k][pixel],
+ * then the LDS-DMA GEMM kernel of the float64 Winograd path runs on the same packed weights `wp`
+ * (iiseg_conv_plan_f64 / _pack_f64); the partial sums of the K slices are added in a fixed order, and the
+ * number of slices does not depend on the batch.  workspace: iiseg_conv_gemm_f64_workspace_elems doubles. */
+int iiseg_conv_gemm_f64_supported(const iiseg_conv_desc* d);
+int64_t iiseg_conv_gemm_f64_workspace_elems(const iiseg_conv_desc* d);
+int iiseg_conv_gemm_f64(void* stream, const iiseg_conv_desc* d, const double* x, const double* wp,
+                        const double* bias, double* workspace, double* out);
 /* x (B,C,H,W) -> out (B, C*KH*KW, H-KH+1, W-KW+1), channel index c*KH*KW + ky*KW + kx */
 int iiseg_im2col_f64(void* stream, const double* x, double* out, int32_t B, int32_t C, int32_t H,
                      int32_t W, int32_t KH, int32_t KW);

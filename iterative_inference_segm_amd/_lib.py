@@ -140,6 +140,10 @@ SIGNATURES = {
     'iiseg_conv_plan_f64': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pack_f64': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
     'iiseg_conv_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 8),
+    'iiseg_conv_halo_f64_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_gemm_f64_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_gemm_f64_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_gemm_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5),
     'iiseg_im2col_f64': (C.c_int, [_vp, _vp, _vp] + [_i32] * 6),
     'iiseg_maxpool2x2_f64': (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32]),
     'iiseg_unpool_eqmask_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32]),

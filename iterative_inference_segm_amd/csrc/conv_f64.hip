@@ -17,6 +17,7 @@
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
+#include "conv_f64_common.h"
 
 using namespace iiseg;
 
@@ -29,28 +30,6 @@ constexpr int RSRC_W3 = 0x00027000;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int BM = 64, BN = 128;
 
-struct ConvParams64 {
-    const double* x1;
-    const double* x2;
-    const double* pre;
-    const double* pooled;
-    const double* wp;
-    const double* bias;
-    const double* add;
-    double* out;
-    int B, C1, C2, H, W;
-    int h2, w2;
-    int Cout, OH, OW, oy0, ox0;
-    int AH, AW, ay0, ax0;
-    int Kpad, Mpad;
-    int pad, dil;
-    int P;
-    int n_ptiles, n_mtiles;
-    int relu;
-    int out_ctot, out_c0;
-    int transposed;
-    int out_H, out_W, out_y0, out_x0;
-};
 
 __device__ __forceinline__ double buf_ld64(const double* base, int bytes, unsigned voff, unsigned soff) {
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, RSRC_W3);
@@ -323,7 +302,33 @@ int check64(const iiseg_conv_desc* d) {
     return IISEG_OK;
 }
 
+// launch parameters of a validated request (pointers left to the caller)
+ConvParams64 params64(const iiseg_conv_desc* d) {
+    ConvParams64 p = {};
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0;
+    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
+    p.Kpad = d->Kpad; p.Mpad = d->Mpad; p.pad = d->pad; p.dil = d->dil;
+    p.P = d->B * d->OH * d->OW;
+    p.n_ptiles = p.n_mtiles = 0;
+    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
+    p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
+    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
+    p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
+    p.out_H = d->out_H ? d->out_H : d->OH;
+    p.out_W = d->out_H ? d->out_W : d->OW;
+    p.out_y0 = d->out_H ? d->out_y0 : 0;
+    p.out_x0 = d->out_H ? d->out_x0 : 0;
+    return p;
+}
+
 }  // namespace
+
+extern "C" int iiseg_conv_halo_f64_supported(const iiseg_conv_desc* d) {
+    if (check64(d) != IISEG_OK) return 0;
+    return iiseg_conv_halo_f64_ok(params64(d), d->KH, d->KW) ? 1 : 0;
+}
 
 extern "C" int iiseg_conv_plan_f64(iiseg_conv_desc* d) {
     if (!d) return IISEG_ERR_NULL;
@@ -363,25 +368,12 @@ extern "C" int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const doub
     if (unpool && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
     if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
         return IISEG_ERR_SHAPE;
-    ConvParams64 p;
+    ConvParams64 p = params64(d);
     p.x1 = x1; p.x2 = x2; p.pre = pre; p.pooled = pooled; p.wp = wp; p.bias = bias; p.add = add;
     p.out = out;
-    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
-    p.h2 = d->H / 2; p.w2 = d->W / 2;
-    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0;
-    p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
-    p.Kpad = d->Kpad; p.Mpad = d->Mpad; p.pad = d->pad; p.dil = d->dil;
-    p.P = d->B * d->OH * d->OW;
-    p.n_ptiles = p.n_mtiles = 0;
-    p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
-    p.out_ctot = d->out_ctot ? d->out_ctot : d->Cout;
-    p.out_c0 = d->out_ctot ? d->out_c0 : 0;
-    p.transposed = (d->flags & IISEG_CONV_TRANSPOSED2) ? 1 : 0;
-    p.out_H = d->out_H ? d->out_H : d->OH;
-    p.out_W = d->out_H ? d->out_W : d->OW;
-    p.out_y0 = d->out_H ? d->out_y0 : 0;
-    p.out_x0 = d->out_H ? d->out_x0 : 0;
     hipStream_t s = (hipStream_t)stream;
+    // plain 3x3 layers: the halo-tile kernel (conv_halo_f64.hip), bit-identical to the static-tap one
+    if (iiseg_conv_halo_f64_ok(p, d->KH, d->KW)) return iiseg_launch_conv_halo_f64(s, p, unpool);
     if (d->KH == 3) return launch64<3, 3, 4>(s, p, unpool);
     return launch64<1, 1, 16>(s, p, unpool);
 }

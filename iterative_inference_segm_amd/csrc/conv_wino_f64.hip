@@ -361,7 +361,121 @@ int wino64_geom(const iiseg_conv_desc* d, Wino64Geom& g) {
     return IISEG_OK;
 }
 
+// ---- deep 1x1 layers (fc6 after iiseg_im2col_f64, fc7, score_fr: models/fcn8.py:75-85) as split-K GEMMs ----
+// on wino64_gemm_kernel: the static-tap kernel walks K = 25088 with a gather per element and a barrier pair
+// per 16 k (28 TFLOP/s); here x (B, K, OH*OW) is laid out once as V[k][t] and both operands stream by LDS-DMA.
+// The packed weights Wp[Kpad][Mpad] of iiseg_conv_pack_f64 ARE the A operand; K slices play the xi role.
+struct Gemm64Geom {
+    int K, Kpad, Mpad, T, Tpad, S, Kc, OHW;
+};
+
+__global__ __launch_bounds__(256) void gemm64_input_kernel(const double* __restrict__ x, double* __restrict__ V,
+                                                           int K, int Kpad, int OHW, int T, int Tpad) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int b = t / OHW, px = t - b * OHW;
+    const double* xb = x + (size_t)b * K * OHW + px;
+    for (int k = blockIdx.y; k < Kpad; k += gridDim.y)
+        V[(size_t)k * Tpad + t] = k < K ? xb[(size_t)k * OHW] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void gemm64_output_kernel(const double* __restrict__ M,
+                                                            const double* __restrict__ bias,
+                                                            double* __restrict__ out, int Cout, int OHW, int T,
+                                                            int Tpad, int Mpad, int S, int relu) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const int b = t / OHW, px = t - b * OHW;
+    const size_t ss = (size_t)Mpad * Tpad;
+    for (int co = blockIdx.y; co < Cout; co += gridDim.y) {
+        const double* m = M + (size_t)co * Tpad + t;
+        double v = m[0];
+        for (int s = 1; s < S; ++s) v += m[(size_t)s * ss];   // fixed order: deterministic
+        if (bias) v += bias[co];
+        if (relu) v = fmax(v, 0.0);
+        out[((size_t)b * Cout + co) * OHW + px] = v;
+    }
+}
+
+int gemm64_geom(const iiseg_conv_desc* d, Gemm64Geom& g) {
+    if (!d) return IISEG_ERR_NULL;
+    if (d->KH != 1 || d->KW != 1 || d->C2 != 0 || d->dil != 1 || d->pad != 0 ||
+        (d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2)))
+        return IISEG_ERR_UNSUPPORTED;
+    if (d->B <= 0 || d->C1 <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return IISEG_ERR_SHAPE;
+    // full, dense output only
+    if (d->oy0 != 0 || d->ox0 != 0 || d->OH != d->H || d->OW != d->W || d->out_ctot != 0 || d->out_H != 0)
+        return IISEG_ERR_UNSUPPORTED;
+    g.K = d->C1;
+    g.Kpad = d->Kpad;
+    g.Mpad = d->Mpad;
+    if (g.Kpad < g.K || g.Kpad % GBK || g.Mpad % GBM || g.Mpad < d->Cout) return IISEG_ERR_UNSUPPORTED;
+    g.OHW = d->H * d->W;
+    const int64_t T = (int64_t)d->B * g.OHW;
+    const int64_t Tpad = (T + GBN - 1) / GBN * GBN;
+    if (Tpad * g.Kpad * 8 >= (int64_t)1 << 31 || (int64_t)g.Kpad * g.Mpad * 8 >= (int64_t)1 << 31)
+        return IISEG_ERR_UNSUPPORTED;
+    g.T = (int)T;
+    g.Tpad = (int)Tpad;
+    // split-K: the divisor S of Kpad / 16 (<= 16) minimising GEMM rounds (512 resident 64 x 128 tiles at the
+    // measured 55 TFLOP/s) + the traffic of the S partial products.  S fixes the association of the K sum,
+    // so it must NOT depend on the batch: it is chosen for a nominal 3200 pixels (64 images x 7 x 7).
+    const int tiles = 25 * (g.Mpad / GBM), units = g.Kpad / GBK;
+    const double tile_s = 2.0 * g.Kpad * GBM * GBN / (55e12 / 512);
+    const double red_s = 16.0 * g.Mpad * 3200 / 5e12;
+    double best = 1e30;
+    g.S = 1;
+    for (int S = 1; S <= 16; ++S) {
+        if (units % S || units / S < 8) continue;
+        const double cost = (double)((S * tiles + 511) / 512) / S * tile_s + S * red_s;
+        if (cost < best) { best = cost; g.S = S; }
+    }
+    g.Kc = g.Kpad / g.S;
+    return IISEG_OK;
+}
+
 }  // namespace
+
+extern "C" int iiseg_conv_gemm_f64_supported(const iiseg_conv_desc* d) {
+    Gemm64Geom g;
+    return gemm64_geom(d, g) == IISEG_OK ? 1 : 0;
+}
+
+extern "C" int64_t iiseg_conv_gemm_f64_workspace_elems(const iiseg_conv_desc* d) {
+    Gemm64Geom g;
+    if (gemm64_geom(d, g) != IISEG_OK) return 0;
+    return (int64_t)g.Tpad * ((int64_t)g.Kpad + (int64_t)g.S * g.Mpad);
+}
+
+extern "C" int iiseg_conv_gemm_f64(void* stream, const iiseg_conv_desc* d, const double* x, const double* wp,
+                                   const double* bias, double* workspace, double* out) {
+    Gemm64Geom g;
+    const int st = gemm64_geom(d, g);
+    if (st) return st;
+    if (!x || !wp || !workspace || !out) return IISEG_ERR_NULL;
+    if (((uintptr_t)wp & 15) || ((uintptr_t)workspace & 15)) return IISEG_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    double* V = workspace;
+    double* M = workspace + (size_t)g.Kpad * g.Tpad;
+    const int tb = (g.T + 255) / 256;
+    IISEG_LAUNCH(gemm64_input_kernel, dim3(tb, g.Kpad < 1024 ? g.Kpad : 1024), dim3(256), 0, s, x, V, g.K,
+                 g.Kpad, g.OHW, g.T, g.Tpad);
+    Wino64Params p = {};
+    p.U = wp;
+    p.V = V;
+    p.M = M;
+    p.Kc = g.Kc;
+    p.Mpad = g.Mpad;
+    p.Tpad = g.Tpad;
+    p.T = g.T;
+    p.n_ttiles = g.Tpad / GBN;
+    p.n_mtiles = g.Mpad / GBM;
+    IISEG_LAUNCH(wino64_gemm_kernel, dim3(g.S * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
+    const int cy = d->Cout < 1024 ? d->Cout : 1024;
+    IISEG_LAUNCH(gemm64_output_kernel, dim3(tb, cy), dim3(256), 0, s, M, bias, out, d->Cout, g.OHW, g.T, g.Tpad,
+                 g.Mpad, g.S, (d->flags & IISEG_CONV_RELU) ? 1 : 0);
+    return iiseg_check_launch();
+}
 
 extern "C" int iiseg_conv_wino_f64_supported(const iiseg_conv_desc* d) {
     Wino64Geom g;

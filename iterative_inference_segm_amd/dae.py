@@ -16,6 +16,10 @@ import torch
 from . import ops
 from .weights import load_param_list
 
+# float64 decoder layers on the halo-tile kernel apply DePool2D while staging their patches
+# (conv_halo_f64.hip); 0: materialise the unpooled window first (pool_unpool.hip) and run the plain conv
+F64_FUSE_UNPOOL = os.environ.get('IISEG_F64_FUSE_UNPOOL', '1') != '0'
+
 
 def _n_pool(concat_h, additional_pool):
     n = int(concat_h[-1][-1]) if 'pool' in concat_h[-1] else 0   # DAE_h.py:37-40
@@ -423,8 +427,10 @@ class StandardDAE:
             fuse = self.fuse_unpool
             if fuse is None:
                 # fused in float32; in float64 where the layer runs in Winograd form (its input
-                # transform applies the mask), materialised for the direct float64 kernel
-                fuse = conv.dtype == torch.float32 or getattr(conv, 'wino_f64', False)
+                # transform applies the mask) or on the halo-tile kernel (its patch staging does);
+                # materialised for the static-tap float64 kernel
+                fuse = conv.dtype == torch.float32 or getattr(conv, 'wino_f64', False) or \
+                    (F64_FUSE_UNPOOL and (conv.KH, conv.KW, conv.dil) == (3, 3, 1) and not conv.transposed)
             if not fuse:
                 # materialise DePool2D with the HBM-bound kernel and run the plain conv
                 uy0, ux0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)

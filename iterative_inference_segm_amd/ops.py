@@ -30,7 +30,8 @@ WINO_MIN_CIN = int(os.environ.get('IISEG_WINO_MIN_CIN', '128'))
 # output channels (conv_wino_f64.hip); IISEG_WINO_F64=0 keeps every layer on the direct kernel
 WINO_F64 = os.environ.get('IISEG_WINO_F64', '1') != '0'
 WINO_F64_MIN_CIN = int(os.environ.get('IISEG_WINO_F64_MIN_CIN', '128'))
-WINO_F64_MIN_COUT = int(os.environ.get('IISEG_WINO_F64_MIN_COUT', '64'))
+# (a 128 -> 64 layer at 113^2 is HBM-bound on the V / M round trips: 1.35 ms against 1.1 ms on the halo kernel)
+WINO_F64_MIN_COUT = int(os.environ.get('IISEG_WINO_F64_MIN_COUT', '128'))
 WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
 # Layers with at most this many input channels use the kernel that also applies the output
 # transform (products stay in registers, no M round trip through HBM); deeper layers are
@@ -131,6 +132,16 @@ def _wino_workspace(n, device):
     if ws is None or ws.numel() < n:
         _wino_ws[key] = None
         ws = _wino_ws[key] = torch.empty(int(n), dtype=torch.float32, device=device)
+    return ws
+
+
+def _wino_workspace64(n, device):
+    """float64 scratch of the current workspace tag (Winograd V / M, the GEMM form's V / partial sums)."""
+    key = _ws_key(device)
+    ws = _wino_ws64.get(key)
+    if ws is None or ws.numel() < n:
+        _wino_ws64[key] = None
+        ws = _wino_ws64[key] = torch.empty(int(n), dtype=torch.float64, device=device)
     return ws
 
 
@@ -558,6 +569,17 @@ class Conv:
                 prof.append((names[i], self.flops(B, d.OH, d.OW) if i == 1 else 0.0, ev0, ev1))
                 ev0 = ev1
             return out
+        if dt == torch.float64 and CONV_GEMM and (d.KH, d.KW) == (1, 1) and d.C1 >= 1024 and x2 is None and \
+                not unpool and add is None and self.lib.iiseg_conv_gemm_f64_supported(C.byref(d)):
+            # deep 1x1 layers (fc6 after im2col, fc7, score_fr): split-K GEMM on the Winograd path's kernel
+            ws = _wino_workspace64(self.lib.iiseg_conv_gemm_f64_workspace_elems(C.byref(d)), x1.device)
+            ev0 = _ev() if prof is not None else None
+            check(self.lib.iiseg_conv_gemm_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(wp, dt),
+                                               _ptr(self.b, dt), _ptr(ws, dt), _ptr(out, dt)),
+                  'iiseg_conv_gemm_f64')
+            if prof is not None:
+                prof.append(('wino64_gemm_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
+            return out
         if dt == torch.float64 and self.wino_f64 and not self.via_im2col and \
                 self.lib.iiseg_conv_wino_f64_supported(C.byref(d)) and \
                 self._form_by_full_map(self.lib.iiseg_conv_wino_f64_supported, d):
@@ -575,6 +597,8 @@ class Conv:
         if prof is not None:
             ev1 = _ev()
             kern = self.kernel
+            if dt == torch.float64 and self.lib.iiseg_conv_halo_f64_supported(C.byref(d)):
+                kern = 'conv_halo_f64_kernel'
             if kern == 'conv_halo_f32_kernel' and C2 > 0 and C1 % 4:
                 kern = 'conv_taps_f32_kernel'      # a k-tile would straddle the two sources
             prof.append((kern, self.flops(B, d.OH, d.OW), ev0, ev1))
@@ -960,12 +984,7 @@ class Conv:
                                   device=self.W.device)
             check(lib.iiseg_conv_wino_pack_f64(_stream(), C.byref(d), _ptr(self.W, dt), self.so, self.sc,
                                                _ptr(self._U, dt)), 'iiseg_conv_wino_pack_f64')
-        n = lib.iiseg_conv_wino_f64_workspace_elems(C.byref(d))
-        key = _ws_key(x1.device)
-        ws = _wino_ws64.get(key)
-        if ws is None or ws.numel() < n:
-            _wino_ws64[key] = None
-            ws = _wino_ws64[key] = torch.empty(int(n), dtype=dt, device=x1.device)
+        ws = _wino_workspace64(lib.iiseg_conv_wino_f64_workspace_elems(C.byref(d)), x1.device)
         ev0 = _ev() if prof is not None else None
         check(lib.iiseg_conv_wino_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(pre, dt),
                                       _ptr(pooled, dt), _ptr(self._U, dt),

@@ -70,6 +70,88 @@ def test_conv_f64_concat_unpool_window_add(ops):
                           onn.depool_eqmask(up, pre, pooled))
 
 
+# the halo-tile float64 kernel (conv_halo_f64.hip: plain 3x3 layers): exact on integer data -- every
+# product and partial sum is an integer below 2^53, so whatever the tile, window or MFMA row count the
+# result must EQUAL the oracle's
+HALO64 = [  # B, C1, C2, H, W, Cout, pad, unpool, window, relu
+    (2, 5, 0, 45, 70, 20, 1, False, None, True),            # 64-row tiles, ragged tile edges, k padding
+    (1, 64, 0, 23, 37, 11, 1, False, None, False),          # 16-row tiles
+    (2, 8, 4, 19, 33, 64, 1, False, (3, 2, 13, 30), True),  # two sources, window
+    (1, 12, 0, 21, 35, 11, 1, True, None, False),           # DePool2D input, odd map (no window for the last row / column)
+    (2, 9, 0, 18, 40, 70, 1, True, (1, 5, 16, 33), True),   # DePool2D input, 64-row tiles, window
+    (1, 3, 0, 30, 66, 16, 0, False, None, True),            # pad 0
+    (1, 11, 0, 12, 12, 64, 5, False, None, True),           # pad > 1 (pad-100 layers)
+]
+
+
+@pytest.mark.parametrize('case', HALO64)
+def test_conv_halo_f64_exact_on_integers(ops, case):
+    B, C1, C2, H, W, Cout, pad, unpool, window, relu = case
+    rng = np.random.default_rng(sum(x for x in case[:7]))
+    Wt = rng.integers(-2, 3, size=(Cout, C1 + C2, 3, 3)).astype(np.float64)
+    b = rng.integers(-4, 5, size=Cout).astype(np.float64)
+    conv = ops.Conv(Wt, b, pad=pad, relu=relu, dtype=F64)
+    kw = {}
+    if unpool:
+        pre = np.maximum(rng.integers(-3, 4, size=(B, C1, H, W)), 0).astype(np.float64)
+        pooled = onn.maxpool2(pre)
+        up = rng.integers(-3, 4, size=pooled.shape).astype(np.float64)
+        xin = onn.depool_eqmask(up, pre, pooled)
+        x1 = dev(up)
+        kw.update(pre=dev(pre), pooled=dev(pooled))
+    else:
+        xin = rng.integers(-3, 4, size=(B, C1 + C2, H, W)).astype(np.float64)
+        x1 = dev(xin[:, :C1])
+        if C2:
+            kw['x2'] = dev(xin[:, C1:])
+    ref = onn.conv2d(xin, Wt, b, pad=pad, relu=False)
+    other = rng.integers(-5, 6, size=ref.shape).astype(np.float64)
+    ref = ref + other
+    if relu:
+        ref = np.maximum(ref, 0)
+    if window is not None:
+        y0, x0, oh, ow = window
+        ref = ref[:, :, y0:y0 + oh, x0:x0 + ow]
+        kw.update(window=window, add_off=(y0, x0))
+    got = host(conv(x1, add=dev(other), **kw))
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    # placement into a larger map + channel slice leave everything else untouched
+    if window is None and not unpool:
+        big = torch.full((B, Cout + 3, ref.shape[2] + 4, ref.shape[3] + 5), 7.0, dtype=F64, device='cuda')
+        conv(x1, add=dev(other), out=big, out_c0=2, place=(1, 3), **kw)
+        hb = host(big)
+        assert np.array_equal(hb[:, 2:2 + Cout, 1:1 + ref.shape[2], 3:3 + ref.shape[3]], ref)
+        hb[:, 2:2 + Cout, 1:1 + ref.shape[2], 3:3 + ref.shape[3]] = 7.0
+        assert np.all(hb == 7.0)
+
+
+def test_conv_halo_f64_is_the_form_of_the_thin_layers(ops):
+    """iiseg_conv_halo_f64_supported: plain 3x3 layers yes; dilated, transposed and 1x1 layers no."""
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    for k, dil, want in ((3, 1, 1), (3, 2, 0), (1, 1, 0)):
+        conv = ops.Conv(rng.standard_normal((8, 6, k, k)), None, pad=0, relu=False, dil=dil, dtype=F64)
+        d, _, _ = conv._plan(1, 6, 0, 20, 20, None, None, False)
+        assert conv.lib.iiseg_conv_halo_f64_supported(C.byref(d)) == want
+
+
+@pytest.mark.parametrize('case', [(3, 1100, 5, 6, 70, 1), (2, 24, 9, 10, 130, 7), (1, 2048, 7, 7, 11, 1)])
+def test_conv_gemm_f64_exact_on_integers(ops, case):
+    """Deep 1x1 layers / im2col'd KxK layers as split-K GEMMs (iiseg_conv_gemm_f64): exact on integer data,
+    whatever the number of K slices."""
+    import ctypes as C
+    B, Cin, H, W, Cout, k = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.integers(-3, 4, size=(B, Cin, H, W)).astype(np.float64)
+    Wt = rng.integers(-2, 3, size=(Cout, Cin, k, k)).astype(np.float64)
+    b = rng.integers(-4, 5, size=Cout).astype(np.float64)
+    conv = ops.Conv(Wt, b, pad=0, relu=True, dtype=F64)
+    d, _, _ = conv._plan(B, Cin, 0, H, W, None, None, False)
+    assert conv.lib.iiseg_conv_gemm_f64_supported(C.byref(d)) == 1
+    got = host(conv(dev(x)))
+    assert np.array_equal(got, onn.conv2d(x, Wt, b, pad=0, relu=True))
+
+
 def test_tail_deconv_metrics_f64(ops):
     rng = np.random.default_rng(10)
     x, Wt, b = rng.standard_normal((2, 11, 5, 6)), rng.standard_normal((11, 11, 16, 16)), \
@@ -164,10 +246,11 @@ WINO64_CASES = [  # B, Cin, H, W, Cout, pad, relu, window, anchor
 
 
 @pytest.mark.parametrize('case', WINO64_CASES)
-def test_conv_wino_f64(ops, case):
+def test_conv_wino_f64(ops, case, monkeypatch):
     """float64 Winograd F(2x2,3x3) (csrc/conv_wino_f64.hip) vs the oracle, incl. windows and tile
     anchors; and bit-identical between a windowed and the full-map launch with the same anchor."""
     B, Cin, H, W, Cout, pad, relu, window, anchor = case
+    monkeypatch.setattr(ops, 'WINO_F64_MIN_COUT', 64)       # (the default sends Cout < 128 to the halo kernel)
     rng = np.random.default_rng(sum(case[:6]))
     x, Wt, b = rng.standard_normal((B, Cin, H, W)), rng.standard_normal((Cout, Cin, 3, 3)), \
         rng.standard_normal(Cout)
@@ -183,7 +266,8 @@ def test_conv_wino_f64(ops, case):
         assert np.array_equal(got, full[:, :, y0:y0 + h, x0:x0 + w])
 
 
-def test_conv_wino_f64_concat_add_placement_and_exact_ties(ops):
+def test_conv_wino_f64_concat_add_placement_and_exact_ties(ops, monkeypatch):
+    monkeypatch.setattr(ops, 'WINO_F64_MIN_COUT', 64)
     rng = np.random.default_rng(31)
     h, t = rng.standard_normal((2, 96, 10, 11)), rng.standard_normal((2, 64, 10, 11))
     Wt, b = rng.standard_normal((72, 160, 3, 3)), rng.standard_normal(72)
@@ -208,11 +292,12 @@ def test_conv_wino_f64_concat_add_placement_and_exact_ties(ops):
 @pytest.mark.parametrize('shape,window,anchor', [((2, 128, 13, 15), None, (0, 0)),
                                                  ((1, 144, 16, 12), (3, 2, 9, 8), (1, 0)),
                                                  ((2, 128, 9, 9), (0, 0, 9, 9), (1, 1))])
-def test_conv_wino_f64_fused_unpool(ops, shape, window, anchor):
+def test_conv_wino_f64_fused_unpool(ops, shape, window, anchor, monkeypatch):
     """DePool2D (layers/mylayers.py:88-115) applied inside the float64 Winograd input transform: vs the
     oracle, and bit-identical to the same Winograd layer run on the materialised unpooled map (odd
     sizes leave the last row / column of `pre` outside every pooling window -> zeros)."""
     B, Cc, H, W = shape
+    monkeypatch.setattr(ops, 'WINO_F64_MIN_COUT', 64)
     rng = np.random.default_rng(H * W + Cc)
     pre = np.maximum(rng.standard_normal(shape), 0)          # ReLU zeros -> genuine ties
     pooled = onn.maxpool2(pre)
