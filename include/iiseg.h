@@ -332,6 +332,21 @@ int iiseg_conv_c8_m16_supported(const iiseg_conv_desc* d);
 int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
                       const uint8_t* mask_in, const float* bn_a, const float* bn_b, const void* wp16,
                       const float* bias, void* out, int out_kind);
+/* 1x1 convolution on a bf16 C8 tensor (csrc/conv1x1_c8.hip): FC-DenseNet's TransitionDown (BN -> ReLU -> 1x1
+ * conv -> 2x2 max-pool, FC_DenseNet.layers.TransitionDown at models/FCDenseNet.py:95) and the SoftmaxLayer's
+ * 1x1 score convolution (models/FCDenseNet.py:134) on the dense block's stack.
+ *   x        (B, in_ctot / 8, H, W, 8) bf16; the layer reads its first Cin channels (Cin % 16 == 0)
+ *   bn_a/b   NULL, or the folded BatchNorm of those channels (iiseg_bn_fold_f32): x <- max(a x + b, 0)
+ *   wp       iiseg_conv1x1_c8_pack of w[Cout][Cin_w] (iiseg_conv1x1_c8_weight_bytes bytes)
+ *   pool 1:  out = bf16 C8 (B, out_ctot / 8, H / 2, W / 2, 8); channels [out_c0, out_c0 + Cout) receive
+ *            maxpool2x2(conv) + bias (ignore_border), a partial last chunk is zero-padded
+ *   pool 0:  out = fp32 NCHW (B, Cout, H, W) = conv + bias (out_ctot, out_c0 ignored) */
+int64_t iiseg_conv1x1_c8_weight_bytes(int Cout, int Cin);
+int iiseg_conv1x1_c8_pack(void* stream, const float* w, int64_t stride_o, int64_t stride_c, int Cout,
+                          int Cin_w, int Cin, void* wp);
+int iiseg_conv1x1_c8(void* stream, const void* x, int B, int Cin, int in_ctot, int H, int W,
+                     const float* bn_a, const float* bn_b, const void* wp, const float* bias, int Cout,
+                     int pool, void* out, int out_ctot, int out_c0);
 int iiseg_bn_fold_f32(void* stream, const float* beta, const float* gamma, const float* mean,
                       const float* inv_std, float* a, float* b, int n);
 int64_t iiseg_bn_stats_c8_workspace_elems(int n);

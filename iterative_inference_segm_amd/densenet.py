@@ -15,10 +15,16 @@ MI355X mapping:
     center-cropped straight into the new stack; the skip stack is copied behind it.
 Because BN couples the images of a batch, a reference batch must stay on one GPU.
 """
+import os
+
 import numpy as np
 import torch
 
 from . import ops
+
+# mma='bf16c8': TransitionDown and the 1x1 class-score layer as one C8 kernel each (0: the 'bf16' forms on
+# fp32 NCHW copies of the stack, through layout converters)
+C8_1X1 = os.environ.get('IISEG_DENSENET_C8_1X1', '1') != '0'
 
 GROWTH = 16
 N_POOL = 5
@@ -102,9 +108,9 @@ class FCDenseNet:
         """mma: 'f32' (default) | 'bf16' (bf16 MFMA operands, fp32 NCHW activations) | 'bf16c8'
         (configs[2] as BASELINE names it: the dense-block stacks as bf16 C8 tensors, every
         BN_ReLU_Conv of a dense block one launch of the 16-row C8 kernel with BatchNorm + ReLU applied
-        while the input is staged; the first conv on the 64-channel C8 kernel; TransitionDown /
-        TransitionUp / the 1x1 score layer -- 11 of the 103 convolutions -- on the 'bf16' forms through
-        layout converters)."""
+        while the input is staged; the first conv and TransitionUp on the 64-channel C8 kernel;
+        TransitionDown (BN + ReLU + 1x1 conv + pool) and the 1x1 score layer one launch each of
+        csrc/conv1x1_c8.hip on the stack -- all 103 convolutions read bf16 C8)."""
         mma = mma or ops.DEFAULT_MMA
         self.c8 = mma == 'bf16c8' and dtype == torch.float32 and growth == 16
         if mma in ('bf16c8', 'bf16x3'):
@@ -141,6 +147,9 @@ class FCDenseNet:
                                                                        p['W'].shape[0] % 16 == 0))
                 e['conv'] = ops.Conv(p['W'], p['b'], pad=k // 2, relu=False, device=device,
                                      dtype=dtype, mma='bf16c8' if on_c8 else mma_other)
+                if self.c8 and k == 1 and C8_1X1 and p['kind'] in ('td', 'softmax') and p['W'].shape[1] % 16 == 0:
+                    # TransitionDown / the class-score layer on the C8 stack itself (csrc/conv1x1_c8.hip)
+                    e['conv8'] = ops.Conv1x1C8(p['W'], p['b'], device=device)
             self.layers.append(e)
 
     def __call__(self, x):
@@ -187,16 +196,25 @@ class FCDenseNet:
             # TransitionDown (BN -> ReLU -> 1x1 conv -> pool) on the fp32-NCHW forms
             e = next(it)
             n = stack.n
-            xs = ops.c8_slice_to_nchw(stack.buf, 0, n)
-            t = ops.bn_relu(xs, n, e['beta'], e['gamma'], stack.mean, stack.inv_std, out=xs)
-            t = ops.maxpool2x2(e['conv'](t))
-            del xs
+            nxt = _Stack8(B, n + g * self.nlpb[i + 1], H // 2, W // 2, dev)
+            if 'conv8' in e:
+                # one kernel on the C8 stack: BN + ReLU on the way in, the 2x2 max-pool in the epilogue, bf16
+                # C8 straight into the next block's stack
+                ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, n, a=stack.a, b=stack.b)
+                e['conv8'](stack.buf, n, bn=(stack.a, stack.b), pool=True, out=nxt.buf, out_c0=0)
+                t = None
+            else:
+                # on the fp32-NCHW forms through layout converters
+                xs = ops.c8_slice_to_nchw(stack.buf, 0, n)
+                t = ops.bn_relu(xs, n, e['beta'], e['gamma'], stack.mean, stack.inv_std, out=xs)
+                t = ops.maxpool2x2(e['conv'](t))
+                del xs
+                ops.nchw_to_c8_slice(t, nxt.buf, 0)
             H, W = H // 2, W // 2
-            stack = _Stack8(B, n + g * self.nlpb[i + 1], H, W, dev)
-            ops.nchw_to_c8_slice(t, stack.buf, 0)
+            stack = nxt
             stack.added(n)
             if i + 1 in ints:
-                hidden.append(t)
+                hidden.append(t if t is not None else ops.c8_slice_to_nchw(stack.buf, 0, n))
         skips = skips[::-1]
         nblock = self.nlpb[self.n_pool]
         block0 = stack.n
@@ -237,7 +255,11 @@ class FCDenseNet:
             del blk, up
             for _ in range(nlay):
                 self._brc8(it, stack)
-        score = next(it)['conv'](ops.c8_slice_to_nchw(stack.buf, 0, stack.n))   # SoftmaxLayer's 1x1 conv
+        e = next(it)                                                  # SoftmaxLayer's 1x1 conv
+        if 'conv8' in e:
+            score = e['conv8'](stack.buf, stack.n)
+        else:
+            score = e['conv'](ops.c8_slice_to_nchw(stack.buf, 0, stack.n))
         probs = ops.crop_softmax(score, H, W, off=(0, 0))
         return hidden + [probs]
 

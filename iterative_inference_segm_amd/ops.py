@@ -1334,6 +1334,65 @@ def confusion_accumulate(y, t, cm, sums, active=None):
 
 
 
+class Conv1x1C8:
+    """A 1x1 layer on a bf16 C8 tensor (csrc/conv1x1_c8.hip; include/iiseg.h iiseg_conv1x1_c8): FC-DenseNet's
+    TransitionDown (`bn` + `pool=True`: BN -> ReLU -> 1x1 conv -> 2x2 max-pool into a slice of the next
+    stack) and its 1x1 class-score layer (`pool=False`: fp32 NCHW).  W (Cout, Cin, 1, 1), b (Cout) or None."""
+
+    def __init__(self, W, b, device='cuda'):
+        self.lib = _lib.load()
+        self.W = torch.as_tensor(W).to(torch.float32).contiguous().to(device)
+        self.b = None if b is None else torch.as_tensor(b).to(torch.float32).contiguous().to(device)
+        if self.W.dim() != 4 or tuple(self.W.shape[2:]) != (1, 1):
+            raise ValueError('Conv1x1C8 takes (Cout, Cin, 1, 1) filters')
+        self.Cout, self.Cin = int(self.W.shape[0]), int(self.W.shape[1])
+        self._wp = {}
+
+    def flops(self, B, H, W):
+        return 2.0 * self.Cin * self.Cout * H * W * B
+
+    def __call__(self, x8, in_c=None, bn=None, pool=False, out=None, out_c0=0):
+        if not is_c8(x8) or not x8.is_contiguous():
+            raise RuntimeError('Conv1x1C8 needs a contiguous C8 tensor')
+        B, C8n, H, W, _ = x8.shape
+        cin = int(in_c) if in_c is not None else C8n * 8
+        if cin % 16 or cin > C8n * 8 or cin < self.Cin or cin - self.Cin >= 16:
+            raise RuntimeError('Conv1x1C8: %d input channels of %d (layer: %d)' % (cin, C8n * 8, self.Cin))
+        wp = self._wp.get(cin)
+        if wp is None:
+            n = self.lib.iiseg_conv1x1_c8_weight_bytes(self.Cout, cin)
+            wp = self._wp[cin] = torch.empty(int(n) // 2, dtype=torch.bfloat16, device=self.W.device)
+            check(self.lib.iiseg_conv1x1_c8_pack(_stream(), _ptr(self.W), self.Cin, 1, self.Cout, self.Cin, cin,
+                                                 _ptr(wp, torch.bfloat16)), 'iiseg_conv1x1_c8_pack')
+        if pool:
+            if out is None:
+                out = torch.zeros((B, c8_chunks(self.Cout), H // 2, W // 2, 8), dtype=torch.bfloat16,
+                                  device=x8.device)
+                out_c0 = 0
+            if not is_c8(out) or not out.is_contiguous() or out.shape[0] != B or \
+                    tuple(out.shape[2:4]) != (H // 2, W // 2):
+                raise RuntimeError('Conv1x1C8 pool target %s' % (tuple(out.shape),))
+            octot = out.shape[1] * 8
+        else:
+            if out is None:
+                out = torch.empty((B, self.Cout, H, W), dtype=torch.float32, device=x8.device)
+            if tuple(out.shape) != (B, self.Cout, H, W) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise RuntimeError('Conv1x1C8 target %s' % (tuple(out.shape),))
+            octot = 0
+        a, b_ = bn if bn is not None else (None, None)
+        if a is not None and (a.numel() < cin or b_.numel() < cin):
+            raise RuntimeError('Conv1x1C8: folded BN vectors shorter than the input')
+        prof = CONV_PROFILE
+        ev0 = _ev() if prof is not None else None
+        check(self.lib.iiseg_conv1x1_c8(_stream(), C.c_void_p(x8.data_ptr()), B, cin, C8n * 8, H, W, _ptr(a),
+                                        _ptr(b_), _ptr(wp, torch.bfloat16), _ptr(self.b), self.Cout,
+                                        1 if pool else 0, C.c_void_p(out.data_ptr()), octot, int(out_c0)),
+              'iiseg_conv1x1_c8')
+        if prof is not None:
+            prof.append(('conv1x1_c8_kernel', self.flops(B, H, W), ev0, _ev()))
+        return out
+
+
 def bn_fold(beta, gamma, mean, inv_std, n, a=None, b=None, cap=None):
     """(a, b) with max(a x + b, 0) == relu(BatchNorm(x)) for the first n channels (float32 vectors of
     `cap` >= n entries, zero beyond n): the input-side BN + ReLU of the 16-channel C8 layers."""

@@ -7,7 +7,7 @@ import torch
 import bench
 from iterative_inference_segm_amd import synthetic as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-B = 32
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 ii, _, _ = bench.build_model('cuda', ['pool4'], dtype=torch.float64)
 Xs = [torch.from_numpy(S.make_images(B, 224, 224, seed=1234 + 1000 * i)).cuda().double() for i in range(2)]
 Ts = [torch.from_numpy(S.make_labels(B, 224, 224, seed=99 + 1000 * i)).cuda().double() for i in range(2)]

@@ -420,6 +420,9 @@ def test_config3_densenet_on_c8_stacks(built_lib):
     assert ii8.fcn.c8
     n8 = sum(1 for e in ii8.fcn.layers if e['conv'].c8)
     assert n8 == 92                                        # 91 dense-block layers + the first conv
+    # ... and the other 11 convolutions on C8 kernels of their own: 5 TransitionDown + the score layer
+    # (conv1x1_c8.hip), 5 TransitionUp (zero-inserted block on conv_c8_kernel)
+    assert sum(1 for e in ii8.fcn.layers if 'conv8' in e) == 11
     X = S.make_images(32, 224, 224, seed=303)
     o8, o32 = ii8.pred_fcn_fn(X), ii32.pred_fcn_fn(X)
     y8, y32 = host(o8[-1]), host(o32[-1])

@@ -537,3 +537,51 @@ def test_conv_c8_m16_dense_block_layer(ops):
     assert np.allclose(host(fa)[:n + 16], (g * ii)[:n + 16], rtol=1e-6)
     assert np.allclose(host(fb)[:n + 16], (be - mm * g * ii)[:n + 16], rtol=1e-5, atol=1e-6)
     assert not host(fa)[n + 16:].any()
+
+
+@pytest.mark.parametrize('case', [(3, 112, 48, 22, 30, 48),     # B, cap, n, H, W, Cout: one 64-channel tile, partial
+                                  (2, 96, 80, 13, 18, 80),      # two m-tiles, odd map (ignore_border)
+                                  (1, 32, 32, 40, 66, 32)])
+def test_conv1x1_c8_transition_down(ops, case):
+    """FC-DenseNet's TransitionDown on a C8 stack as ONE kernel (csrc/conv1x1_c8.hip; FC_DenseNet.layers
+    TransitionDown, models/FCDenseNet.py:95): BatchNorm + ReLU of the first n channels on the way in, 1x1
+    conv, 2x2 max-pool (ignore_border), + bias, bf16 C8 into a slice of the next stack -- bit for bit on
+    integer data, the rest of the target untouched."""
+    B, cap, n, H, W, Cout = case
+    rng = np.random.default_rng(sum(case))
+    stack = np.zeros((B, cap, H, W))
+    stack[:, :n] = ints(rng, B, n, H, W, lo=-3, hi=4)
+    stack[:, n:] = 9.0                                   # later slices: must not be read
+    a = rng.integers(1, 3, size=n).astype(np.float64)
+    bsh = rng.integers(-2, 3, size=n).astype(np.float64)
+    xin = np.maximum(stack[:, :n] * a[None, :, None, None] + bsh[None, :, None, None], 0)
+    Wt = ints(rng, Cout, n, 1, 1, lo=-1, hi=2)
+    bias = ints(rng, Cout)
+    ref = onn.maxpool2(onn.conv2d(xin, Wt, bias, pad=0, relu=False))
+    # (the stored value is the fp32 result rounded to bf16: the same rounding on the reference)
+    ref = torch.from_numpy(ref).float().bfloat16().float().numpy().astype(np.float64)
+    conv = ops.Conv1x1C8(Wt, bias)
+    s8 = ops.nchw_to_c8(dev(stack))
+    at = torch.zeros(cap, device='cuda'); bt = torch.zeros(cap, device='cuda')
+    at[:n] = torch.from_numpy(a).float().cuda(); bt[:n] = torch.from_numpy(bsh).float().cuda()
+    ocap = Cout + 32
+    nxt = torch.full((B, ocap // 8, H // 2, W // 2, 8), 5.0, dtype=torch.bfloat16, device='cuda')
+    r = conv(s8, n, bn=(at, bt), pool=True, out=nxt, out_c0=16)
+    assert r is nxt
+    full = from_c8(nxt, ocap)
+    assert np.array_equal(full[:, 16:16 + Cout], ref)
+    assert np.all(full[:, :16] == 5.0) and np.all(full[:, 16 + Cout:] == 5.0)
+    assert np.array_equal(from_c8(s8, cap), stack)       # the source stack is only read
+
+
+def test_conv1x1_c8_score_layer(ops):
+    """The SoftmaxLayer's 1x1 class-score convolution on the C8 stack (models/FCDenseNet.py:134): fp32 NCHW
+    out, no BN, exact on integer data; pixel count not a multiple of the 512-pixel tile."""
+    rng = np.random.default_rng(77)
+    B, n, H, W, Cout = 2, 64, 19, 31, 11
+    x = ints(rng, B, n, H, W, lo=-3, hi=4)
+    Wt = ints(rng, Cout, n, 1, 1, lo=-2, hi=3)
+    bias = ints(rng, Cout)
+    got = host(ops.Conv1x1C8(Wt, bias)(ops.nchw_to_c8(dev(x)), n))
+    assert got.shape == (B, Cout, H, W) and got.dtype == np.float32
+    assert np.array_equal(got, onn.conv2d(x, Wt, bias, pad=0, relu=False))
