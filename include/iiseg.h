@@ -332,6 +332,18 @@ int iiseg_conv_c8_m16_supported(const iiseg_conv_desc* d);
 int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
                       const uint8_t* mask_in, const float* bn_a, const float* bn_b, const void* wp16,
                       const float* bias, void* out, int out_kind);
+/* The same with a caller-owned scratch buffer for SPLIT-K launches: on small maps (one tile per image, 40+
+ * k-tiles in sequence: the deep dense blocks of FC-DenseNet at 7^2 .. 28^2) the channel range is dealt to
+ * 16 / tiles-per-image workgroups per tile, each sums its share from zero into an fp32 slab, and a second
+ * launch (one workgroup per tile) adds the slabs in slice order and writes the result -- a fixed association
+ * that depends on the layer geometry only, never on the batch.  workspace: iiseg_conv_c8_m16_workspace_bytes(d)
+ * bytes (0: the launch is not split and workspace may be NULL), 16-byte aligned.  Without a workspace the
+ * launch is not split (iiseg_conv_c8_m16). */
+int64_t iiseg_conv_c8_m16_workspace_bytes(const iiseg_conv_desc* d);
+int iiseg_conv_c8_m16_ws(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
+                         const uint8_t* mask_in, const float* bn_a, const float* bn_b, const void* wp16,
+                         const float* bias, void* out, int out_kind, void* workspace,
+                         int64_t workspace_bytes);
 /* 1x1 convolution on a bf16 C8 tensor (csrc/conv1x1_c8.hip): FC-DenseNet's TransitionDown (BN -> ReLU -> 1x1
  * conv -> 2x2 max-pool, FC_DenseNet.layers.TransitionDown at models/FCDenseNet.py:95) and the SoftmaxLayer's
  * 1x1 score convolution (models/FCDenseNet.py:134) on the dense block's stack.

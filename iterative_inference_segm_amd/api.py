@@ -83,7 +83,7 @@ class IterativeInference:
     def __del__(self):
         # the engine's scratch buffers go with it
         try:
-            for cache in (ops._wino_ws, ops._wino_ws64, ops._bn_ws):
+            for cache in (ops._wino_ws, ops._wino_ws64, ops._bn_ws, ops._m16_ws):
                 for k in [k for k in cache if isinstance(k, tuple) and k[1] == self._ws_tag]:
                     cache.pop(k, None)
         except Exception:

@@ -76,6 +76,11 @@ struct M16Params {
     int relu;
     int n_ptiles, tiles_y, tiles_x, th, tw;
     unsigned pw_magic, tw_magic;
+    // split-K (small maps: few tiles, long channel loops), two launches: phase 1 -- workgroup (tile, slice) sums
+    // k-tiles [nkt slice / nsplit, nkt (slice + 1) / nsplit) from zero (slice 0: from the bias) into an fp32 slab;
+    // phase 2 -- one workgroup per tile adds the slabs in slice order and runs the epilogue.  phase 0: no split
+    int nsplit, phase;
+    float* slabs;                 // [n_ptiles][nsplit][NB * 256 * 4]
 };
 
 enum { M16_PLAIN = 0, M16_UNPOOL = 1, M16_BNRELU = 2 };
@@ -94,7 +99,14 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
 
     // ---- tile: th x tw pixels of one image, blocks dealt round-robin to the XCDs in runs ------------
     int pt, mt;
-    tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, 1, pt, mt);
+    const int S = p.nsplit;
+    int sidx = 0;
+    if (p.phase == 1) {
+        pt = (int)blockIdx.x / S;
+        sidx = (int)blockIdx.x - pt * S;
+    } else {
+        tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, 1, pt, mt);
+    }
     const int tpi = p.tiles_y * p.tiles_x;
     const int tb = pt / tpi;
     const int tr = pt - tb * tpi;
@@ -176,8 +188,9 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
     f32x4 acc[NB];
     {
         const __amdgpu_buffer_rsrc_t r_bias = mk_rsrc(p.bias, p.bias ? (unsigned)p.Cout * 4u : 0u);
-        const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             r_bias, (int)(16u * (unsigned)g), 0, 0));
+        if (sidx != 0) bv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = bv;
     }
@@ -256,19 +269,22 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
         }
     };
 
-    const int nkt = p.nkt;
-    if constexpr (MODE == M16_PLAIN) {
-        dma_x(0, 0);
-        dma_w(0, 0);
-    } else {
-        load_x(0);
-        dma_w(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        store_x(0, 0);
+    const int kt0 = p.phase == 1 ? p.nkt * sidx / S : 0;
+    const int kt1 = p.phase == 1 ? p.nkt * (sidx + 1) / S : (p.phase == 2 ? 0 : p.nkt);
+    if (p.phase != 2) {
+        if constexpr (MODE == M16_PLAIN) {
+            dma_x(2 * kt0, 0);
+            dma_w(kt0, 0);
+        } else {
+            load_x(2 * kt0);
+            dma_w(kt0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            store_x(2 * kt0, 0);
+        }
     }
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nkt;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
         // own DMA pieces (and LDS writes) retired, then the barrier publishes them and tells that every
         // wave is done reading what the previous step read
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -295,6 +311,27 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 store_x(2 * (kt + 1), buf ^ 1);
             }
+        }
+    }
+
+    if (p.phase == 1) {
+        // partial sums of this slice -> its slab (only the lanes that own an output pixel)
+        float* slab = p.slabs + ((size_t)pt * S + sidx) * (NB * 256 * 4);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (eok[k]) *reinterpret_cast<f32x4*>(slab + (k * 256 + tid) * 4) = acc[k];
+        return;
+    }
+    if (p.phase == 2) {
+        // the slabs in slice order: a fixed association of the channel sum
+        const float* slab0 = p.slabs + (size_t)pt * S * (NB * 256 * 4);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            if (!eok[k]) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + (k * 256 + tid) * 4);
+            for (int q = 1; q < S; ++q)
+                v += *reinterpret_cast<const f32x4*>(slab0 + (size_t)q * (NB * 256 * 4) + (k * 256 + tid) * 4);
+            acc[k] = v;
         }
     }
 
@@ -424,13 +461,52 @@ int m16_check(const iiseg_conv_desc* d) {
     return IISEG_OK;
 }
 
+
+// tile shape of a launch and its split-K factor.  The factor depends on the tiles PER IMAGE and the channel
+// count only -- never on the batch -- so an image gets the same association of its channel sum alone and
+// in a batch: 16 / tiles-per-image slices (one 7^2 or 14^2 map of FC-DenseNet's deep blocks is ONE tile with
+// 41 .. 67 k-tiles in sequence, 32 workgroups on 256 CUs at batch 32), at least four k-tiles per slice.
+void m16_tiling(const iiseg_conv_desc* d, int* th, int* tw, int* nsplit) {
+    int64_t tiles;
+    rect_shape(d->OH, d->OW, NB * 64, HCAP, false, th, tw, &tiles);
+    static const char* shape_env = getenv("IISEG_M16_SHAPE");           // "th,tw": timing experiments
+    if (shape_env) {
+        int a = 0, b = 0;
+        if (sscanf(shape_env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a * b <= NB * 64 && (a + 2) * (b + 2) <= HCAP) {
+            *th = a; *tw = b;
+        }
+    }
+    static const int split_env = getenv("IISEG_M16_SPLITK") ? atoi(getenv("IISEG_M16_SPLITK")) : 1;
+    const int tpi = ((d->OH + *th - 1) / *th) * ((d->OW + *tw - 1) / *tw);
+    int S = 16 / tpi;
+    const int nkt = d->C1 / 16;
+    if (S > nkt / 4) S = nkt / 4;
+    *nsplit = (split_env && S > 1) ? S : 1;
+}
+
 }  // namespace
 
 extern "C" int iiseg_conv_c8_m16_supported(const iiseg_conv_desc* d) { return m16_check(d) == IISEG_OK ? 1 : 0; }
 
+extern "C" int64_t iiseg_conv_c8_m16_workspace_bytes(const iiseg_conv_desc* d) {
+    if (m16_check(d) != IISEG_OK) return 0;
+    int th, tw, S;
+    m16_tiling(d, &th, &tw, &S);
+    if (S <= 1) return 0;
+    const int64_t tiles = (int64_t)d->B * ((d->OH + th - 1) / th) * ((d->OW + tw - 1) / tw);
+    return tiles * S * (NB * 256 * 4) * 4;
+}
+
 extern "C" int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
                                  const uint8_t* mask_in, const float* bn_a, const float* bn_b,
                                  const void* wp16, const float* bias, void* out, int out_kind) {
+    return iiseg_conv_c8_m16_ws(stream, d, x1, in_ctot, mask_in, bn_a, bn_b, wp16, bias, out, out_kind, nullptr, 0);
+}
+
+extern "C" int iiseg_conv_c8_m16_ws(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
+                                    const uint8_t* mask_in, const float* bn_a, const float* bn_b,
+                                    const void* wp16, const float* bias, void* out, int out_kind,
+                                    void* workspace, int64_t workspace_bytes) {
     const int st = m16_check(d);
     if (st) return st;
     if (in_ctot == 0) in_ctot = d->C1;
@@ -459,30 +535,38 @@ extern "C" int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const v
     p.out_y0 = d->out_H ? d->out_y0 : 0;
     p.out_x0 = d->out_H ? d->out_x0 : 0;
     p.relu = (d->flags & IISEG_CONV_RELU) ? 1 : 0;
-    int64_t tiles;
-    rect_shape(d->OH, d->OW, NB * 64, HCAP, false, &p.th, &p.tw, &tiles);
-    static const char* shape_env = getenv("IISEG_M16_SHAPE");           // "th,tw": timing experiments
-    if (shape_env) {
-        int a = 0, b = 0;
-        if (sscanf(shape_env, "%d,%d", &a, &b) == 2 && a > 0 && b > 0 && a * b <= NB * 64 && (a + 2) * (b + 2) <= HCAP) {
-            p.th = a; p.tw = b;
-        }
-    }
+    m16_tiling(d, &p.th, &p.tw, &p.nsplit);
     p.tiles_y = (d->OH + p.th - 1) / p.th;
     p.tiles_x = (d->OW + p.tw - 1) / p.tw;
     p.n_ptiles = d->B * p.tiles_y * p.tiles_x;
     p.pw_magic = magic20(p.tw + 2);
     p.tw_magic = magic20(p.tw);
+    if (p.nsplit > 1) {
+        const int64_t need = (int64_t)p.n_ptiles * p.nsplit * (NB * 256 * 4) * 4;
+        if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) p.nsplit = 1;
+        else p.slabs = (float*)workspace;
+    }
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(p.n_ptiles), block(256);
-    if (out_kind == 3) {
-        if (unpool) IISEG_LAUNCH((conv_c8_m16_kernel<M16_UNPOOL, true>), grid, block, 0, s, p);
-        else if (bn_a) IISEG_LAUNCH((conv_c8_m16_kernel<M16_BNRELU, true>), grid, block, 0, s, p);
-        else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, true>), grid, block, 0, s, p);
+    const dim3 block(256);
+    auto launch = [&](dim3 grid) {
+        if (out_kind == 3) {
+            if (unpool) IISEG_LAUNCH((conv_c8_m16_kernel<M16_UNPOOL, true>), grid, block, 0, s, p);
+            else if (bn_a) IISEG_LAUNCH((conv_c8_m16_kernel<M16_BNRELU, true>), grid, block, 0, s, p);
+            else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, true>), grid, block, 0, s, p);
+        } else {
+            if (unpool) IISEG_LAUNCH((conv_c8_m16_kernel<M16_UNPOOL, false>), grid, block, 0, s, p);
+            else if (bn_a) IISEG_LAUNCH((conv_c8_m16_kernel<M16_BNRELU, false>), grid, block, 0, s, p);
+            else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, false>), grid, block, 0, s, p);
+        }
+    };
+    if (p.nsplit > 1) {
+        p.phase = 1;
+        launch(dim3(p.n_ptiles * p.nsplit));
+        p.phase = 2;
+        launch(dim3(p.n_ptiles));
     } else {
-        if (unpool) IISEG_LAUNCH((conv_c8_m16_kernel<M16_UNPOOL, false>), grid, block, 0, s, p);
-        else if (bn_a) IISEG_LAUNCH((conv_c8_m16_kernel<M16_BNRELU, false>), grid, block, 0, s, p);
-        else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, false>), grid, block, 0, s, p);
+        p.phase = 0;
+        launch(dim3(p.n_ptiles));
     }
     return iiseg_check_launch();
 }

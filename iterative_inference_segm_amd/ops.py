@@ -145,11 +145,24 @@ def _wino_workspace64(n, device):
     return ws
 
 
+_m16_ws = {}
+
+
+def _m16_workspace(nbytes, device):
+    """Scratch of the split-K launches of the 16-row C8 kernel (fp32 slabs of partial sums)."""
+    key = _ws_key(device)
+    ws = _m16_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _m16_ws[key] = None
+        ws = _m16_ws[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return ws
+
+
 def workspace_refs(device):
     """The scratch tensors launches under the current workspace tag point into (fp32 / float64
     Winograd workspaces, BN partial sums): a captured HIP graph keeps them alive."""
     key = _ws_key(device)
-    return tuple(c.get(key) for c in (_wino_ws, _wino_ws64, _bn_ws))
+    return tuple(c.get(key) for c in (_wino_ws, _wino_ws64, _bn_ws, _m16_ws))
 
 
 def workspace_ptrs(device):
@@ -768,10 +781,14 @@ class Conv:
         dtp = lambda t: None if t is None else _ptr(t, t.dtype)
         prof = CONV_PROFILE
         ev0 = _ev() if prof is not None else None
-        check(lib.iiseg_conv_c8_m16(_stream(), C.byref(d), dtp(x1), in_ctot, dtp(mask_in),
-                                    None if bn is None else _ptr(bn[0]), None if bn is None else _ptr(bn[1]),
-                                    dtp(self._W16c8), _ptr(self.b), dtp(out), 3 if fmt == 'nchw' else 1),
-              'iiseg_conv_c8_m16')
+        # split-K launches (small maps, long channel loops) sum their slices through a scratch buffer
+        nws = lib.iiseg_conv_c8_m16_workspace_bytes(C.byref(d))
+        ws = _m16_workspace(nws, x1.device) if nws else None
+        check(lib.iiseg_conv_c8_m16_ws(_stream(), C.byref(d), dtp(x1), in_ctot, dtp(mask_in),
+                                       None if bn is None else _ptr(bn[0]), None if bn is None else _ptr(bn[1]),
+                                       dtp(self._W16c8), _ptr(self.b), dtp(out), 3 if fmt == 'nchw' else 1,
+                                       None if ws is None else C.c_void_p(ws.data_ptr()), int(nws)),
+              'iiseg_conv_c8_m16_ws')
         if prof is not None:
             prof.append(('conv_c8_m16_kernel', self.flops(B, OH, OW), ev0, _ev()))
             if CONV_PROFILE_INFO is not None:

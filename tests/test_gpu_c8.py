@@ -585,3 +585,37 @@ def test_conv1x1_c8_score_layer(ops):
     got = host(ops.Conv1x1C8(Wt, bias)(ops.nchw_to_c8(dev(x)), n))
     assert got.shape == (B, Cout, H, W) and got.dtype == np.float32
     assert np.array_equal(got, onn.conv2d(x, Wt, bias, pad=0, relu=False))
+
+
+@pytest.mark.parametrize('case', [(3, 7, 7, 144), (2, 14, 14, 208), (2, 28, 28, 96), (1, 20, 33, 64)])
+def test_conv_c8_m16_split_k(ops, case):
+    """Small maps with long channel loops (FC-DenseNet's deep dense blocks): the channel range of a tile dealt to
+    several workgroups, slabs of fp32 partial sums added in slice order by a second launch (iiseg_conv_c8_m16_ws)
+    -- exact on integer data, repeatable, the stack around the slice untouched."""
+    import ctypes as C
+    B, H, W, n = case
+    rng = np.random.default_rng(sum(case))
+    cap = n + 32
+    stack = np.zeros((B, cap, H, W))
+    stack[:, :n] = ints(rng, B, n, H, W, lo=-2, hi=3)
+    stack[:, n:] = 9.0
+    a = rng.integers(1, 3, size=n).astype(np.float64)
+    bsh = rng.integers(-1, 2, size=n).astype(np.float64)
+    xin = np.maximum(stack[:, :n] * a[None, :, None, None] + bsh[None, :, None, None], 0)
+    Wt = (rng.random((16, n, 3, 3)) < 0.08) * ints(rng, 16, n, 3, 3, lo=-1, hi=2)    # sparse: sums stay bf16-exact
+    bias = ints(rng, 16)
+    ref = onn.conv2d(xin, Wt, bias, pad=1, relu=False)
+    assert np.abs(ref).max() <= 256
+    conv = ops.Conv(Wt, bias, pad=1, relu=False, mma='bf16c8')
+    at = torch.zeros(cap, device='cuda'); bt = torch.zeros(cap, device='cuda')
+    at[:n] = torch.from_numpy(a).float().cuda(); bt[:n] = torch.from_numpy(bsh).float().cuda()
+    for rep in range(2):
+        s8 = ops.nchw_to_c8(dev(stack))
+        conv(s8, in_c=n, bn=(at, bt), out=s8, out_c0=n)
+        full = from_c8(s8, cap)
+        assert np.array_equal(full[:, n:n + 16], ref), rep
+        assert np.array_equal(full[:, :n], stack[:, :n]) and np.array_equal(full[:, n + 16:], stack[:, n + 16:])
+    d = ops.ConvDesc()
+    d.B, d.C1, d.C2, d.H, d.W, d.Cout, d.KH, d.KW, d.pad, d.dil, d.OH, d.OW = B, n, 0, H, W, 16, 3, 3, 1, 1, H, W
+    split = conv.lib.iiseg_conv_c8_m16_workspace_bytes(C.byref(d)) > 0
+    assert split == ((H, W) in ((7, 7), (14, 14)))       # (one tile per image and >= 8 k-tiles: split launches)
