@@ -337,13 +337,23 @@ int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, in
  * 16 / tiles-per-image workgroups per tile, each sums its share from zero into an fp32 slab, and a second
  * launch (one workgroup per tile) adds the slabs in slice order and writes the result -- a fixed association
  * that depends on the layer geometry only, never on the batch.  workspace: iiseg_conv_c8_m16_workspace_bytes(d)
- * bytes (0: the launch is not split and workspace may be NULL), 16-byte aligned.  Without a workspace the
- * launch is not split (iiseg_conv_c8_m16). */
+ * bytes (it also holds the per-tile statistics below), 16-byte aligned.  Without a workspace the launch is
+ * not split (iiseg_conv_c8_m16). */
 int64_t iiseg_conv_c8_m16_workspace_bytes(const iiseg_conv_desc* d);
+/* Two more fusions of a dense-block layer (models/FCDenseNet.py:88-92) ride on the same entry point:
+ *   stat_mean / stat_inv_std (bf16 C8 output only, needs the workspace): the batch statistics (biased variance,
+ *     stat_eps; P10) of the 16 produced channels -- of the stored bf16 values, per-tile sums in double out of the
+ *     conv's epilogue, added in a fixed order by a one-workgroup reduction -- written to entries [out_c0,
+ *     out_c0 + 16) of the two vectors (iiseg_bn_stats_c8's result up to the order of the double sums);
+ *   fold_* (with the statistics): that reduction then also forms the (a, b) pair of the NEXT consumer's
+ *     BatchNorm over the first fold_n channels of the stack from the two vectors (iiseg_bn_fold_f32's
+ *     arithmetic, one launch less per layer). */
 int iiseg_conv_c8_m16_ws(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
                          const uint8_t* mask_in, const float* bn_a, const float* bn_b, const void* wp16,
                          const float* bias, void* out, int out_kind, void* workspace,
-                         int64_t workspace_bytes);
+                         int64_t workspace_bytes, float* stat_mean, float* stat_inv_std, double stat_eps,
+                         const float* fold_beta, const float* fold_gamma, float* fold_a, float* fold_b,
+                         int fold_n);
 /* 1x1 convolution on a bf16 C8 tensor (csrc/conv1x1_c8.hip): FC-DenseNet's TransitionDown (BN -> ReLU -> 1x1
  * conv -> 2x2 max-pool, FC_DenseNet.layers.TransitionDown at models/FCDenseNet.py:95) and the SoftmaxLayer's
  * 1x1 score convolution (models/FCDenseNet.py:134) on the dense block's stack.

@@ -88,7 +88,7 @@ SIGNATURES = {
     'iiseg_conv_c8_m16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_c8_m16': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 6 + [_i32]),
     'iiseg_conv_c8_m16_workspace_bytes': (_i64, [C.POINTER(ConvDesc)]),
-    'iiseg_conv_c8_m16_ws': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 6 + [_i32, _vp, _i64]),
+    'iiseg_conv_c8_m16_ws': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 6 + [_i32, _vp, _i64, _vp, _vp, _f64] + [_vp] * 4 + [_i32]),
     'iiseg_conv1x1_c8_weight_bytes': (_i64, [C.c_int, C.c_int]),
     'iiseg_conv1x1_c8_pack': (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, C.c_int, C.c_int, _vp]),
     'iiseg_conv1x1_c8': (C.c_int, [_vp, _vp] + [C.c_int] * 5 + [_vp] * 4 + [C.c_int, C.c_int, _vp, C.c_int, C.c_int]),

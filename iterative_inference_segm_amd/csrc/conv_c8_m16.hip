@@ -81,6 +81,9 @@ struct M16Params {
     // phase 2 -- one workgroup per tile adds the slabs in slice order and runs the epilogue.  phase 0: no split
     int nsplit, phase;
     float* slabs;                 // [n_ptiles][nsplit][NB * 256 * 4]
+    // batch statistics of the 16 produced channels (bf16 C8 output): per-tile sums / sums of squares of the
+    // STORED values in double, stat_ws[chunk 0 / 1][tile][16]; bn_stats_c8_final_kernel adds the tiles in order
+    double* stat_ws;
 };
 
 enum { M16_PLAIN = 0, M16_UNPOOL = 1, M16_BNRELU = 2 };
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
         const __amdgpu_buffer_rsrc_t r_out =
             mk_rsrc((const char*)p.out + (size_t)tb * oct8 * OPL * 16, (unsigned)(oct8 * OPL) * 16u);
         const unsigned cplane = (unsigned)(((p.out_c0 >> 3) + (g >> 1)) * OPL) * 16u + 8u * (unsigned)(g & 1);
+        double st_s[4] = {0.0, 0.0, 0.0, 0.0}, st_ss[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const unsigned opix = (unsigned)((p.out_y0 + ey[k]) * p.out_W + p.out_x0 + ex[k]);
@@ -370,6 +374,36 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
             u32x2 w2;
             w2[0] = pack_bf16(v[0], v[1]); w2[1] = pack_bf16(v[2], v[3]);
             __builtin_amdgcn_raw_buffer_store_b64(w2, r_out, (int)(eok[k] ? opix * 16u + cplane : OOB), 0, 0);
+            if (p.stat_ws && eok[k]) {
+                const float sv[4] = {bf_lo(w2[0]), bf_hi(w2[0]), bf_lo(w2[1]), bf_hi(w2[1])};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { st_s[q] += sv[q]; st_ss[q] += (double)sv[q] * sv[q]; }
+            }
+        }
+        if (p.stat_ws) {
+            // channel 4 g + q: the 16 lanes of a group in a fixed-order butterfly, then the four waves in order
+            __shared__ double red[4][4][8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    st_s[q] += __shfl_xor(st_s[q], o, 64);
+                    st_ss[q] += __shfl_xor(st_ss[q], o, 64);
+                }
+            if (l15 == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { red[wave][g][q] = st_s[q]; red[wave][g][4 + q] = st_ss[q]; }
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const int c = tid & 15, which = tid >> 4;            // channel, 0: sum / 1: sum of squares
+                const int gg = c >> 2, qq = c & 3;
+                double t = red[0][gg][which * 4 + qq];
+                t += red[1][gg][which * 4 + qq];
+                t += red[2][gg][which * 4 + qq];
+                t += red[3][gg][which * 4 + qq];
+                p.stat_ws[((size_t)(c >> 3) * p.n_ptiles + pt) * 16 + which * 8 + (c & 7)] = t;
+            }
         }
     }
 }
@@ -421,21 +455,61 @@ __global__ __launch_bounds__(256) void bn_stats_c8_kernel(const uint4* __restric
     if (threadIdx.x < 16) ws[((size_t)blockIdx.x * BN_SLICES + slice) * 16 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(64) void bn_stats_c8_final_kernel(const double* __restrict__ ws, int c8_0, double count,
-                                                               double eps, float* __restrict__ mean,
-                                                               float* __restrict__ inv_std) {
-    const int j = threadIdx.x;
-    if (j >= 8) return;
-    double s = 0.0, ss = 0.0;
-    for (int k = 0; k < BN_SLICES; ++k) {
-        s += ws[((size_t)blockIdx.x * BN_SLICES + k) * 16 + j];
-        ss += ws[((size_t)blockIdx.x * BN_SLICES + k) * 16 + 8 + j];
+// Stage 2: one workgroup per chunk of 8 channels; thread (subset u = tid / 16, value j = tid % 16) adds slices
+// u, u + 64, ... in order, then the 64 subsets are added in order -- a fixed association whatever nslices is.
+// fold_*: (optional, single-chunk-pair launches of the dense-block layers) after the statistics of the new
+// channels are in place, the (a, b) pair of the NEXT consumer's BatchNorm over its first fold_n channels
+// (bn_fold_kernel's arithmetic) by workgroup 0 -- saves that launch.  Needs both chunks' statistics, so the
+// workgroups of a folding launch are ONE workgroup looping over the chunks.
+__global__ __launch_bounds__(1024) void bn_stats_c8_final_kernel(const double* __restrict__ ws, int nslices, int c8_0,
+                                                                 int nchunks, double count, double eps,
+                                                                 float* __restrict__ mean, float* __restrict__ inv_std,
+                                                                 const float* __restrict__ fold_beta,
+                                                                 const float* __restrict__ fold_gamma,
+                                                                 float* __restrict__ fold_a, float* __restrict__ fold_b,
+                                                                 int fold_n) {
+    constexpr int NSUB = 64;
+    __shared__ double part[NSUB][16];
+    const int tid = threadIdx.x, j = tid & 15, u = tid >> 4;
+    const int ch0 = fold_a ? 0 : blockIdx.x, ch1 = fold_a ? nchunks : blockIdx.x + 1;
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const double* w = ws + (size_t)ch * nslices * 16 + j;
+        double t = 0.0;
+        int k = u;
+        // (eight loads in flight, added in slice order)
+        for (; k + 7 * NSUB < nslices; k += 8 * NSUB) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = w[(size_t)(k + q * NSUB) * 16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += v[q];
+        }
+        for (; k < nslices; k += NSUB) t += w[(size_t)k * 16];
+        part[u][j] = t;
+        __syncthreads();
+        if (tid < 16) {
+            double sm = 0.0;
+            for (int q = 0; q < NSUB; ++q) sm += part[q][tid];
+            part[0][tid] = sm;
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const double m = part[0][tid] / count;
+            double var = part[0][8 + tid] / count - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[(c8_0 + ch) * 8 + tid] = (float)m;
+            inv_std[(c8_0 + ch) * 8 + tid] = (float)(1.0 / sqrt(var + eps));
+        }
+        __syncthreads();
     }
-    const double m = s / count;
-    double var = ss / count - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[(c8_0 + blockIdx.x) * 8 + j] = (float)m;
-    inv_std[(c8_0 + blockIdx.x) * 8 + j] = (float)(1.0 / sqrt(var + eps));
+    if (fold_a) {
+        __threadfence_block();
+        for (int c = tid; c < fold_n; c += 1024) {
+            const float sc = fold_gamma[c] * inv_std[c];
+            fold_a[c] = sc;
+            fold_b[c] = fold_beta[c] - mean[c] * sc;
+        }
+    }
 }
 
 int m16_check(const iiseg_conv_desc* d) {
@@ -492,21 +566,24 @@ extern "C" int64_t iiseg_conv_c8_m16_workspace_bytes(const iiseg_conv_desc* d) {
     if (m16_check(d) != IISEG_OK) return 0;
     int th, tw, S;
     m16_tiling(d, &th, &tw, &S);
-    if (S <= 1) return 0;
     const int64_t tiles = (int64_t)d->B * ((d->OH + th - 1) / th) * ((d->OW + tw - 1) / tw);
-    return tiles * S * (NB * 256 * 4) * 4;
+    // per-tile statistics of the produced channels (2 chunks x 16 doubles), then the split-K slabs
+    return tiles * 2 * 16 * 8 + (S > 1 ? tiles * S * (NB * 256 * 4) * 4 : 0);
 }
 
 extern "C" int iiseg_conv_c8_m16(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
                                  const uint8_t* mask_in, const float* bn_a, const float* bn_b,
                                  const void* wp16, const float* bias, void* out, int out_kind) {
-    return iiseg_conv_c8_m16_ws(stream, d, x1, in_ctot, mask_in, bn_a, bn_b, wp16, bias, out, out_kind, nullptr, 0);
+    return iiseg_conv_c8_m16_ws(stream, d, x1, in_ctot, mask_in, bn_a, bn_b, wp16, bias, out, out_kind, nullptr, 0,
+                                nullptr, nullptr, 0.0, nullptr, nullptr, nullptr, nullptr, 0);
 }
 
 extern "C" int iiseg_conv_c8_m16_ws(void* stream, const iiseg_conv_desc* d, const void* x1, int in_ctot,
                                     const uint8_t* mask_in, const float* bn_a, const float* bn_b,
                                     const void* wp16, const float* bias, void* out, int out_kind,
-                                    void* workspace, int64_t workspace_bytes) {
+                                    void* workspace, int64_t workspace_bytes, float* stat_mean,
+                                    float* stat_inv_std, double stat_eps, const float* fold_beta,
+                                    const float* fold_gamma, float* fold_a, float* fold_b, int fold_n) {
     const int st = m16_check(d);
     if (st) return st;
     if (in_ctot == 0) in_ctot = d->C1;
@@ -541,10 +618,17 @@ extern "C" int iiseg_conv_c8_m16_ws(void* stream, const iiseg_conv_desc* d, cons
     p.n_ptiles = d->B * p.tiles_y * p.tiles_x;
     p.pw_magic = magic20(p.tw + 2);
     p.tw_magic = magic20(p.tw);
+    const int64_t stat_bytes = (int64_t)p.n_ptiles * 2 * 16 * 8;
+    if (fold_a && (!stat_mean || !fold_b || !fold_beta || !fold_gamma || fold_n <= 0)) return IISEG_ERR_NULL;
+    if (stat_mean) {
+        if (!stat_inv_std || out_kind != 1 || !workspace || workspace_bytes < stat_bytes || ((uintptr_t)workspace & 15))
+            return IISEG_ERR_UNSUPPORTED;
+        p.stat_ws = (double*)workspace;
+    }
     if (p.nsplit > 1) {
-        const int64_t need = (int64_t)p.n_ptiles * p.nsplit * (NB * 256 * 4) * 4;
+        const int64_t need = stat_bytes + (int64_t)p.n_ptiles * p.nsplit * (NB * 256 * 4) * 4;
         if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) p.nsplit = 1;
-        else p.slabs = (float*)workspace;
+        else p.slabs = (float*)((char*)workspace + stat_bytes);
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256);
@@ -559,15 +643,22 @@ extern "C" int iiseg_conv_c8_m16_ws(void* stream, const iiseg_conv_desc* d, cons
             else IISEG_LAUNCH((conv_c8_m16_kernel<M16_PLAIN, false>), grid, block, 0, s, p);
         }
     };
+    double* const stat_ws = p.stat_ws;
     if (p.nsplit > 1) {
         p.phase = 1;
+        p.stat_ws = nullptr;
         launch(dim3(p.n_ptiles * p.nsplit));
         p.phase = 2;
+        p.stat_ws = stat_ws;
         launch(dim3(p.n_ptiles));
     } else {
         p.phase = 0;
         launch(dim3(p.n_ptiles));
     }
+    if (stat_ws)
+        IISEG_LAUNCH(bn_stats_c8_final_kernel, dim3(fold_a ? 1 : 2), dim3(1024), 0, s, (const double*)stat_ws,
+                     p.n_ptiles, p.out_c0 / 8, 2, (double)d->B * d->OH * d->OW, stat_eps, stat_mean, stat_inv_std,
+                     fold_beta, fold_gamma, fold_a, fold_b, fold_n);
     return iiseg_check_launch();
 }
 
@@ -589,7 +680,8 @@ extern "C" int iiseg_bn_stats_c8(void* stream, const void* x, int B, int Ctot, i
     if (Ctot % 8 || c0 % 8 || n % 8) return IISEG_ERR_UNSUPPORTED;
     IISEG_LAUNCH(bn_stats_c8_kernel, dim3(n / 8, BN_SLICES), dim3(256), 0, (hipStream_t)stream,
                        (const uint4*)x, B, Ctot / 8, c0 / 8, H * W, workspace);
-    IISEG_LAUNCH(bn_stats_c8_final_kernel, dim3(n / 8), dim3(64), 0, (hipStream_t)stream, workspace,
-                       c0 / 8, (double)B * H * W, eps, mean, inv_std);
+    IISEG_LAUNCH(bn_stats_c8_final_kernel, dim3(n / 8), dim3(1024), 0, (hipStream_t)stream, workspace, BN_SLICES,
+                 c0 / 8, n / 8, (double)B * H * W, eps, mean, inv_std, (const float*)nullptr, (const float*)nullptr,
+                 (float*)nullptr, (float*)nullptr, 0);
     return iiseg_check_launch();
 }

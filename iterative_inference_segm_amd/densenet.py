@@ -26,6 +26,10 @@ from . import ops
 # fp32 NCHW copies of the stack, through layout converters)
 C8_1X1 = os.environ.get('IISEG_DENSENET_C8_1X1', '1') != '0'
 
+# dense-block layers: BatchNorm fold and the statistics of the produced slice inside the conv launch (0: separate
+# bn_fold / bn_stats_c8 launches)
+M16_FUSE_BN = os.environ.get('IISEG_M16_FUSE_BN', '1') != '0'
+
 GROWTH = 16
 N_POOL = 5
 LAYERS_PER_BLOCK = [4, 5, 7, 10, 12, 15, 12, 10, 7, 5, 4]      # FCDenseNet.py:208
@@ -82,6 +86,25 @@ class _Stack:
         return self.buf if self.n == self.buf.shape[1] else self.buf[:, :self.n].contiguous()
 
 
+class _Peek:
+    """Iterator over the layer entries with a look at the next one."""
+
+    def __init__(self, items):
+        self.items, self.i = items, 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.i >= len(self.items):
+            raise StopIteration
+        self.i += 1
+        return self.items[self.i - 1]
+
+    def peek(self):
+        return self.items[self.i] if self.i < len(self.items) else None
+
+
 class _Stack8:
     """The same stack as bf16 C8 chunks (B, cap / 8, H, W, 8) -- mma='bf16c8': the format the dense-block
     layers read and write (csrc/conv_c8_m16.hip); the statistics (fp32) are those of the stored bf16
@@ -95,6 +118,7 @@ class _Stack8:
         self.a = torch.zeros(cap, dtype=torch.float32, device=device)     # folded BN of the consumer
         self.b = torch.zeros(cap, dtype=torch.float32, device=device)
         self.n = 0
+        self.folded_for = None      # the layer entry (a, b) currently hold the folded BatchNorm of
 
     def added(self, k, stats=True):
         if stats:
@@ -171,14 +195,28 @@ class FCDenseNet:
         """Dense-block layer on the C8 stack: BN + ReLU of the first n channels on the way in, 16 new
         channels into the next slice (models/FCDenseNet.py:88-92)."""
         e = next(it)
-        ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, stack.n, a=stack.a, b=stack.b)
-        e['conv'](stack.buf, in_c=stack.n, bn=(stack.a, stack.b), out=stack.buf, out_c0=stack.n)
-        stack.added(self.growth)
+        if not M16_FUSE_BN:
+            ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, stack.n, a=stack.a, b=stack.b)
+            e['conv'](stack.buf, in_c=stack.n, bn=(stack.a, stack.b), out=stack.buf, out_c0=stack.n)
+            stack.added(self.growth)
+            return
+        # the statistics of the new slice come out of the conv's epilogue; the one-workgroup reduction that finishes
+        # them also folds the NEXT consumer's BatchNorm (a dense-block layer or the TransitionDown of this stack)
+        if stack.folded_for is not e:
+            ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, stack.n, a=stack.a, b=stack.b)
+        nxt = it.peek()
+        fold = None
+        if nxt is not None and nxt['kind'] in ('brc', 'td') and stack.n + self.growth <= stack.a.numel():
+            fold = (nxt['beta'], nxt['gamma'], stack.a, stack.b, stack.n + self.growth)
+        e['conv'](stack.buf, in_c=stack.n, bn=(stack.a, stack.b), out=stack.buf, out_c0=stack.n,
+                  stats=(stack.mean, stack.inv_std, BN_EPS), fold=fold)
+        stack.added(self.growth, stats=False)
+        stack.folded_for = nxt if fold is not None else None
 
     def _forward_c8(self, x):
         B, _, H, W = x.shape
         g, dev = self.growth, self.device
-        it = iter(self.layers)
+        it = _Peek(self.layers)
         hidden = [x] if 'input' in self.layer else []
         ints = [int(h[-1]) for h in self.layer if h != 'input']
         first = self.layers[0]['conv']
@@ -200,7 +238,8 @@ class FCDenseNet:
             if 'conv8' in e:
                 # one kernel on the C8 stack: BN + ReLU on the way in, the 2x2 max-pool in the epilogue, bf16
                 # C8 straight into the next block's stack
-                ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, n, a=stack.a, b=stack.b)
+                if stack.folded_for is not e:
+                    ops.bn_fold(e['beta'], e['gamma'], stack.mean, stack.inv_std, n, a=stack.a, b=stack.b)
                 e['conv8'](stack.buf, n, bn=(stack.a, stack.b), pool=True, out=nxt.buf, out_c0=0)
                 t = None
             else:

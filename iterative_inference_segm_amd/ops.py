@@ -387,7 +387,7 @@ class Conv:
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
                  window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None,
                  mask_in=None, unpool_hw=None, mask_out=None, store_out=True, out_format=None,
-                 in_c=None, bn=None):
+                 in_c=None, bn=None, stats=None, fold=None):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
@@ -408,9 +408,9 @@ class Conv:
         input."""
         if is_c8(x1):
             return self._call_c8(x1, x2, add, add_off, window, out, place, pool_out, mask_in,
-                                 unpool_hw, mask_out, store_out, out_format, out_c0, in_c, bn)
-        if in_c is not None or bn is not None:
-            raise RuntimeError('in_c / bn: C8 input only (layers with at most 16 output channels)')
+                                 unpool_hw, mask_out, store_out, out_format, out_c0, in_c, bn, stats, fold)
+        if in_c is not None or bn is not None or stats is not None or fold is not None:
+            raise RuntimeError('in_c / bn / stats: C8 input only (layers with at most 16 output channels)')
         dt = self.dtype
         unpool = pre is not None or mask_in is not None
         masked = mask_in is not None or mask_out is not None
@@ -712,12 +712,16 @@ class Conv:
         check(self.lib.iiseg_conv_c8_tiling(C.byref(d), 1 if pool else 0, t), 'iiseg_conv_c8_tiling')
         return tuple(t)
 
-    def _call_c8_m16(self, x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn):
+    def _call_c8_m16(self, x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn,
+                     stats=None, fold=None):
         """Layers with at most 16 output channels on bf16 C8 activations (include/iiseg.h,
         iiseg_conv_c8_m16).  in_c: convolve only the first in_c channels of x1 (a dense block's stack);
         out + out_c0: write the 16 channels [out_c0, out_c0 + 16) of the wider C8 tensor `out`;
         bn = (a, b): BatchNorm + ReLU x <- max(a x + b, 0) applied to the input on the way in
-        (`bn_fold`).  Returns `out`."""
+        (`bn_fold`); stats = (mean, inv_std, eps): the batch statistics of the 16 produced channels (bf16 C8
+        output) into entries [out_c0, out_c0 + 16) of the two vectors, out of the conv's epilogue; fold =
+        (beta, gamma, a, b, n) (with stats): the reduction that finishes the statistics also forms the
+        (a, b) pair of the NEXT consumer's BatchNorm over the first n channels.  Returns `out`."""
         lib = self.lib
         unpool = mask_in is not None
         B = x1.shape[0]
@@ -764,8 +768,7 @@ class Conv:
         if not ok or out.shape[0] != B or (place is None and tuple(out.shape[2:4]) != (OH, OW)):
             raise RuntimeError('bad output target %s for a 16-channel C8 layer' % (tuple(out.shape),))
         if bn is not None:
-            a, b = bn
-            if a.dtype != torch.float32 or b.dtype != torch.float32 or a.numel() < C1 or b.numel() < C1:
+            if len(bn) != 2 or any(t.dtype != torch.float32 or t.numel() < C1 for t in bn):
                 raise RuntimeError('bn = (a, b): float32, at least %d entries' % C1)
         if self._W16c8 is None or self._W16c8_cin != C1:
             dp = ConvDesc()
@@ -784,10 +787,22 @@ class Conv:
         # split-K launches (small maps, long channel loops) sum their slices through a scratch buffer
         nws = lib.iiseg_conv_c8_m16_workspace_bytes(C.byref(d))
         ws = _m16_workspace(nws, x1.device) if nws else None
+        if stats is not None and (fmt != 'c8' or stats[0].dtype != torch.float32 or
+                                  stats[1].dtype != torch.float32 or
+                                  min(stats[0].numel(), stats[1].numel()) < (out_c0 or 0) + 16):
+            raise RuntimeError('stats = (mean, inv_std, eps): float32 vectors covering the produced slice, C8 output')
+        if fold is not None and (stats is None or any(t.dtype != torch.float32 or t.numel() < fold[4]
+                                                      for t in fold[:4])):
+            raise RuntimeError('fold = (beta, gamma, a, b, n) needs stats and float32 vectors of n entries')
         check(lib.iiseg_conv_c8_m16_ws(_stream(), C.byref(d), dtp(x1), in_ctot, dtp(mask_in),
                                        None if bn is None else _ptr(bn[0]), None if bn is None else _ptr(bn[1]),
                                        dtp(self._W16c8), _ptr(self.b), dtp(out), 3 if fmt == 'nchw' else 1,
-                                       None if ws is None else C.c_void_p(ws.data_ptr()), int(nws)),
+                                       None if ws is None else C.c_void_p(ws.data_ptr()), int(nws),
+                                       None if stats is None else _ptr(stats[0]),
+                                       None if stats is None else _ptr(stats[1]),
+                                       float(stats[2]) if stats is not None else 0.0,
+                                       *((_ptr(fold[0]), _ptr(fold[1]), _ptr(fold[2]), _ptr(fold[3]), int(fold[4]))
+                                         if fold is not None else (None, None, None, None, 0))),
               'iiseg_conv_c8_m16_ws')
         if prof is not None:
             prof.append(('conv_c8_m16_kernel', self.flops(B, OH, OW), ev0, _ev()))
@@ -798,7 +813,7 @@ class Conv:
         return out
 
     def _call_c8(self, x1, x2, add, add_off, window, out, place, pool_out, mask_in, unpool_hw,
-                 mask_out, store_out, out_format, out_c0=None, in_c=None, bn=None):
+                 mask_out, store_out, out_format, out_c0=None, in_c=None, bn=None, stats=None, fold=None):
         """The layer on bf16 C8 activations (include/iiseg.h, iiseg_conv_c8).  x1 / x2 / pool_out:
         C8 tensors (`is_c8`); add: C8 bf16 or C8 fp32 (float32, same 5-D shape); mask_in / mask_out:
         uint8 (B, C/8, h, w, 8).  out_format: 'c8' (default), 'c8f32', or 'nchw' (fp32 NCHW, the
@@ -809,7 +824,10 @@ class Conv:
             raise RuntimeError("C8 input needs a 3x3 layer built with mma='bf16c8'")
         if C8_M16 and self.Cout <= 16 and not self.x3 and x2 is None and add is None and pool_out is None and \
                 store_out and (out_format or 'c8') in ('c8', 'nchw'):
-            return self._call_c8_m16(x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn)
+            return self._call_c8_m16(x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn,
+                                     stats, fold)
+        if stats is not None or fold is not None:
+            raise RuntimeError('stats: layers with at most 16 output channels')
         if in_c is not None or bn is not None:
             raise RuntimeError('in_c / bn on C8 input: layers with at most 16 output channels')
         unpool = mask_in is not None

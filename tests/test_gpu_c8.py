@@ -617,5 +617,43 @@ def test_conv_c8_m16_split_k(ops, case):
         assert np.array_equal(full[:, :n], stack[:, :n]) and np.array_equal(full[:, n + 16:], stack[:, n + 16:])
     d = ops.ConvDesc()
     d.B, d.C1, d.C2, d.H, d.W, d.Cout, d.KH, d.KW, d.pad, d.dil, d.OH, d.OW = B, n, 0, H, W, 16, 3, 3, 1, 1, H, W
-    split = conv.lib.iiseg_conv_c8_m16_workspace_bytes(C.byref(d)) > 0
-    assert split == ((H, W) in ((7, 7), (14, 14)))       # (one tile per image and >= 8 k-tiles: split launches)
+    # (beyond the per-tile statistics -- 256 bytes a tile -- the scratch holds slabs only for split launches: one
+    # tile per image and >= 8 k-tiles)
+    split = conv.lib.iiseg_conv_c8_m16_workspace_bytes(C.byref(d)) > 256 * B * 4
+    assert split == ((H, W) in ((7, 7), (14, 14)))
+
+
+@pytest.mark.parametrize('shape', [(3, 21, 30), (4, 7, 7)])
+def test_conv_c8_m16_fused_statistics_and_next_fold(ops, shape):
+    """A dense-block layer with the BatchNorm bookkeeping inside its launches: the batch statistics of the 16
+    produced channels out of the conv's epilogue (per-tile sums in double, added in a fixed order), and the (a, b)
+    pair of the NEXT layer's BatchNorm formed by the reduction that finishes them.  Output bit-identical to the
+    plain launch; statistics equal to bn_stats_c8's up to the order of the double sums; the folded pair equal to
+    bn_fold on those statistics.  (7 x 7: a split-K launch -- the statistics come from its second phase.)"""
+    B, H, W = shape
+    rng = np.random.default_rng(B * H)
+    cap, n = 96, 64
+    stack = torch.zeros((B, cap, H, W), device='cuda')
+    stack[:, :n] = torch.from_numpy(rng.standard_normal((B, n, H, W)).astype(np.float32)).cuda()
+    s8 = ops.nchw_to_c8(stack)
+    mean = torch.zeros(cap, device='cuda'); inv = torch.zeros(cap, device='cuda')
+    ops.bn_stats_c8(s8, 0, n, mean, inv, eps=1e-4)
+    gamma = torch.rand(cap, device='cuda') + 0.5; beta = torch.rand(cap, device='cuda') - 0.5
+    g2 = torch.rand(cap, device='cuda') + 0.5; b2 = torch.rand(cap, device='cuda') - 0.5
+    Wt = rng.standard_normal((16, n, 3, 3)).astype(np.float32) / np.sqrt(9 * n)
+    conv = ops.Conv(Wt, rng.standard_normal(16).astype(np.float32), pad=1, relu=False, mma='bf16c8')
+    a, b = ops.bn_fold(beta, gamma, mean, inv, n, cap=cap)
+    ref8 = s8.clone()
+    conv(ref8, in_c=n, bn=(a, b), out=ref8, out_c0=n)
+    m_ref, i_ref = mean.clone(), inv.clone()
+    ops.bn_stats_c8(ref8, n, 16, m_ref, i_ref, eps=1e-4)
+    got8 = s8.clone()
+    m_got, i_got = mean.clone(), inv.clone()
+    a2 = torch.zeros(cap, device='cuda'); bb2 = torch.zeros(cap, device='cuda')
+    conv(got8, in_c=n, bn=(a, b), out=got8, out_c0=n, stats=(m_got, i_got, 1e-4), fold=(b2, g2, a2, bb2, n + 16))
+    assert torch.equal(got8, ref8)
+    assert np.allclose(host(m_got), host(m_ref), rtol=1e-6, atol=1e-7)
+    assert np.allclose(host(i_got), host(i_ref), rtol=1e-6)
+    assert np.array_equal(host(m_got)[:n], host(mean)[:n]) and not host(m_got)[n + 16:].any()
+    fa, fb = ops.bn_fold(b2, g2, m_got, i_got, n + 16, cap=cap)
+    assert torch.equal(fa, a2) and torch.equal(fb, bb2)
