@@ -213,6 +213,7 @@ def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
     if dispatch:
         ops.profile_begin()
     ops.CONV_PROFILE = prof = []
+    ops.KERNEL_BYTES.clear()
     one_step(ii, X, T, num_iter, step_size, graph=False)
     torch.cuda.synchronize()
     ops.CONV_PROFILE = None
@@ -230,6 +231,19 @@ def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
     achieved = flops / (ms * 1e-3) / 1e12
     gb, prov = _traffic(kern)
     whole = all_gflop / ms_per_step          # GFLOP / ms = TFLOP/s
+    if ops.KERNEL_BYTES.get(kern):
+        # a vector-ALU kernel bound by HBM traffic (csrc/conv_small.hip: the context module's 11 -> 11 layers):
+        # algorithmic bytes = every input plane read once + every output plane written once
+        gbs = ops.KERNEL_BYTES[kern] / (ms * 1e-3) / 1e9
+        return {'bound': 'hbm', 'kernel': kern, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                'timing': 'HIP events on each kernel dispatch' if dispatch else 'HIP events on the stream',
+                'launches_per_step': n, 'avg_launch_ms': round(ms / n, 4),
+                'gb_per_launch': round(ops.KERNEL_BYTES[kern] / n / 1e9, 4), 'kernel_ms_per_step': round(ms, 2),
+                'per_kernel_ms_per_step': {k: round(v[1], 2) for k, v in per.items()},
+                'per_kernel_tflops': {k: round(v[0] / v[1] / 1e9, 1) for k, v in per.items() if v[0]},
+                'all_conv_ms_per_step': round(all_ms, 2),
+                'whole_path': {'executed_tflops': round(whole, 2), 'frac': round(whole / peak, 4)}}
     return {'bound': 'mfma', 'kernel': kern, 'achieved': round(achieved, 2), 'peak': peak,
             'timing': 'HIP events on each kernel dispatch (hipExtLaunchKernelGGL start / stop)' if dispatch
                       else 'HIP events recorded on the stream around each launch',
@@ -247,6 +261,7 @@ def conv_roofline(ii, X, T, num_iter, step_size, ms_per_step, peak, mode='f32'):
                                    'count their 4/9) / ms_per_step of the timed run / MFMA peak'}}
 
 
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 GFLOP_C3, GFLOP_C4 = 254.6, 1867.8      # nominal GFLOP per refined image, configs[2] / [3]
 
 
@@ -319,9 +334,12 @@ def other_configs(device, step_size, no_roofline):
         if not no_roofline:
             rl = conv_roofline(ii, Xs[0], Ts[0], steps, step_size, d * 1e3,
                                PEAK_TFLOPS_F32_MFMA if mma is None else PEAK_TFLOPS_BF16_MFMA)
-            ent['roofline'] = {k: rl[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'launches_per_step',
-                                                  'avg_launch_ms', 'kernel_ms_per_step', 'all_conv_ms_per_step',
-                                                  'per_kernel_ms_per_step', 'per_kernel_tflops')}
+            ent['roofline'] = {k: rl[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac',
+                                                  'launches_per_step', 'avg_launch_ms', 'kernel_ms_per_step',
+                                                  'all_conv_ms_per_step', 'per_kernel_ms_per_step',
+                                                  'per_kernel_tflops')}
+            if 'gb_per_launch' in rl:
+                ent['roofline']['gb_per_launch'] = rl['gb_per_launch']
             ent['roofline']['whole_path_frac'] = rl['whole_path']['frac']
         res[key] = ent
         del ii, Xs, Ts

@@ -132,6 +132,10 @@ int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const float* x1, cons
  * pool_out is the FULL pooled tensor (B, Cout, fullH/2, fullW/2); the pooled positions of the
  * computed window are written in place.  Supported (iiseg_conv_pool_supported) for the 3x3 layers
  * the halo kernel takes (16 < Cout < 256) with an even window origin and whole pooling windows. */
+/* 1 when iiseg_conv_f32 runs this (planned, plain: no add / pool / masks) request on the vector-ALU kernel
+ * for layers between at most 16 channels on either side (csrc/conv_small.hip: the context module's 1x1 /
+ * dilated 3x3 layers, models/contextmod_dae.py:74-105) -- a scheduling fact, for profiles. */
+int iiseg_conv_small_supported(const iiseg_conv_desc* d);
 int iiseg_conv_pool_supported(const iiseg_conv_desc* d);
 int iiseg_conv_pool_f32(void* stream, const iiseg_conv_desc* d, const float* x1, const float* x2,
                         const float* pre, const float* pooled, const float* wp, const int32_t* ktab,

@@ -50,6 +50,7 @@ SIGNATURES = {
     'iiseg_conv_plan': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pack_f32': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp, _vp]),
     'iiseg_conv_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
+    'iiseg_conv_small_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pool_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_pool_f32': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 10),
     'iiseg_conv_mask_supported': (C.c_int, [C.POINTER(ConvDesc)]),

@@ -27,6 +27,9 @@ int iiseg_launch_conv_taps(hipStream_t s, const ConvParams& p, int KH, int KW, i
 // conv_halo.hip: halo-tile direct 3x3 kernel
 bool iiseg_conv_halo_ok(const ConvParams& p, int KH, int KW);
 int iiseg_launch_conv_halo(hipStream_t s, const ConvParams& p, int bm, bool unpool);
+// conv_small.hip: layers between at most 16 channels on either side, on the vector ALU
+bool iiseg_conv_small_ok(const ConvParams& p, int KH, int KW);
+int iiseg_launch_conv_small(hipStream_t s, const ConvParams& p, int KH);
 
 namespace {
 
@@ -416,6 +419,15 @@ extern "C" int iiseg_conv_f32(void* stream, const iiseg_conv_desc* d, const floa
     return iiseg_conv_pool_f32(stream, d, x1, x2, pre, pooled, wp, ktab, bias, add, out, nullptr);
 }
 
+extern "C" int iiseg_conv_small_supported(const iiseg_conv_desc* d) {
+    if (!d || check_desc(d) || (d->flags & (IISEG_CONV_UNPOOL | IISEG_CONV_TRANSPOSED2))) return 0;
+    ConvParams p = {};
+    p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
+    p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.Mpad = d->Mpad; p.pad = d->pad;
+    p.out = reinterpret_cast<float*>(16);         // (only tested for presence)
+    return iiseg_conv_small_ok(p, d->KH, d->KW) ? 1 : 0;
+}
+
 extern "C" int iiseg_conv_pool_supported(const iiseg_conv_desc* d) {
     if (!d || check_desc(d)) return 0;
     static const int halo = getenv("IISEG_CONV_HALO") ? atoi(getenv("IISEG_CONV_HALO")) : 1;
@@ -540,6 +552,9 @@ static int conv_run(void* stream, const iiseg_conv_desc* d, const float* x1, con
     if (pool_out && (!use_halo || add || d->Cout <= 16)) return IISEG_ERR_UNSUPPORTED;
     if (bn && !use_halo) return IISEG_ERR_UNSUPPORTED;
     if ((mask_in || mask_out) && !use_halo) return IISEG_ERR_UNSUPPORTED;
+    // tiny layers (context module: 11 -> 11, dilated): HBM-bound, half of an MFMA tile would be padding
+    if (!unpool && !bn && !pool_out && iiseg_conv_small_ok(p, d->KH, d->KW))
+        return iiseg_launch_conv_small(s, p, d->KH);
     if (use_halo) return iiseg_launch_conv_halo(s, p, pick_bm(d->Cout), unpool);
     if (iiseg_taps_cpt(d->KH, d->KW) > 0)
         return iiseg_launch_conv_taps(s, p, d->KH, d->KW, pick_bm(d->Cout), unpool);

@@ -1,0 +1,164 @@
+// 1x1 / (dilated) 3x3 convolution between at most 16 and at most 16 channels in fp32 on the VECTOR ALU: the
+// layers of the context-module DAE (models/contextmod_dae.py:74-105: conv3x3 on [image, y] -> six
+// DilatedConv2DLayer 11 -> 11, dilation 1, 2, 4, 8, 16, 1 -> 1x1; 50 refinement steps in BASELINE configs[4]).
+//
+// Why not the matrix pipe: with 11 channels on either side a 16x16x4 fp32 MFMA tile multiplies 16 rows for 11
+// and 12 k for 11 -- half of the products are padding, the 16-row halo kernel ran these layers at 24-45 TFLOP/s
+// nominal, 2.2-2.6 x their HBM time -- and a dilated layer's patch is 2.5-6 x its tile (three row bands 2 d apart,
+// staged dword by dword).  The layers are bound by HBM traffic (read 11 planes, write 11 planes), not by
+// arithmetic: here a thread owns four consecutive pixels and all output channels in registers, operands come
+// straight from L1 / L2 in coalesced row segments (no LDS patch, no halo amplification whatever the dilation),
+// the weights (Wp[k][Mpad] of iiseg_conv_pack_f32) are scalar loads -- SGPR operands of the FMAs -- and the
+// products are v_pk_fma_f32 pairs of output channels.  Sum order: bias, then channel-major / tap-minor
+// sequential fp32 FMAs.  (Measured on the way: one pixel per thread with the weights broadcast from LDS or as
+// scalars runs at the speed of the halo kernel -- 99 dword loads per pixel keep the texture path busier than the
+// FMAs keep the ALU.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "iiseg.h"
+#include "common.h"
+#include "conv_common.h"
+
+using namespace iiseg;
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+constexpr int RSRC_W3 = 0x00027000;
+constexpr unsigned OOB = 0x80000000u;
+
+// T taps (1 or 9); COP: output channels padded to a multiple of 4 (<= 16).  Tile = 16 rows x 64 columns: thread
+// (row tid / 16, column group tid % 16) owns FOUR consecutive pixels of a row, so a tap of a channel is one
+// 16-byte load for four pixels (a wave: four 256-byte row segments) and every weight pair multiplies four pixels
+// -- the vector memory path is then behind the FMAs, not in front of them.  'valid' layers only (pad 0: every
+// tap of a valid pixel lies inside its row): with zero padding the border groups would have to load element by
+// element, and that form measured slower than the halo kernel (0.26 / 0.30 against 0.20 / 0.26 ms on the two
+// padded layers of the module), which keeps them.
+template <int T, int COP>
+__global__ __launch_bounds__(256) void conv_small_f32_kernel(const ConvParams p, const int tiles_y, const int tiles_x) {
+    constexpr int KW = T == 9 ? 3 : 1;
+    const int tid = threadIdx.x, tx = tid & 15, tyy = tid >> 4;
+    const int tpi = tiles_y * tiles_x;
+    const int b = blockIdx.x / tpi;
+    const int tr = blockIdx.x - b * tpi;
+    const int ty = tr / tiles_x, txx = tr - ty * tiles_x;
+    const int wy = ty * 16 + tyy, wx = txx * 64 + tx * 4;           // window coordinates of the first pixel
+    const int Cin = p.C1, HW = p.H * p.W;
+    const int nv = min(4, p.OW - wx);                               // valid pixels of the group (<= 0: none)
+    const bool any_ok = wy < p.OH && nv > 0;
+    const int ix0 = p.ox0 + wx - p.pad;
+    // per tap row: byte offset of (iy, ix0) inside a channel plane, or OOB when the row is padding / unused
+    unsigned roff[KW];
+#pragma unroll
+    for (int ky = 0; ky < KW; ++ky) {
+        const int iy = p.oy0 + wy - p.pad + ky * p.dil;
+        roff[ky] = (any_ok && (unsigned)iy < (unsigned)p.H) ? 4u * (unsigned)(iy * p.W + ix0) : OOB;
+    }
+    // (a ragged last group reads up to 12 bytes past its pixels -- the next row, or, at the very end of the image,
+    // out of the descriptor's range: raw buffer loads are range-checked dword by dword)
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.x1 + (size_t)b * Cin * HW), 0, Cin * HW * 4, RSRC_W3);
+    f32x2 acc[4][COP / 2];
+#pragma unroll
+    for (int j = 0; j < COP / 2; ++j) {
+        const f32x2 bv = {(p.bias && 2 * j < p.Cout) ? p.bias[2 * j] : 0.f,
+                          (p.bias && 2 * j + 1 < p.Cout) ? p.bias[2 * j + 1] : 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e][j] = bv;
+    }
+    f32x4 xv[2][T];
+    auto load = [&](int c, int s) __attribute__((always_inline)) {
+        const int so = c * HW * 4;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            xv[s][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rx, (int)(roff[t / KW] == OOB ? OOB : roff[t / KW] + 4u * (unsigned)((t % KW) * p.dil)), so, 0));
+    };
+    load(0, 0);
+    for (int c = 0; c < Cin; c += 2) {
+        // two channels per trip: the loads of the next channel are in flight under the FMAs of this one
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int cc = c + h;
+            if (cc >= Cin) break;
+            if (cc + 1 < Cin) load(cc + 1, h ^ 1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                // weight row k = c T + tap of Wp[Kpad][Mpad]: wave-uniform address -> scalar loads, the weights
+                // are SGPR operands of the FMAs
+                const float* wr = p.wp + (size_t)(cc * T + t) * p.Mpad;
+#pragma unroll
+                for (int q = 0; q < COP / 4; ++q) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + q * 4);
+                    const f32x2 wa = {w4[0], w4[1]}, wb = {w4[2], w4[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 xx = {xv[h][t][e], xv[h][t][e]};
+                        acc[e][2 * q] = __builtin_elementwise_fma(xx, wa, acc[e][2 * q]);
+                        acc[e][2 * q + 1] = __builtin_elementwise_fma(xx, wb, acc[e][2 * q + 1]);
+                    }
+                }
+            }
+        }
+    }
+    if (!any_ok) return;
+    const int OPL = p.out_H * p.out_W;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out + (size_t)b * p.out_ctot * OPL), 0, p.out_ctot * OPL * 4, RSRC_W3);
+    const unsigned o0 = 4u * (unsigned)(p.out_c0 * OPL + (p.out_y0 + wy) * p.out_W + p.out_x0 + wx);
+#pragma unroll
+    for (int j = 0; j < COP / 2; ++j)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int co = 2 * j + k;
+            if (co >= p.Cout) continue;
+            float v0 = acc[0][j][k], v1 = acc[1][j][k], v2 = acc[2][j][k], v3 = acc[3][j][k];
+            if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            const unsigned oo = o0 + 4u * (unsigned)(co * OPL);
+            if (nv == 4) {
+                const f32x4 v = {v0, v1, v2, v3};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), ro, (int)oo, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), ro, (int)oo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v1), ro, (int)(nv > 1 ? oo + 4u : OOB), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v2), ro, (int)(nv > 2 ? oo + 8u : OOB), 0, 0);
+            }
+        }
+}
+
+template <int T>
+int launch_small(hipStream_t s, const ConvParams& p) {
+    const int tiles_y = (p.OH + 15) / 16, tiles_x = (p.OW + 63) / 64;
+    const dim3 grid(p.B * tiles_y * tiles_x), block(256);
+    const int cop = (p.Cout + 3) / 4 * 4;
+    switch (cop) {
+        case 4: IISEG_LAUNCH((conv_small_f32_kernel<T, 4>), grid, block, 0, s, p, tiles_y, tiles_x); break;
+        case 8: IISEG_LAUNCH((conv_small_f32_kernel<T, 8>), grid, block, 0, s, p, tiles_y, tiles_x); break;
+        case 12: IISEG_LAUNCH((conv_small_f32_kernel<T, 12>), grid, block, 0, s, p, tiles_y, tiles_x); break;
+        default: IISEG_LAUNCH((conv_small_f32_kernel<T, 16>), grid, block, 0, s, p, tiles_y, tiles_x); break;
+    }
+    return iiseg_check_launch();
+}
+
+}  // namespace
+
+// single-source, plain (no DePool2D input, skip-add, pool, masks, BatchNorm), 'valid' (pad 0) 1x1 / 3x3 request
+// between at most 16 channels on either side, any dilation
+bool iiseg_conv_small_ok(const ConvParams& p, int KH, int KW) {
+    static const int on = getenv("IISEG_CONV_SMALL") ? atoi(getenv("IISEG_CONV_SMALL")) : 1;
+    if (!on || p.transposed || p.pad != 0 || p.C2 != 0 || p.C1 > 16 || p.Cout > 16 || p.add || p.pool || p.mask_in ||
+        p.mask_out || p.bn_mean || !p.out)
+        return false;
+    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3))) return false;
+    if (p.Mpad < 16 || (p.Mpad & 3)) return false;
+    if ((int64_t)p.C1 * p.H * p.W * 4 >= (1ll << 31) - 4) return false;      // per-image 32-bit byte offsets
+    if ((int64_t)p.B * ((p.OH + 3) / 4) * ((p.OW + 63) / 64) >= (1ll << 31)) return false;
+    return true;
+}
+
+int iiseg_launch_conv_small(hipStream_t s, const ConvParams& p, int KH) {
+    return KH == 3 ? launch_small<9>(s, p) : launch_small<1>(s, p);
+}

@@ -19,6 +19,9 @@ CONV_PROFILE = None
 # With CONV_PROFILE: when set to a list, every C8 launch also appends its geometry (one dict per launch,
 # same order as the 'conv_c8_kernel' entries of CONV_PROFILE) -- scripts/c8_step_profile.py
 CONV_PROFILE_INFO = None
+# ... and for kernels that are bound by HBM traffic rather than the matrix pipe: algorithmic bytes (input planes
+# read once + output planes written once) summed per kernel name while CONV_PROFILE is on
+KERNEL_BYTES = {}
 
 _SUFFIX = {torch.float32: 'f32', torch.float64: 'f64'}
 
@@ -612,6 +615,10 @@ class Conv:
             kern = self.kernel
             if dt == torch.float64 and self.lib.iiseg_conv_halo_f64_supported(C.byref(d)):
                 kern = 'conv_halo_f64_kernel'
+            if dt == torch.float32 and add is None and self.lib.iiseg_conv_small_supported(C.byref(d)):
+                kern = 'conv_small_f32_kernel'         # vector ALU, HBM-bound: algorithmic bytes for the roofline
+                KERNEL_BYTES[kern] = KERNEL_BYTES.get(kern, 0.0) + \
+                    4.0 * B * (self.Cin * d.H * d.W + self.Cout * d.OH * d.OW)
             if kern == 'conv_halo_f32_kernel' and C2 > 0 and C1 % 4:
                 kern = 'conv_taps_f32_kernel'      # a k-tile would straddle the two sources
             prof.append((kern, self.flops(B, d.OH, d.OW), ev0, ev1))

@@ -633,3 +633,58 @@ def test_dispatch_timing_of_launches(built_lib):
     assert abs(sum(per_conv) - sum(ops.PROFILE_MS[:5])) < 1e-6
     assert sum(ops.PROFILE_MS) <= e0.elapsed_time(e1) * 1.05
     assert tuple(p.shape) == (4, 64, 30, 30)
+
+
+SMALL_CASES = [  # B, Cin, H, W, Cout, k, pad, dil, relu, window, place
+    (2, 11, 70, 130, 11, 3, 0, 1, True, None, False),      # context module: 'valid' 11 -> 11
+    (1, 11, 90, 100, 11, 3, 0, 16, True, None, False),     # dilation 16
+    (2, 11, 40, 75, 11, 3, 0, 8, True, None, False),
+    (3, 11, 31, 67, 11, 1, 0, 1, False, None, False),      # the 1x1 output layer, ragged last pixel group
+    (1, 16, 20, 66, 16, 3, 0, 2, False, (3, 2, 9, 57), True),    # window + placement, 16 channels
+    (1, 3, 19, 19, 5, 3, 0, 4, True, None, False),         # tiny map
+    (2, 11, 21, 31, 11, 3, 0, 1, True, None, False),       # ragged last pixel group at the end of the buffer
+    (2, 11, 23, 37, 11, 3, 0, 2, False, None, False),
+]
+
+
+@pytest.mark.parametrize('case', SMALL_CASES)
+def test_conv_small_channels_on_the_vector_alu(ops, case):
+    """Layers between at most 16 channels on either side (csrc/conv_small.hip: the context module,
+    models/contextmod_dae.py:74-105) on the vector ALU: equal to the oracle on integer data (every product and
+    partial sum exact in fp32), within the fp32 conv tolerance on random data; window and placement."""
+    import ctypes as C
+    B, Cin, H, W, Cout, k, pad, dil, relu, window, place = case
+    rng = np.random.default_rng(sum(c for c in case[:9]))
+    conv_i = ops.Conv(rng.integers(-2, 3, size=(Cout, Cin, k, k)).astype(np.float32),
+                      rng.integers(-4, 5, size=Cout).astype(np.float32), pad=pad, relu=relu, dil=dil)
+    d, _, _ = conv_i._plan(B, Cin, 0, H, W, window, None, False)
+    assert conv_i.lib.iiseg_conv_small_supported(C.byref(d)) == 1
+    d1 = type(d).from_buffer_copy(d)
+    d1.pad = 1                              # (zero-padded layers stay on the halo kernel)
+    assert conv_i.lib.iiseg_conv_small_supported(C.byref(d1)) == 0
+    xi = rng.integers(-3, 4, size=(B, Cin, H, W)).astype(np.float32)
+    ref = onn.conv2d(xi.astype(np.float64), host(conv_i.W).astype(np.float64), host(conv_i.b).astype(np.float64),
+                     pad=pad, dilation=dil, relu=relu)
+    kw = {}
+    if window is not None:
+        y0, x0, oh, ow = window
+        ref = ref[:, :, y0:y0 + oh, x0:x0 + ow]
+        kw['window'] = window
+    if place:
+        big = torch.full((B, Cout, ref.shape[2] + 3, ref.shape[3] + 2), 7.0, device='cuda')
+        conv_i(dev(xi), out=big, place=(2, 1), **kw)
+        hb = host(big)
+        assert np.array_equal(hb[:, :, 2:2 + ref.shape[2], 1:1 + ref.shape[3]], ref.astype(np.float32))
+        hb[:, :, 2:2 + ref.shape[2], 1:1 + ref.shape[3]] = 7.0
+        assert np.all(hb == 7.0)
+    else:
+        got = host(conv_i(dev(xi), **kw))
+        assert got.shape == ref.shape and np.array_equal(got, ref.astype(np.float32))
+    # random data: fp32 sequential FMAs against float64
+    x, Wt, b = rnd(rng, B, Cin, H, W), rnd(rng, Cout, Cin, k, k) / np.sqrt(Cin * k * k), rnd(rng, Cout)
+    ref = onn.conv2d(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), pad=pad, dilation=dil,
+                     relu=relu)
+    if window is not None:
+        ref = ref[:, :, y0:y0 + oh, x0:x0 + ow]
+    got = host(ops.Conv(Wt, b, pad=pad, relu=relu, dil=dil)(dev(x), **kw))
+    assert np.abs(got - ref).max() <= conv_tol(ref, Cin * k * k)
