@@ -34,6 +34,14 @@ class ContextModDAE:
         W, b = params['dilconv7']
         self.last = ops.Conv(W, b, pad=0, relu=False, layout='iohw', device=device,
                              dtype=dtype)                                # :102-105
+        # the same two padded layers as 'valid' convolutions of zero-bordered buffers (a refinement loop keeps
+        # those buffers, `new_session`): zero padding = a border that is written once and never again, and a
+        # 'valid' layer between <= 16 channels runs on the vector-ALU kernel (csrc/conv_small.hip)
+        self.conv1_valid = ops.Conv(params['conv1'][0], params['conv1'][1], pad=0, relu=True,
+                                    device=device, dtype=dtype)
+        W, b = params['dilconv1']
+        self.dil1_valid = ops.Conv(W, b, pad=0, relu=True, dil=DILATIONS[0], layout='iohw', device=device,
+                                   dtype=dtype)
 
     def conv_layers(self):
         d = {'conv1': self.conv1, 'dilconv7': self.last}
@@ -43,24 +51,29 @@ class ContextModDAE:
     def new_session(self, h_list=None, y=None, tags=None):
         """State of one refinement loop (h fixed, y evolving): the ConcatLayer((h, y)) buffer of
         contextmod_dae.py:55-59 with h copied in once; each step only refreshes the y channels
-        (plain device copies), so conv1 runs single-source on the 16-channel halo kernel."""
+        (plain device copies), so conv1 runs single-source."""
         if not h_list or y is None or len(h_list) != 1:
             return None
         h = h_list[0]
-        cat = torch.empty((y.shape[0], h.shape[1] + y.shape[1], y.shape[2], y.shape[3]),
-                          dtype=y.dtype, device=y.device)
-        cat[:, :h.shape[1]].copy_(h)
-        return {'cat': cat, 'ch': h.shape[1]}
+        B, ch, H, W = h.shape[0], h.shape[1], y.shape[2], y.shape[3]
+        # [h, y] with the one-pixel zero border of conv1's pad, and conv1's output inside PadLayer(32)'s zeros
+        cat = torch.zeros((B, ch + y.shape[1], H + 2, W + 2), dtype=y.dtype, device=y.device)
+        cat[:, :ch, 1:-1, 1:-1].copy_(h)
+        pad32 = torch.zeros((B, self.conv1.Cout, H + 64, W + 64), dtype=y.dtype, device=y.device)
+        return {'cat': cat, 'ch': ch, 'pad32': pad32}
 
     def scores(self, h_list, y, mask_override=None, session=None):
         if len(h_list) != 1:
             raise ValueError('expected 1 h tensor, got %d' % len(h_list))
         if session is not None:
-            session['cat'][:, session['ch']:].copy_(y)
-            t = self.conv1(session['cat'])
+            session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
+            self.conv1_valid(session['cat'], out=session['pad32'], place=(32, 32))
+            t = self.dil1_valid(session['pad32'])
+            rest = self.dil[1:]
         else:
             t = self.conv1(h_list[0], x2=y)                          # h first (P13)
-        for conv in self.dil:
+            rest = self.dil
+        for conv in rest:
             t = conv(t)
         return self.last(t)
 
