@@ -604,6 +604,24 @@ int iiseg_conv_pack_f64(void* stream, const iiseg_conv_desc* d, const double* w,
 int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const double* x1, const double* x2,
                    const double* pre, const double* pooled, const double* wp, const double* bias,
                    const double* add, double* out);
+/* iiseg_conv_f64 with the 2x2 max-pool (Pool2DLayer(x, 2), ignore_border) of the result fused into the epilogue
+ * of the halo-tile kernel: pool_out = the FULL pooled tensor (B, Cout, fullH / 2, fullW / 2), written where the
+ * computed window has whole pooling windows (as iiseg_conv_pool_f32; out is still stored: DePool2D compares the
+ * float64 pre-pool map). */
+int iiseg_conv_pool_f64_supported(const iiseg_conv_desc* d);
+int iiseg_conv_pool_f64(void* stream, const iiseg_conv_desc* d, const double* x1, const double* x2,
+                        const double* pre, const double* pooled, const double* wp, const double* bias,
+                        const double* add, double* out, double* pool_out);
+/* ... and with the DePool2D masks as bytes (iiseg_conv_mask_f32's convention: bit (y & 1) * 2 + (x & 1) of the
+ * window's byte = pre == pooled, here compared in FLOAT64 by the encoder layer's epilogue, so the decisions are
+ * those of the pre / pooled form): mask_out (uint8, pool_out's shape) is written next to the pool and `out`
+ * may then be NULL -- the float64 pre-pool map is never stored; mask_in (uint8, x1's shape) replaces pre /
+ * pooled in the DePool2D staging of the decoder layer. */
+int iiseg_conv_mask_f64_supported(const iiseg_conv_desc* d);
+int iiseg_conv_mask_f64(void* stream, const iiseg_conv_desc* d, const double* x1, const double* x2,
+                        const double* pre, const double* pooled, const uint8_t* mask_in, const double* wp,
+                        const double* bias, const double* add, double* out, double* pool_out,
+                        uint8_t* mask_out);
 /* 1 when iiseg_conv_f64 runs this (planned) request on the halo-tile kernel (conv_halo_f64.hip: plain
  * 3x3 layers, patch staged once per 4 input channels, 16-row MFMA tiles for Cout <= 16) instead of the
  * static-tap kernel; same packed weights, bit-identical results -- a scheduling fact, for profiles. */

@@ -147,6 +147,10 @@ SIGNATURES = {
     'iiseg_conv_pack_f64': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i64, _i64, _vp]),
     'iiseg_conv_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 8),
     'iiseg_conv_halo_f64_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_pool_f64_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_pool_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 9),
+    'iiseg_conv_mask_f64_supported': (C.c_int, [C.POINTER(ConvDesc)]),
+    'iiseg_conv_mask_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 11),
     'iiseg_conv_gemm_f64_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_f64_workspace_elems': (_i64, [C.POINTER(ConvDesc)]),
     'iiseg_conv_gemm_f64': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 5),

@@ -355,22 +355,64 @@ extern "C" int iiseg_conv_pack_f64(void* stream, const iiseg_conv_desc* d, const
     return iiseg_check_launch();
 }
 
+// 1 when iiseg_conv_pool_f64 can fuse the 2x2 max-pool into this (planned) request: a halo-kernel layer with
+// more than 16 output channels, whole pooling windows (even origin; an odd extent only where the window ends
+// at the map's last, unpaired row / column), no skip-add
+extern "C" int iiseg_conv_pool_f64_supported(const iiseg_conv_desc* d) {
+    if (check64(d) != IISEG_OK) return 0;
+    if (d->Cout <= 16 || !iiseg_conv_halo_f64_ok(params64(d), d->KH, d->KW)) return 0;
+    const int fullH = d->H + 2 * d->pad - 2, fullW = d->W + 2 * d->pad - 2;
+    if ((d->oy0 | d->ox0) & 1) return 0;
+    if ((d->OH & 1) && d->oy0 + d->OH != fullH) return 0;
+    if ((d->OW & 1) && d->ox0 + d->OW != fullW) return 0;
+    return 1;
+}
+
 extern "C" int iiseg_conv_f64(void* stream, const iiseg_conv_desc* d, const double* x1,
                               const double* x2, const double* pre, const double* pooled,
                               const double* wp, const double* bias, const double* add, double* out) {
+    return iiseg_conv_pool_f64(stream, d, x1, x2, pre, pooled, wp, bias, add, out, nullptr);
+}
+
+extern "C" int iiseg_conv_pool_f64(void* stream, const iiseg_conv_desc* d, const double* x1,
+                                   const double* x2, const double* pre, const double* pooled,
+                                   const double* wp, const double* bias, const double* add, double* out,
+                                   double* pool_out) {
+    return iiseg_conv_mask_f64(stream, d, x1, x2, pre, pooled, nullptr, wp, bias, add, out, pool_out, nullptr);
+}
+
+// DePool2D masks as bytes on the halo-tile kernel: any plain 3x3 request it runs
+extern "C" int iiseg_conv_mask_f64_supported(const iiseg_conv_desc* d) {
+    if (check64(d) != IISEG_OK) return 0;
+    return iiseg_conv_halo_f64_ok(params64(d), d->KH, d->KW) ? 1 : 0;
+}
+
+extern "C" int iiseg_conv_mask_f64(void* stream, const iiseg_conv_desc* d, const double* x1,
+                                   const double* x2, const double* pre, const double* pooled,
+                                   const uint8_t* mask_in, const double* wp, const double* bias,
+                                   const double* add, double* out, double* pool_out, uint8_t* mask_out) {
     int st = check64(d);
     if (st) return st;
-    if (!x1 || !wp || !out) return IISEG_ERR_NULL;
+    if (!x1 || !wp) return IISEG_ERR_NULL;
+    if (!out && !(pool_out && mask_out)) return IISEG_ERR_NULL;     // the pre-pool map may be skipped
     if (d->C2 > 0 && !x2) return IISEG_ERR_NULL;
     if ((uintptr_t)wp & 15) return IISEG_ERR_ALIGN;
     const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
-    if (unpool && (!pre || !pooled)) return IISEG_ERR_NULL;
+    if ((mask_in || mask_out) && !iiseg_conv_mask_f64_supported(d)) return IISEG_ERR_UNSUPPORTED;
+    if (mask_out && !pool_out) return IISEG_ERR_UNSUPPORTED;
+    if (mask_in && !unpool) return IISEG_ERR_UNSUPPORTED;
+    if (unpool && !mask_in && (!pre || !pooled)) return IISEG_ERR_NULL;
     if (unpool && d->C2 != 0) return IISEG_ERR_UNSUPPORTED;
     if (add && (d->AH < d->ay0 + d->OH || d->AW < d->ax0 + d->OW || d->ay0 < 0 || d->ax0 < 0))
         return IISEG_ERR_SHAPE;
+    if (pool_out && (add || !iiseg_conv_pool_f64_supported(d))) return IISEG_ERR_UNSUPPORTED;
     ConvParams64 p = params64(d);
     p.x1 = x1; p.x2 = x2; p.pre = pre; p.pooled = pooled; p.wp = wp; p.bias = bias; p.add = add;
     p.out = out;
+    p.pool = pool_out;
+    p.mask_in = mask_in; p.mask_out = mask_out;
+    p.pool_H = (d->H + 2 * d->pad - d->dil * (d->KH - 1)) / 2;
+    p.pool_W = (d->W + 2 * d->pad - d->dil * (d->KW - 1)) / 2;
     hipStream_t s = (hipStream_t)stream;
     // plain 3x3 layers: the halo-tile kernel (conv_halo_f64.hip), bit-identical to the static-tap one
     if (iiseg_conv_halo_f64_ok(p, d->KH, d->KW)) return iiseg_launch_conv_halo_f64(s, p, unpool);

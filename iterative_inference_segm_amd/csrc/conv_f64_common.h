@@ -27,6 +27,14 @@ struct ConvParams64 {
     int out_ctot, out_c0;
     int transposed;
     int out_H, out_W, out_y0, out_x0;
+    // fused 2x2 max-pool of the output (conv_halo_f64 only, Cout > 16): full (fullH / 2, fullW / 2) planes
+    double* pool;
+    int pool_H, pool_W;
+    // DePool2D masks as BYTES (as ConvParams::mask_in / mask_out of the fp32 kernels): mask[b][c][y/2][x/2] bit
+    // (y&1)*2 + (x&1) = (pre[y][x] == pooled[y/2][x/2]).  mask_out: written next to `pool` (then `out` may be NULL);
+    // mask_in: the DePool2D staging reads it instead of pre / pooled (x1 = up as before)
+    const unsigned char* mask_in;
+    unsigned char* mask_out;
 };
 
 // conv_halo_f64.hip: true when the halo-tile kernel can run this (already validated) request

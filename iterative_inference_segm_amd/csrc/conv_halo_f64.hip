@@ -53,7 +53,10 @@ __device__ __forceinline__ void dma4(i32x4s rsrc, unsigned lds, unsigned voff, u
                  : "memory");
 }
 
-template <int BM, int TH, bool UNPOOL>
+// MASKIN (with UNPOOL): the DePool2D mask comes as bytes (ConvParams64::mask_in, written by the pool-fused
+// encoder layer of the level: bit (y & 1) * 2 + (x & 1) of the window's byte = pre == pooled, compared in
+// float64 THERE) -- `up` + one byte per window instead of `up`, `pooled` and four `pre` values.
+template <int BM, int TH, bool UNPOOL, bool MASKIN = false>
 __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(const ConvParams64 p,
                                                                              const int tiles_y,
                                                                              const int tiles_x) {
@@ -140,10 +143,11 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
     }
 
     // one image per tile: descriptors start at image b of each source
-    const double* base1 = UNPOOL ? p.pre + (size_t)b * C1 * HW : p.x1 + (size_t)b * C1 * HW;
+    const double* base1 = UNPOOL ? (MASKIN ? p.x1 : p.pre + (size_t)b * C1 * HW) : p.x1 + (size_t)b * C1 * HW;
+    const unsigned char* basem = MASKIN ? p.mask_in + (size_t)b * C1 * hw2 : nullptr;
     const double* base2 = p.C2 > 0 ? p.x2 + (size_t)b * p.C2 * HW : base1;
     const unsigned n1 = (unsigned)(C1 * HW) * 8u, n2 = p.C2 > 0 ? (unsigned)(p.C2 * HW) * 8u : n1;
-    const double* baseq = UNPOOL ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
+    const double* baseq = (UNPOOL && !MASKIN) ? p.pooled + (size_t)b * C1 * hw2 : nullptr;
     const double* baseu = UNPOOL ? p.x1 + (size_t)b * C1 * hw2 : nullptr;
     const int nq = C1 * hw2 * 8;
     const i32x4s s_x1 = mk_srsrc(base1, n1), s_x2 = mk_srsrc(base2, n2);
@@ -151,7 +155,8 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds_addr(&Ws[0][0]) + (unsigned)wave * 1024u);
     const unsigned lds_p = __builtin_amdgcn_readfirstlane(lds_addr(&Ps[0][0]) + (unsigned)wave * 256u);
 
-    double xq[UNPOOL ? NQ : 1], xu[UNPOOL ? NQ : 1], xp[UNPOOL ? NQ : 1][4];
+    double xq[(UNPOOL && !MASKIN) ? NQ : 1], xu[UNPOOL ? NQ : 1], xp[(UNPOOL && !MASKIN) ? NQ : 1][4];
+    unsigned xm[MASKIN ? NQ : 1];
 
 #define H64_STAGE_W(KT, BUF)                                                                       \
     {                                                                                              \
@@ -169,10 +174,16 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
                 constexpr int i = decltype(I)::value;                                              \
                 const bool cok = qc[i] < crem;                                                     \
                 const unsigned vo2 = cok ? qv[i] : OOB;                                            \
-                xq[i] = ld64(baseq, nq, vo2, (unsigned)(c0 * hw2) * 8u);                           \
                 xu[i] = ld64(baseu, nq, vo2, (unsigned)(c0 * hw2) * 8u);                           \
-                _Pragma("unroll") for (int sl = 0; sl < 4; ++sl)                                   \
-                    xp[i][sl] = ld64(base1, (int)n1, cok ? pv[i][sl] : OOB, (unsigned)(c0 * HW) * 8u); \
+                if constexpr (MASKIN) {                                                            \
+                    xm[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(                         \
+                        __builtin_amdgcn_make_buffer_rsrc((void*)basem, 0, nq >> 3, RSRC_W3),      \
+                        (int)(vo2 == OOB ? OOB : vo2 >> 3), (int)(c0 * hw2), 0);                   \
+                } else {                                                                           \
+                    xq[i] = ld64(baseq, nq, vo2, (unsigned)(c0 * hw2) * 8u);                       \
+                    _Pragma("unroll") for (int sl = 0; sl < 4; ++sl)                               \
+                        xp[i][sl] = ld64(base1, (int)n1, cok ? pv[i][sl] : OOB, (unsigned)(c0 * HW) * 8u); \
+                }                                                                                  \
             });                                                                                    \
         } else {                                                                                   \
             const bool s1 = c0 < C1;                                                               \
@@ -191,7 +202,10 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
         static_for<0, NQ>([&](auto I) __attribute__((always_inline)) {                             \
             constexpr int i = decltype(I)::value;                                                  \
             _Pragma("unroll") for (int sl = 0; sl < 4; ++sl)                                       \
-                if (qs[i][sl] >= 0) Ps[BUF][qs[i][sl]] = (xp[i][sl] == xq[i]) ? xu[i] : 0.0;       \
+                if (qs[i][sl] >= 0) {                                                              \
+                    if constexpr (MASKIN) Ps[BUF][qs[i][sl]] = ((xm[i] >> sl) & 1u) ? xu[i] : 0.0; \
+                    else Ps[BUF][qs[i][sl]] = (xp[i][sl] == xq[i]) ? xu[i] : 0.0;                  \
+                }                                                                                  \
         });                                                                                        \
     }
 
@@ -258,13 +272,19 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
 #undef H64_STORE_X
 
     // epilogue.  f64 16x16x4 C/D layout: column = lane & 15 (pixel), row = (lane >> 4) + 4 r
-    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW, PPL = (size_t)p.pool_H * p.pool_W;
+    // Fused 2x2 max-pool (Pool2DLayer(x, 2), ignore_border): window origin, tile origin and a wave's RW = 2 rows
+    // are even, so column tiles j, j + 2 of a lane are the two rows and lane ^ 1 the other column of one window;
+    // the pooled value is the max of the four STORED values.  A trailing unpaired row / column has no window.
+    const bool pooling = BM == 64 && RW == 2 && p.pool != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int wy = wy0 + wave * RW + (j >> 1), wx = wx0 + (j & 1) * 16 + n;
-        if (wy >= p.OH || wx >= p.OW) continue;
-        double* outp = p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
-                       (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx;
+        const bool ok = wy < p.OH && wx < p.OW;
+        // (out may be NULL with the pool + mask bytes: nothing reads the pre-pool map then)
+        double* outp = p.out ? p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
+                                   (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx
+                             : nullptr;
         const double* addp = p.add ? p.add + (size_t)b * p.Cout * APL + (size_t)(p.ay0 + wy) * p.AW +
                                          p.ax0 + wx
                                    : nullptr;
@@ -273,14 +293,39 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m0 + i * 16 + kq + 4 * r;
-                if (co < p.Cout) {
-                    double v = acc[i][j][r];
+                double v = acc[i][j][r];
+                if (ok && co < p.Cout) {
                     if (p.bias) v += p.bias[co];
                     if (addp) v += addp[(size_t)co * APL];
                     if (p.relu) v = fmax(v, 0.0);
-                    outp[(size_t)co * OPL] = v;
+                    if (outp) outp[(size_t)co * OPL] = v;
                 }
+                acc[i][j][r] = v;
             }
+    }
+    if (pooling) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {                           // column half of the tile row pair
+            const int wy = wy0 + wave * RW, wx = wx0 + jj * 16 + n;
+            const int py = (p.oy0 + wy) >> 1, px = (p.ox0 + wx) >> 1;
+            const bool ok = !(n & 1) && wy + 1 < p.OH && wx + 1 < p.OW && py < p.pool_H && px < p.pool_W;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = m0 + i * 16 + kq + 4 * r;
+                    const double m0_ = fmax(acc[i][jj][r], acc[i][jj + 2][r]);
+                    const double m = fmax(m0_, __shfl_xor(m0_, 1, 64));
+                    // bit (row & 1) * 2 + (col & 1): pre == pooled -- this lane's column, then lane ^ 1's
+                    const unsigned mine = (acc[i][jj][r] == m ? 1u : 0u) | (acc[i][jj + 2][r] == m ? 4u : 0u);
+                    const unsigned bits = mine | ((unsigned)__shfl_xor((int)mine, 1, 64) << 1);
+                    if (ok && co < p.Cout) {
+                        const size_t po = ((size_t)b * p.Cout + co) * PPL + (size_t)py * p.pool_W + px;
+                        p.pool[po] = m;
+                        if (p.mask_out) p.mask_out[po] = (unsigned char)bits;
+                    }
+                }
+        }
     }
 }
 
@@ -291,7 +336,9 @@ int launch_h64(hipStream_t s, const ConvParams64& cp, bool unpool) {
     p.n_ptiles = p.B * tiles_y * tiles_x;
     p.n_mtiles = BM == 16 ? (p.Cout + 15) / 16 : p.Mpad / 64;
     const dim3 grid(p.n_ptiles * p.n_mtiles), block(256);
-    if (unpool)
+    if (unpool && p.mask_in)
+        IISEG_LAUNCH((conv_halo_f64_kernel<BM, TH, true, true>), grid, block, 0, s, p, tiles_y, tiles_x);
+    else if (unpool)
         IISEG_LAUNCH((conv_halo_f64_kernel<BM, TH, true>), grid, block, 0, s, p, tiles_y, tiles_x);
     else
         IISEG_LAUNCH((conv_halo_f64_kernel<BM, TH, false>), grid, block, 0, s, p, tiles_y, tiles_x);
@@ -313,6 +360,7 @@ bool iiseg::iiseg_conv_halo_f64_ok(const ConvParams64& p, int KH, int KW) {
 }
 
 int iiseg::iiseg_launch_conv_halo_f64(hipStream_t s, const ConvParams64& p, bool unpool) {
+    if (p.pool && p.Cout <= 16) return IISEG_ERR_UNSUPPORTED;
     static const int th16 = getenv("IISEG_F64_HALO16_TH") ? atoi(getenv("IISEG_F64_HALO16_TH")) : 8;
     if (p.Cout <= 16) return th16 == 16 ? launch_h64<16, 16>(s, p, unpool) : launch_h64<16, 8>(s, p, unpool);
     return launch_h64<64, 8>(s, p, unpool);

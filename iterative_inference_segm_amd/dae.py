@@ -171,7 +171,7 @@ class StandardDAE:
     def _mask_levels(self, overridden):
         """Levels (1-based) whose DePool2D mask travels as bytes in this call."""
         if not self.use_masks or overridden or self.keep_pre or self.bn or self.trace is not None or \
-                self.unpool_type == 'standard' or self.dtype != torch.float32 or \
+                self.unpool_type == 'standard' or self.dtype not in (torch.float32, torch.float64) or \
                 self.fuse_unpool is False:
             return frozenset()
         levels = set()

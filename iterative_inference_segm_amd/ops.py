@@ -42,6 +42,10 @@ WINO_MIN_COUT = int(os.environ.get('IISEG_WINO_MIN_COUT', '128'))
 WINO_FUSED_MAX_CIN = int(os.environ.get('IISEG_WINO_FUSED_MAX_CIN', '256'))
 # fuse the 2x2 max-pool behind a halo-kernel conv into that conv's epilogue
 POOL_FUSE = os.environ.get('IISEG_POOL_FUSE', '1') != '0'
+# float64 path: the same in the halo-tile float64 kernel's epilogue (conv_halo_f64.hip)
+F64_POOL_FUSE = os.environ.get('IISEG_F64_POOL_FUSE', '1') != '0'
+# ... and DePool2D masks as bytes between its encoder / decoder layers (the float64 pre-pool map is never stored)
+F64_MASKS = os.environ.get('IISEG_F64_MASKS', '1') != '0'
 # BN_ReLU_Conv of FC-DenseNet's dense blocks as one kernel.  Off by default: measured 6 % SLOWER
 # end to end on config 3 (361 vs 383 images/s) -- the per-element parameter loads in the conv's
 # staging cost more than the separate HBM-bound normalisation pass saves.
@@ -521,6 +525,19 @@ class Conv:
                 self.lib.iiseg_conv_wino_supported(C.byref(d)) and \
                 self._form_by_full_map(self.lib.iiseg_conv_wino_supported, d):
             return self._call_wino(d, x1, x2, pre, pooled, add, out, prof)
+        if masked and dt == torch.float64:
+            if pool_out is not None:
+                fh, fw = self.out_hw(H, W)
+                if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2) or pool_out.dtype != dt:
+                    raise RuntimeError('pool_out shape %s' % (tuple(pool_out.shape),))
+            ev0 = _ev() if prof is not None else None
+            check(self.lib.iiseg_conv_mask_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(pre, dt),
+                                               _ptr(pooled, dt), _ptr(mask_in, torch.uint8), _ptr(wp, dt),
+                                               _ptr(self.b, dt), _ptr(add, dt), _ptr(out, dt), _ptr(pool_out, dt),
+                                               _ptr(mask_out, torch.uint8)), 'iiseg_conv_mask_f64')
+            if prof is not None:
+                prof.append(('conv_halo_f64_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
+            return out
         if masked:
             if pool_out is not None:
                 fh, fw = self.out_hw(H, W)
@@ -534,6 +551,18 @@ class Conv:
                                                _ptr(mask_out, torch.uint8)), 'iiseg_conv_mask_f32')
             if prof is not None:
                 prof.append((self.kernel, self.flops(B, d.OH, d.OW), ev0, _ev()))
+            return out
+        if pool_out is not None and dt == torch.float64:
+            fh, fw = self.out_hw(H, W)
+            if tuple(pool_out.shape) != (B, self.Cout, fh // 2, fw // 2) or pool_out.dtype != dt or \
+                    not self.lib.iiseg_conv_pool_f64_supported(C.byref(d)) or add is not None:
+                raise RuntimeError('conv + pool fusion is not available for this launch')
+            ev0 = _ev() if prof is not None else None
+            check(self.lib.iiseg_conv_pool_f64(_stream(), C.byref(d), _ptr(x1, dt), _ptr(x2, dt), _ptr(pre, dt),
+                                               _ptr(pooled, dt), _ptr(wp, dt), _ptr(self.b, dt), None,
+                                               _ptr(out, dt), _ptr(pool_out, dt)), 'iiseg_conv_pool_f64')
+            if prof is not None:
+                prof.append(('conv_halo_f64_kernel', self.flops(B, d.OH, d.OW), ev0, _ev()))
             return out
         if pool_out is not None:
             fh, fw = self.out_hw(H, W)
@@ -676,7 +705,13 @@ class Conv:
         whether the call will hand it a C8 tensor (None: the form the layer was built for) -- a
         layer built with mma='bf16c8' and called on fp32 NCHW input runs the 'bf16' forms, and
         those decide."""
-        if not POOL_FUSE or self.dtype != torch.float32:
+        if not POOL_FUSE:
+            return False
+        if self.dtype == torch.float64:
+            # float64: the halo-tile kernel's epilogue (conv_halo_f64.hip), layers it runs with > 16 output channels
+            return F64_POOL_FUSE and (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed and \
+                not self.wino_f64 and self.Cout > 16
+        if self.dtype != torch.float32:
             return False
         if self.c8 and c8 is not False:
             return True
@@ -690,6 +725,10 @@ class Conv:
         `pool_fusable`."""
         if self.c8 and c8 is not False:
             return True
+        if self.dtype == torch.float64:
+            # float64: layers of the halo-tile kernel (the mask bytes hold float64 comparisons)
+            return F64_MASKS and (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed and \
+                not self.wino_f64
         if self.dtype != torch.float32 or (self.KH, self.KW) != (3, 3) or self.dil != 1 or \
                 self.transposed or self.kernel != 'conv_halo_f32_kernel' or self.wino_bf16:
             return False

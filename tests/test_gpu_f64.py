@@ -152,6 +152,102 @@ def test_conv_gemm_f64_exact_on_integers(ops, case):
     assert np.array_equal(got, onn.conv2d(x, Wt, b, pad=0, relu=True))
 
 
+@pytest.mark.parametrize('case', [(2, 12, 19, 37, 40, 1, None), (1, 64, 30, 70, 128, 1, (2, 4, 20, 58)),
+                                  (2, 11, 13, 33, 64, 5, None)])
+def test_conv_halo_f64_fused_pool(ops, case):
+    """The 2x2 max-pool (ignore_border) in the float64 halo kernel's epilogue: the pooled tensor EQUALS the pool of
+    the stored pre-pool map (which is still written: DePool2D compares it), on whole windows of the launch window;
+    everything outside stays untouched."""
+    B, Cin, H, W, Cout, pad, window = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x, Wt, b = rng.standard_normal((B, Cin, H, W)), rng.standard_normal((Cout, Cin, 3, 3)), rng.standard_normal(Cout)
+    conv = ops.Conv(Wt, b, pad=pad, relu=True, dtype=F64)
+    assert conv.pool_fusable()
+    fh, fw = conv.out_hw(H, W)
+    pool = torch.full((B, Cout, fh // 2, fw // 2), -7.0, dtype=F64, device='cuda')
+    kw = {}
+    if window is not None:
+        kw['window'] = conv.pool_window(H, W, window)
+        assert kw['window'] is not None
+    out = host(conv(dev(x), pool_out=pool, **kw))
+    ref = onn.conv2d(x, Wt, b, pad=pad, relu=True)
+    got_pool = host(pool)
+    if window is None:
+        assert np.abs(out - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
+        assert np.array_equal(got_pool, onn.maxpool2(out))
+    else:
+        y0, x0, oh, ow = kw['window']
+        assert np.abs(out - ref[:, :, y0:y0 + oh, x0:x0 + ow]).max() <= 1e-12 * (1 + np.abs(ref).max())
+        want = np.full_like(got_pool, -7.0)
+        pw = onn.maxpool2(out)
+        want[:, :, y0 // 2:y0 // 2 + pw.shape[2], x0 // 2:x0 // 2 + pw.shape[3]] = pw
+        assert np.array_equal(got_pool, want)
+
+
+def _eq_bits(pre, pooled):
+    """bit (y & 1) * 2 + (x & 1) of the window's byte: pre == pooled (include/iiseg.h iiseg_conv_mask_f32)."""
+    B, C, H, W = pre.shape
+    h2, w2 = pooled.shape[2:]
+    m = np.zeros(pooled.shape, np.uint8)
+    for dy in range(2):
+        for dx in range(2):
+            m |= ((pre[:, :, dy:2 * h2:2, dx:2 * w2:2] == pooled).astype(np.uint8) << (dy * 2 + dx))
+    return m
+
+
+@pytest.mark.parametrize('case', [(2, 12, 21, 37, 40, 1), (1, 64, 30, 66, 128, 1)])
+def test_conv_halo_f64_mask_bytes_encoder(ops, case):
+    """float64 encoder side of the byte-mask DePool2D: conv + pool + mask_out with the pre-pool map NOT stored
+    gives the pool of the stored-map launch and exactly the bytes of pre == pooled (float64 comparisons), also on
+    a window."""
+    B, Cin, H, W, Cout, pad = case
+    rng = np.random.default_rng(sum(case))
+    x, Wt, b = rng.standard_normal((B, Cin, H, W)), rng.standard_normal((Cout, Cin, 3, 3)), rng.standard_normal(Cout)
+    conv = ops.Conv(Wt, b, pad=pad, relu=True, dtype=F64)
+    assert conv.pool_fusable() and conv.mask_ok()
+    fh, fw = conv.out_hw(H, W)
+    pooled = torch.empty((B, Cout, fh // 2, fw // 2), dtype=F64, device='cuda')
+    full = conv(dev(x), pool_out=pooled)
+    ref_mask = _eq_bits(host(full), host(pooled))
+    assert int((ref_mask == 15).sum()) > 0                     # ReLU zeros: windows with every bit set
+    pool2 = torch.full_like(pooled, -3.0)
+    mask = torch.full(pooled.shape, 0xAA, dtype=torch.uint8, device='cuda')
+    assert conv(dev(x), pool_out=pool2, mask_out=mask, store_out=False) is None
+    assert np.array_equal(host(pool2), host(pooled)) and np.array_equal(mask.cpu().numpy(), ref_mask)
+    y0, x0, h, ww = win = conv.pool_window(H, W, (3, 5, 8, 22))
+    pool2.fill_(-3.0); mask.fill_(0xAA)
+    conv(dev(x), window=win, out=torch.empty(full.shape, dtype=F64, device='meta'), place=(y0, x0), pool_out=pool2,
+         mask_out=mask, store_out=False)
+    exp_p = np.full(pooled.shape, -3.0); exp_m = np.full(pooled.shape, 0xAA, np.uint8)
+    q = (slice(None), slice(None), slice(y0 // 2, (y0 + h) // 2), slice(x0 // 2, (x0 + ww) // 2))
+    exp_p[q], exp_m[q] = host(pooled)[q], ref_mask[q]
+    assert np.array_equal(host(pool2), exp_p) and np.array_equal(mask.cpu().numpy(), exp_m)
+
+
+@pytest.mark.parametrize('case', [(2, 24, 20, 26, 40), (1, 64, 33, 41, 11), (2, 16, 14, 15, 70)])
+def test_conv_halo_f64_unpool_from_mask_bytes_is_bit_identical(ops, case):
+    """float64 decoder side: the conv over the DePool2D of `up` from mask bytes == from pre / pooled, bit for bit
+    (64-row and 16-row tiles, windows with the skip add, ties and all-equal windows)."""
+    B, Cc, H, W, Cout = case
+    rng = np.random.default_rng(sum(case))
+    pre = np.maximum(rng.standard_normal((B, Cc, H, W)), 0)
+    pooled = onn.maxpool2(pre)
+    up = rng.standard_normal(pooled.shape)
+    conv = ops.Conv(rng.standard_normal((Cout, Cc, 3, 3)) * 0.3, rng.standard_normal(Cout), pad=1, relu=False,
+                    dtype=F64)
+    assert conv.mask_ok()
+    mask = torch.from_numpy(_eq_bits(pre, pooled)).cuda()
+    ref = conv(dev(up), pre=dev(pre), pooled=dev(pooled))
+    got = conv(dev(up), mask_in=mask, unpool_hw=(H, W))
+    assert np.array_equal(host(got), host(ref))
+    add = rng.standard_normal((B, Cout, H + 3, W + 2))
+    for (y0, x0, h, ww) in [(1, 2, 9, 11), (0, 0, H, 5), (H - 4, W - 7, 4, 7)]:
+        kw = dict(window=(y0, x0, h, ww), add=dev(add), add_off=(y0 + 1, x0))
+        ref = conv(dev(up), pre=dev(pre), pooled=dev(pooled), **kw)
+        got = conv(dev(up), mask_in=mask, unpool_hw=(H, W), **kw)
+        assert np.array_equal(host(got), host(ref)), (y0, x0, h, ww)
+
+
 def test_tail_deconv_metrics_f64(ops):
     rng = np.random.default_rng(10)
     x, Wt, b = rng.standard_normal((2, 11, 5, 6)), rng.standard_normal((11, 11, 16, 16)), \
