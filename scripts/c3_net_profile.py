@@ -34,5 +34,5 @@ for k, f, s, e in prof:
     tot += ms
 for key in order:
     f, ms, n = rows[key]
-    print('%-22s Cin %5d  map %4d  n %2d  %.4f ms  %7.1f TF/s' % (key[0], key[1], key[2], n, ms / n, f / ms / 1e9))
+    print("%-22s %s  map %4d  n %2d  %.4f ms  %7.1f TF/s" % (key[0], ("Cin %5d" % key[1]) if key[0].startswith("conv_c8_") else ("GFLOP %5.1f" % (key[1] / 1e9)), key[2], n, ms / n, f / ms / 1e9))
 print('conv launches total %.3f ms' % tot)
