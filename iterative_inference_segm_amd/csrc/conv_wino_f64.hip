@@ -19,6 +19,7 @@
 // (layers/mylayers.py:88-115) is applied while the input transform loads its patches.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
@@ -329,6 +330,217 @@ __global__ __launch_bounds__(256) void wino64_output_kernel(const Wino64Params p
     }
 }
 
+// ---- the transforms again, for tensors within 32-bit byte offsets (every launch of the strict_f64 leg but one) ----
+// wino64_input_kernel / wino64_output_kernel above spend their cycles ISSUING, not waiting (PMC: 78-92 % / 58 % of a
+// wave's cycles issue-stalled, profiles/r04_pmc_f64.md): per 4 x 4 patch of a channel 48 v_cndmask + 36 64-bit
+// address adds around the 32 v_add_f64 of the transform.  Here every per-thread address is a 32-bit byte offset
+// computed ONCE (out-of-image elements get the out-of-range offset: the load returns 0.0, no select), the channel
+// is a scalar offset of the buffer instruction, and V / M are addressed as wave-uniform base + thread index.
+// Same arithmetic in the same order: bit-identical to the kernels above.
+constexpr unsigned OOB64 = 0x80000000u;
+constexpr int RSRC64_W3 = 0x00027000;
+__device__ __forceinline__ double bld64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    typedef int i32x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(double, (i32x2_)__builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bst64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    typedef int i32x2_ __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_, v), r, (int)voff, (int)soff, 0);
+}
+
+constexpr int ICG64 = 4;      // channels per thread (loop, two per trip)
+template <bool UNPOOL>
+__global__ __launch_bounds__(256) void wino64_input2_kernel(const Wino64Params p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const bool tok = t < p.T;
+    const int tt = tok ? t : 0;
+    const int ntt = p.nty * p.ntx;
+    const int b = tt / ntt;
+    const int r = tt - b * ntt;
+    const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
+    const int iy0 = p.ty0 + 2 * tyl - p.pad, ix0 = p.tx0 + 2 * txl - p.pad;
+    const int HW = p.H * p.W;
+    // byte offsets of the 4 x 4 patch inside image b's first channel plane, per source (OOB64: zero padding)
+    unsigned pix[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = tok && (unsigned)(iy0 + i) < (unsigned)p.H && (unsigned)(ix0 + j) < (unsigned)p.W;
+            pix[i][j] = ok ? 8u * (unsigned)((iy0 + i) * p.W + ix0 + j) : OOB64;
+        }
+    const unsigned bb1 = 8u * (unsigned)(b * p.C1 * HW), bb2 = 8u * (unsigned)(b * p.C2 * HW);
+    unsigned pa1[4][4], pa2[UNPOOL ? 1 : 4][UNPOOL ? 1 : 4];      // ... with the image's offset in each source
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pa1[i][j] = pix[i][j] != OOB64 ? pix[i][j] + bb1 : OOB64;
+            if constexpr (!UNPOOL) pa2[i][j] = pix[i][j] != OOB64 ? pix[i][j] + bb2 : OOB64;
+        }
+    // V as one buffer: slice (xi, c) is a scalar offset, the tile a fixed per-thread offset
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.V, 0, (int)(8u * (unsigned)(16 * p.Kc * p.Tpad)), RSRC64_W3);
+    const unsigned tv = tok ? 8u * (unsigned)t : OOB64;
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(UNPOOL ? p.pre : p.x1), 0, (int)(8u * (unsigned)(p.B * p.C1 * HW)), RSRC64_W3);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.C2 > 0 ? p.x2 : p.x1), 0, (int)(8u * (unsigned)(p.B * (p.C2 > 0 ? p.C2 : p.C1) * HW)), RSRC64_W3);
+    // UNPOOL: the 3 x 3 pooling cells the patch touches (pooled / up), byte offsets inside image b's first plane
+    const int hw2 = p.h2 * p.w2;
+    unsigned qix[UNPOOL ? 3 : 1][UNPOOL ? 3 : 1];
+    const int qy0 = iy0 >> 1, qx0 = ix0 >> 1;           // arithmetic shift: floor for iy0 = -pad
+    const bool py = iy0 & 1, px = ix0 & 1;
+    if constexpr (UNPOOL) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bool ok = tok && (unsigned)(qy0 + i) < (unsigned)p.h2 && (unsigned)(qx0 + j) < (unsigned)p.w2;
+                qix[i][j] = ok ? 8u * (unsigned)((qy0 + i) * p.w2 + qx0 + j) + 8u * (unsigned)(b * p.C1 * hw2) : OOB64;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(UNPOOL ? p.pooled : p.x1), 0, (int)(8u * (unsigned)(p.B * p.C1 * (UNPOOL ? hw2 : HW))), RSRC64_W3);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.x1, 0, (int)(8u * (unsigned)(p.B * p.C1 * (UNPOOL ? hw2 : HW))), RSRC64_W3);
+    const size_t xis = (size_t)p.Kc * p.Tpad;
+    const int c0 = blockIdx.y * ICG64;
+    for (int cc = 0; cc < ICG64; cc += 2) {
+        if (c0 + cc >= p.Kc) break;
+        double d[2][4][4];
+        // all loads of the two channels first
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = min(c0 + cc + h, p.Kc - 1);
+            if constexpr (UNPOOL) {
+                double pq[3][3], uq[3][3];
+                const unsigned soq = 8u * (unsigned)(c * hw2);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bool ok = qix[i][j] != OOB64;
+                        pq[i][j] = bld64(rq, qix[i][j], soq);
+                        uq[i][j] = bld64(ru, qix[i][j], soq);
+                        if (!ok) pq[i][j] = __builtin_nan("");     // never equal: outside the pooled map -> 0
+                    }
+                const unsigned so = 8u * (unsigned)(c * HW);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = pix[i][j] != OOB64;
+                        const double pr = bld64(r1, pa1[i][j], so);
+                        const double pa = px ? pq[i >> 1][(j + 1) >> 1] : pq[i >> 1][j >> 1];
+                        const double pb = px ? pq[(i + 1) >> 1][(j + 1) >> 1] : pq[(i + 1) >> 1][j >> 1];
+                        const double ua = px ? uq[i >> 1][(j + 1) >> 1] : uq[i >> 1][j >> 1];
+                        const double ub = px ? uq[(i + 1) >> 1][(j + 1) >> 1] : uq[(i + 1) >> 1][j >> 1];
+                        d[h][i][j] = (ok && pr == (py ? pb : pa)) ? (py ? ub : ua) : 0.0;
+                    }
+            } else {
+                const bool s1 = c < p.C1;
+                const unsigned so = 8u * (unsigned)((s1 ? c : c - p.C1) * HW);
+                if (s1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[h][i][j] = bld64(r1, pa1[i][j], so);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) d[h][i][j] = bld64(r2, pa2[i][j], so);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + cc + h;
+            if (c >= p.Kc) break;
+            double e[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // B^T d
+                e[0][j] = d[h][0][j] - d[h][2][j];
+                e[1][j] = d[h][1][j] + d[h][2][j];
+                e[2][j] = d[h][2][j] - d[h][1][j];
+                e[3][j] = d[h][1][j] - d[h][3][j];
+            }
+            const unsigned sv = 8u * (unsigned)(c * p.Tpad), sx = 8u * (unsigned)(p.Kc * p.Tpad);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // (B^T d) B
+                bst64(rV, tv, sv + (unsigned)(i * 4 + 0) * sx, e[i][0] - e[i][2]);
+                bst64(rV, tv, sv + (unsigned)(i * 4 + 1) * sx, e[i][1] + e[i][2]);
+                bst64(rV, tv, sv + (unsigned)(i * 4 + 2) * sx, e[i][2] - e[i][1]);
+                bst64(rV, tv, sv + (unsigned)(i * 4 + 3) * sx, e[i][1] - e[i][3]);
+            }
+        }
+    }
+}
+
+constexpr int OCG64 = 2;      // output channels per thread (loop)
+__global__ __launch_bounds__(256) void wino64_output2_kernel(const Wino64Params p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= p.T) return;
+    const int ntt = p.nty * p.ntx;
+    const int b = t / ntt;
+    const int r = t - b * ntt;
+    const int tyl = r / p.ntx, txl = r - tyl * p.ntx;
+    const int wy = p.ty0 + 2 * tyl - p.oy0, wx = p.tx0 + 2 * txl - p.ox0;  // window coords
+    const int OPL = p.out_H * p.out_W, APL = p.AH * p.AW;
+    unsigned ooff[2][2], aoff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = (unsigned)(wy + i) < (unsigned)p.OH && (unsigned)(wx + j) < (unsigned)p.OW;
+            ooff[i][j] = ok ? 8u * (unsigned)((b * p.out_ctot + p.out_c0) * OPL + (p.out_y0 + wy + i) * p.out_W +
+                                              p.out_x0 + wx + j)
+                            : OOB64;
+            aoff[i][j] = (ok && p.add) ? 8u * (unsigned)(b * p.Cout * APL + (p.ay0 + wy + i) * p.AW + p.ax0 + wx + j)
+                                       : OOB64;
+        }
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.out, 0, (int)(8u * (unsigned)(p.B * p.out_ctot * OPL)), RSRC64_W3);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.add ? p.add : p.out), 0, p.add ? (int)(8u * (unsigned)(p.B * p.Cout * APL)) : 0, RSRC64_W3);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.M, 0, (int)(8u * (unsigned)(16 * p.Mpad * p.Tpad)), RSRC64_W3);
+    const unsigned tv = 8u * (unsigned)t, sx = 8u * (unsigned)(p.Mpad * p.Tpad);
+    const int co0 = blockIdx.y * OCG64;
+    for (int cc = 0; cc < OCG64; ++cc) {
+        const int co = co0 + cc;
+        if (co >= p.Cout) break;
+        const unsigned sm = 8u * (unsigned)(co * p.Tpad);
+        double mv[16], av[4];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) mv[x] = bld64(rM, tv, sm + (unsigned)x * sx);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) av[i * 2 + j] = bld64(ra, aoff[i][j], 8u * (unsigned)(co * APL));
+        double s2[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // A^T m
+            const double m0 = mv[j], m1 = mv[4 + j], m2 = mv[8 + j], m3 = mv[12 + j];
+            s2[0][j] = m0 + m1 + m2;
+            s2[1][j] = m1 - m2 - m3;
+        }
+        const double bias = p.bias ? p.bias[co] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // (A^T m) A
+            const double y[2] = {s2[i][0] + s2[i][1] + s2[i][2], s2[i][1] - s2[i][2] - s2[i][3]};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double v = y[j] + bias;
+                if (p.add) v += av[i * 2 + j];
+                if (p.relu) v = fmax(v, 0.0);
+                bst64(ro, ooff[i][j], 8u * (unsigned)(co * OPL), v);
+            }
+        }
+    }
+}
+
 struct Wino64Geom {
     int Kc, Mpad, ty0, tx0, nty, ntx, T, Tpad;
 };
@@ -547,11 +759,30 @@ extern "C" int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const
     p.n_mtiles = g.Mpad / GBM;
     hipStream_t s = (hipStream_t)stream;
     const int tb = (g.T + 255) / 256;
-    if (unpool)
+    // the transforms with 32-bit per-thread offsets where every tensor they address stays below 2 GiB
+    static const int t2 = getenv("IISEG_W64_FAST_TRANSFORMS") ? atoi(getenv("IISEG_W64_FAST_TRANSFORMS")) : 1;
+    const int64_t lim = (int64_t)1 << 31;
+    const int64_t HW8 = (int64_t)d->H * d->W * 8, hw28 = (int64_t)(d->H / 2) * (d->W / 2) * 8;
+    const int64_t lim32 = ((int64_t)1 << 32) - 16;            // V / M: unsigned offsets, scalar + per-thread part
+    const bool in_fast = t2 && (int64_t)d->B * d->C1 * HW8 < lim && (int64_t)d->B * d->C2 * HW8 < lim &&
+                         (!unpool || (int64_t)d->B * d->C1 * hw28 < lim) &&
+                         (int64_t)16 * g.Kc * g.Tpad * 8 < lim32;
+    const bool out_fast = t2 && (int64_t)d->B * p.out_ctot * p.out_H * p.out_W * 8 < lim &&
+                          (!add || (int64_t)d->B * d->Cout * d->AH * d->AW * 8 < lim) &&
+                          (int64_t)16 * g.Mpad * g.Tpad * 8 < lim32;
+    if (in_fast) {
+        if (unpool)
+            IISEG_LAUNCH(wino64_input2_kernel<true>, dim3(tb, (g.Kc + ICG64 - 1) / ICG64), dim3(256), 0, s, p);
+        else
+            IISEG_LAUNCH(wino64_input2_kernel<false>, dim3(tb, (g.Kc + ICG64 - 1) / ICG64), dim3(256), 0, s, p);
+    } else if (unpool)
         IISEG_LAUNCH(wino64_input_kernel<true>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
     else
         IISEG_LAUNCH(wino64_input_kernel<false>, dim3(tb, (g.Kc + ICH64 - 1) / ICH64), dim3(256), 0, s, p);
     IISEG_LAUNCH(wino64_gemm_kernel, dim3(16 * p.n_ttiles * p.n_mtiles), dim3(256), 0, s, p);
-    IISEG_LAUNCH(wino64_output_kernel, dim3(tb, (d->Cout + OCH64 - 1) / OCH64), dim3(256), 0, s, p);
+    if (out_fast)
+        IISEG_LAUNCH(wino64_output2_kernel, dim3(tb, (d->Cout + OCG64 - 1) / OCG64), dim3(256), 0, s, p);
+    else
+        IISEG_LAUNCH(wino64_output_kernel, dim3(tb, (d->Cout + OCH64 - 1) / OCH64), dim3(256), 0, s, p);
     return iiseg_check_launch();
 }
