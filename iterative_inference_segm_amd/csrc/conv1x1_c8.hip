@@ -17,6 +17,7 @@
 // BatchNorm arithmetic, not by the matrix pipe: 104 GFLOP per batch of 32 in all five TransitionDowns.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
@@ -38,7 +39,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-constexpr int BM = 64, TM = 2, TN = 4;
+constexpr int TN = 4;
+constexpr int BMP = 64;            // rows the packed weights are padded to
 constexpr int BN_CAP = 2048;          // channels whose (a, b) fit the LDS table
 
 struct P1x1 {
@@ -56,8 +58,10 @@ struct P1x1 {
     int n_ptiles, n_mtiles;
 };
 
-template <bool POOL, bool BNRELU>
-__global__ __launch_bounds__(256, 2) void conv1x1_c8_kernel(const P1x1 p) {
+// TM: 32-channel row blocks per wave (workgroup = 32 TM output channels)
+template <bool POOL, bool BNRELU, int TM>
+__global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv1x1_c8_kernel(const P1x1 p) {
+    constexpr int BM = 32 * TM;
     __shared__ __attribute__((aligned(16))) float sa[BNRELU ? BN_CAP : 4];
     __shared__ __attribute__((aligned(16))) float sb[BNRELU ? BN_CAP : 4];
     int pt, mt;
@@ -223,7 +227,7 @@ int check1x1(int B, int Cin, int in_ctot, int H, int W, int Cout) {
 
 extern "C" int64_t iiseg_conv1x1_c8_weight_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0 || Cin % 16) return 0;
-    return (int64_t)((Cout + BM - 1) / BM * BM) * Cin * 2;
+    return (int64_t)((Cout + BMP - 1) / BMP * BMP) * Cin * 2;
 }
 
 // w: fp32 [Cout][Cin_w] with element strides (stride_o, stride_c); Cin >= Cin_w is the padded channel
@@ -233,7 +237,7 @@ extern "C" int iiseg_conv1x1_c8_pack(void* stream, const float* w, int64_t strid
     if (!w || !wp) return IISEG_ERR_NULL;
     if (Cout <= 0 || Cin_w <= 0 || Cin < Cin_w || Cin % 16) return IISEG_ERR_SHAPE;
     if ((uintptr_t)wp & 15) return IISEG_ERR_ALIGN;
-    const int Mpad = (Cout + BM - 1) / BM * BM;
+    const int Mpad = (Cout + BMP - 1) / BMP * BMP;
     const int64_t n = (int64_t)Mpad * Cin;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     IISEG_LAUNCH(conv1x1_c8_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, stride_o, stride_c,
@@ -253,9 +257,18 @@ extern "C" int iiseg_conv1x1_c8(void* stream, const void* x, int B, int Cin, int
     P1x1 p = {};
     p.x = (const u32x4*)x; p.bn_a = bn_a; p.bn_b = bn_b; p.wp = (const u32x4*)wp; p.bias = bias; p.out = out;
     p.in_c8tot = in_ctot / 8; p.Cin = Cin;
-    p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.Mpad = (Cout + BM - 1) / BM * BM;
-    p.n_mtiles = p.Mpad / BM;
+    p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.Mpad = (Cout + BMP - 1) / BMP * BMP;
+    // 32-channel workgroups for layers of at most 32 output channels (the class-score layer: half the
+    // accumulators, three waves per SIMD), 64-channel ones otherwise (the input is re-read per channel block)
+    static const int tm_env = getenv("IISEG_C8_1X1_TM") ? atoi(getenv("IISEG_C8_1X1_TM")) : 0;
+    const int tm = tm_env ? tm_env : (Cout <= 32 ? 1 : 2);
+    p.n_mtiles = (Cout + 32 * tm - 1) / (32 * tm);
     hipStream_t s = (hipStream_t)stream;
+#define C1X1_LAUNCH(PL, BNR)                                                                          \
+    do {                                                                                              \
+        if (tm == 1) IISEG_LAUNCH((conv1x1_c8_kernel<PL, BNR, 1>), grid, dim3(256), 0, s, p);          \
+        else IISEG_LAUNCH((conv1x1_c8_kernel<PL, BNR, 2>), grid, dim3(256), 0, s, p);                  \
+    } while (0)
     if (pool) {
         // bf16 C8 output: channels [out_c0, out_c0 + Cout) of a (B, out_ctot / 8, H / 2, W / 2, 8) tensor
         if (out_ctot % 8 || out_c0 % 8 || out_c0 < 0 || out_c0 + (Cout + 7) / 8 * 8 > out_ctot) return IISEG_ERR_SHAPE;
@@ -265,15 +278,14 @@ extern "C" int iiseg_conv1x1_c8(void* stream, const void* x, int B, int Cin, int
         p.N = B * p.QH * p.QW;
         p.n_ptiles = (p.N + 127) / 128;
         const dim3 grid(p.n_ptiles * p.n_mtiles);
-        if (bn_a) IISEG_LAUNCH((conv1x1_c8_kernel<true, true>), grid, dim3(256), 0, s, p);
-        else IISEG_LAUNCH((conv1x1_c8_kernel<true, false>), grid, dim3(256), 0, s, p);
+        if (bn_a) C1X1_LAUNCH(true, true); else C1X1_LAUNCH(true, false);
     } else {
         // fp32 NCHW output (B, Cout, H, W)
         p.N = B * H * W;
         p.n_ptiles = (p.N + 511) / 512;
         const dim3 grid(p.n_ptiles * p.n_mtiles);
-        if (bn_a) IISEG_LAUNCH((conv1x1_c8_kernel<false, true>), grid, dim3(256), 0, s, p);
-        else IISEG_LAUNCH((conv1x1_c8_kernel<false, false>), grid, dim3(256), 0, s, p);
+        if (bn_a) C1X1_LAUNCH(false, true); else C1X1_LAUNCH(false, false);
     }
+#undef C1X1_LAUNCH
     return iiseg_check_launch();
 }
