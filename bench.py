@@ -298,7 +298,14 @@ def other_configs(device, step_size, no_roofline):
                           pad_multi_concat=True, device=device, mma=mma)
         return IterativeInference(fcn(ch, mma), dae, N_CLASSES, [N_CLASSES], device=device)
 
+    def c1(mma):
+        dae = StandardDAE(S.make_dae_params(seed=4321), N_CLASSES, device=device, mma=mma)
+        return IterativeInference(fcn(['pool4'], mma), dae, N_CLASSES, [N_CLASSES], device=device)
+
     cases = [  # key, builder, mma, batch, (H, W), steps, nominal GFLOP / image, what
+        ('c1_batch10_f32', c1, None, 10, (224, 224), 10, 872.3,
+         'configs[0] on the GPU: the reference\'s own batch of 10 (the batch the CPU baseline is timed on), fp32'),
+        ('c1_batch10_bf16c8', c1, 'bf16c8', 10, (224, 224), 10, 872.3, 'the same on bf16 C8'),
         ('c3_f32', c3, None, 32, (224, 224), 10, GFLOP_C3,
          'configs[2]: FC-DenseNet103 + standard DAE (padding 0, h = pool4 464 ch), fp32'),
         ('c3_bf16c8', c3, 'bf16c8', 32, (224, 224), 10, GFLOP_C3,
