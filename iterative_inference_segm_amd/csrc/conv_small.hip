@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void conv_small_f32_kernel(const ConvParams p,
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e][j] = bv;
     }
-    f32x4 xv[2][T];
+    constexpr int CT = T == 9 ? 2 : 3;     // channels per trip: CT T weight rows = a multiple of the 3-row ring
+    f32x4 xv[CT][T];
     auto load = [&](int c, int s) __attribute__((always_inline)) {
         const int so = c * HW * 4;
 #pragma unroll
@@ -77,32 +78,48 @@ __global__ __launch_bounds__(256) void conv_small_f32_kernel(const ConvParams p,
             xv[s][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 rx, (int)(roff[t / KW] == OOB ? OOB : roff[t / KW] + 4u * (unsigned)((t % KW) * p.dil)), so, 0));
     };
+    // weight row k = c T + tap of Wp[Kpad][Mpad]: wave-uniform address -> scalar loads, the weights are SGPR
+    // operands of the FMAs; row k + 2 is fetched while row k multiplies (a scalar load issued right in front of
+    // its use parks the wave for the scalar cache's latency, 99 times per pixel group; left to itself hipcc either
+    // does that or hoists a dozen rows and spills scalar registers: the order is pinned row by row)
+    f32x4 wq[3][COP / 4];
+    auto wload = [&](int k, auto S) __attribute__((always_inline)) {
+        constexpr int sw = decltype(S)::value;
+        const float* wr = p.wp + (size_t)k * p.Mpad;
+#pragma unroll
+        for (int q = 0; q < COP / 4; ++q) wq[sw][q] = *reinterpret_cast<const f32x4*>(wr + q * 4);
+    };
     load(0, 0);
-    for (int c = 0; c < Cin; c += 2) {
-        // two channels per trip: the loads of the next channel are in flight under the FMAs of this one
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+    const int nk = Cin * T;
+    wload(0, ic<0>{});
+    wload(min(1, nk - 1), ic<1>{});
+    for (int c = 0; c < Cin; c += CT) {
+        // CT channels per trip: the loads of the next channel are in flight under the FMAs of this one
+        static_for<0, CT>([&](auto Hh) __attribute__((always_inline)) {
+            constexpr int h = decltype(Hh)::value;
             const int cc = c + h;
-            if (cc >= Cin) break;
-            if (cc + 1 < Cin) load(cc + 1, h ^ 1);
+            if (cc < Cin) {
+                if (cc + 1 < Cin) load(cc + 1, (h + 1) % CT);
+                static_for<0, T>([&](auto Tt) __attribute__((always_inline)) {
+                    constexpr int t = decltype(Tt)::value;
+                    constexpr int ws = (h * T + t) % 3;           // (two channels = 2 T rows; T = 1 or 9: see the trip count)
+                    const int kn = min(cc * T + t + 2, nk - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wload(kn, ic<(ws + 2) % 3>{});
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                // weight row k = c T + tap of Wp[Kpad][Mpad]: wave-uniform address -> scalar loads, the weights
-                // are SGPR operands of the FMAs
-                const float* wr = p.wp + (size_t)(cc * T + t) * p.Mpad;
+                    for (int q = 0; q < COP / 4; ++q) {
+                        const f32x2 wa = {wq[ws][q][0], wq[ws][q][1]}, wb = {wq[ws][q][2], wq[ws][q][3]};
 #pragma unroll
-                for (int q = 0; q < COP / 4; ++q) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + q * 4);
-                    const f32x2 wa = {w4[0], w4[1]}, wb = {w4[2], w4[3]};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x2 xx = {xv[h][t][e], xv[h][t][e]};
-                        acc[e][2 * q] = __builtin_elementwise_fma(xx, wa, acc[e][2 * q]);
-                        acc[e][2 * q + 1] = __builtin_elementwise_fma(xx, wb, acc[e][2 * q + 1]);
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2 xx = {xv[h][t][e], xv[h][t][e]};
+                            acc[e][2 * q] = __builtin_elementwise_fma(xx, wa, acc[e][2 * q]);
+                            acc[e][2 * q + 1] = __builtin_elementwise_fma(xx, wb, acc[e][2 * q + 1]);
+                        }
                     }
-                }
+                });
             }
-        }
+        });
     }
     if (!any_ok) return;
     const int OPL = p.out_H * p.out_W;
