@@ -770,7 +770,10 @@ extern "C" int iiseg_conv_wino_f64(void* stream, const iiseg_conv_desc* d, const
     const bool out_fast = t2 && (int64_t)d->B * p.out_ctot * p.out_H * p.out_W * 8 < lim &&
                           (!add || (int64_t)d->B * d->Cout * d->AH * d->AW * 8 < lim) &&
                           (int64_t)16 * g.Mpad * g.Tpad * 8 < lim32;
-    if (in_fast) {
+    // (the DePool2D form of the new input transform measured slower than the old one -- 0.204 against 0.17-0.19 ms
+    // per launch: 34 loads and the window selects per channel either way -- and is only used on request)
+    static const int t2u = getenv("IISEG_W64_FAST_UNPOOL") ? atoi(getenv("IISEG_W64_FAST_UNPOOL")) : 0;
+    if (in_fast && (!unpool || t2u)) {
         if (unpool)
             IISEG_LAUNCH(wino64_input2_kernel<true>, dim3(tb, (g.Kc + ICG64 - 1) / ICG64), dim3(256), 0, s, p);
         else
