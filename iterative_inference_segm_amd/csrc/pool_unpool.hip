@@ -54,6 +54,23 @@ __global__ __launch_bounds__(256) void maxpool2x2_window_kernel(const T* __restr
                                                                 int W, int h, int w, int y0, int x0,
                                                                 int wh, int ww) {
     const size_t n = (size_t)BC * wh * ww;
+    if (n < ((size_t)1 << 31)) {
+        // (32-bit index arithmetic: the 64-bit divisions below are a few dozen instructions each, and the windows
+        // of a refinement step are small -- this kernel is launched 40+ times per batch of the float64 path)
+        const unsigned n32 = (unsigned)n, uww = (unsigned)ww, uwh = (unsigned)wh;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += gridDim.x * blockDim.x) {
+            const unsigned t = i / uww;
+            const int ox = x0 + (int)(i - t * uww);
+            const unsigned bc = t / uwh;
+            const int oy = y0 + (int)(t - bc * uwh);
+            const T* r0 = x + ((size_t)bc * H + 2 * oy) * (size_t)W + 2 * ox;
+            const T* r1 = r0 + W;
+            const T a = r0[0] > r0[1] ? r0[0] : r0[1];
+            const T b = r1[0] > r1[1] ? r1[0] : r1[1];
+            out[((size_t)bc * h + oy) * (size_t)w + ox] = a > b ? a : b;
+        }
+        return;
+    }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
          i += (size_t)gridDim.x * blockDim.x) {
         const int ox = x0 + (int)(i % ww);
