@@ -277,29 +277,52 @@ __global__ __launch_bounds__(256, BM == 16 ? 3 : 2) void conv_halo_f64_kernel(co
     // are even, so column tiles j, j + 2 of a lane are the two rows and lane ^ 1 the other column of one window;
     // the pooled value is the max of the four STORED values.  A trailing unpaired row / column has no window.
     const bool pooling = BM == 64 && RW == 2 && p.pool != nullptr;
+    // One image's planes through buffer descriptors with 32-bit offsets (host: conv_halo_f64_ok); elements outside
+    // the window / past Cout get the out-of-range offset instead of a branch, and the skip-add loads of a column
+    // tile are all issued before its stores (a load behind a store through plain pointers cannot move above it).
+    typedef int i32x2e __attribute__((ext_vector_type(2)));
+    const int OPLi = p.out_H * p.out_W, APLi = p.AH * p.AW;
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.out ? p.out + (size_t)b * p.out_ctot * OPL : nullptr), 0, p.out ? p.out_ctot * OPLi * 8 : 0, RSRC_W3);
+    const __amdgpu_buffer_rsrc_t r_add = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.add ? p.add + (size_t)b * p.Cout * APL : nullptr), 0, p.add ? p.Cout * APLi * 8 : 0, RSRC_W3);
+    double bv[TM][4];
+    unsigned coo[TM][4], coa[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = m0 + i * 16 + kq + 4 * r;
+            const bool cok = co < p.Cout;
+            bv[i][r] = (p.bias && cok) ? p.bias[co] : 0.0;
+            coo[i][r] = cok ? 8u * (unsigned)((p.out_c0 + co) * OPLi) : OOB;
+            coa[i][r] = cok ? 8u * (unsigned)(co * APLi) : OOB;
+        }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int wy = wy0 + wave * RW + (j >> 1), wx = wx0 + (j & 1) * 16 + n;
         const bool ok = wy < p.OH && wx < p.OW;
-        // (out may be NULL with the pool + mask bytes: nothing reads the pre-pool map then)
-        double* outp = p.out ? p.out + ((size_t)b * p.out_ctot + p.out_c0) * OPL +
-                                   (size_t)(p.out_y0 + wy) * p.out_W + p.out_x0 + wx
-                             : nullptr;
-        const double* addp = p.add ? p.add + (size_t)b * p.Cout * APL + (size_t)(p.ay0 + wy) * p.AW +
-                                         p.ax0 + wx
-                                   : nullptr;
+        const unsigned o0 = ok ? 8u * (unsigned)((p.out_y0 + wy) * p.out_W + p.out_x0 + wx) : OOB;
+        const unsigned a0 = (ok && p.add) ? 8u * (unsigned)((p.ay0 + wy) * p.AW + p.ax0 + wx) : OOB;
+        double av[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                av[i][r] = __builtin_bit_cast(double, (i32x2e)__builtin_amdgcn_raw_buffer_load_b64(
+                    r_add, (int)((a0 == OOB || coa[i][r] == OOB) ? OOB : a0 + coa[i][r]), 0, 0));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = m0 + i * 16 + kq + 4 * r;
                 double v = acc[i][j][r];
-                if (ok && co < p.Cout) {
-                    if (p.bias) v += p.bias[co];
-                    if (addp) v += addp[(size_t)co * APL];
+                if (ok && coo[i][r] != OOB) {
+                    if (p.bias) v += bv[i][r];
+                    if (p.add) v += av[i][r];
                     if (p.relu) v = fmax(v, 0.0);
-                    if (outp) outp[(size_t)co * OPL] = v;
                 }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2e, v), r_out,
+                                                      (int)((o0 == OOB || coo[i][r] == OOB) ? OOB : o0 + coo[i][r]), 0, 0);
                 acc[i][j][r] = v;
             }
     }
@@ -355,6 +378,9 @@ bool iiseg::iiseg_conv_halo_f64_ok(const ConvParams64& p, int KH, int KW) {
     const int64_t cmax = p.C1 > p.C2 ? p.C1 : p.C2;
     if (cmax * p.H * p.W * 8 >= (1ll << 31) - 8) return false;     // per-image 32-bit byte offsets
     if ((int64_t)p.Kpad * p.Mpad * 8 >= (1ll << 31)) return false;
+    // the epilogue addresses one image's output / skip-add planes with 32-bit byte offsets
+    if (((int64_t)p.out_ctot + 64) * p.out_H * p.out_W * 8 >= (1ll << 31)) return false;
+    if (p.add && ((int64_t)p.Cout + 64) * p.AH * p.AW * 8 >= (1ll << 31)) return false;
     if ((int64_t)p.B * ((p.OH + 7) / 8) * ((p.OW + 31) / 32) * (p.Mpad / 16) >= (1ll << 31)) return false;
     return true;
 }
