@@ -77,6 +77,22 @@ def _hipcc_version(hipcc):
     return _HIPCC_VERSION[hipcc]
 
 
+# Per-source flags.  The bf16 C8 kernels are compiled with relaxed NaN handling: their ReLU / max-pool
+# epilogues are v_max_f32 straight on MFMA results, and under strict NaN rules hipcc puts a quieting pass
+# (v_max_f32 v, v, v) in front of every one of them and cannot fold the lane exchange of the pool into the
+# max (conv1_1 of the DAE: 725 -> 589 vector instructions per wave).  Results for non-NaN data are the same
+# bit for bit; a NaN in the activations gives an unspecified (never trapping) value instead of a quiet NaN.
+# NOT for the float64 sources: conv_wino_f64.hip uses NaN as its never-equal marker.
+EXTRA_FLAGS = {
+    'conv_c8_bf16.hip': ['-fno-honor-nans'],
+    'conv_c8_m16.hip': ['-fno-honor-nans'],
+    'conv1x1_c8.hip': ['-fno-honor-nans'],
+    'conv_halo.hip': ['-fno-honor-nans'],
+    'conv_wino.hip': ['-fno-honor-nans'],
+    'conv_halo_bf16.hip': ['-fno-honor-nans'],
+    'conv_wino_bf16.hip': ['-fno-honor-nans'],
+}
+
 LAST = {}      # what the latest build() did: {'compiled': [...], 'reused': [...], 'linked': bool}
 
 
@@ -105,9 +121,10 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         # (the key names the include directories relative to the tree: the same tree under another
         # root -- the GPU box's scratch copy -- reuses its objects)
-        key = keys[src] = _digest([s] + headers, extra=key_flags + [version])
+        extra = EXTRA_FLAGS.get(src, [])
+        key = keys[src] = _digest([s] + headers, extra=key_flags + extra + [version])
         if force or _stale(o, key):
-            cmd = [hipcc] + flags + ['-c', s, '-o', o]
+            cmd = [hipcc] + flags + extra + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

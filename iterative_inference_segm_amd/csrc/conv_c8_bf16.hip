@@ -129,7 +129,7 @@ struct C8Params {
 // pool, X3 decided at run time per chunk).  The frequent combinations have straight-line code of their own
 // -- on the 1- to 8-k-tile layers, which are bound by instruction issue, the generic epilogue's scalar
 // branches and addend plumbing are a fifth of a wave's instructions (conv1_1: 0.175 -> 0.124 ms):
-//   1  ONLY the 2x2 max-pool (+ DePool2D mask bytes) of the result is stored (encoder layers)
+//   1  ONLY the 2x2 max-pool (+ DePool2D mask bytes) of the ReLU of the result is stored (encoder layers)
 //   2  bf16 C8 store, no addend, no pool (the plain layers of the FCN-8)
 //   3  bf16 C8 store with a bf16 C8 skip addend (the decoder layers)
 // Same values, same comparisons, same stores as the generic epilogue.
@@ -589,8 +589,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             qb[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8P * PPL) + qpix) * 16u + 8u * lh : OOB;
             qm[jp] = q_ok ? ((unsigned)(eb[2 * jp] * co8 * PPL) + qpix) * 8u + 4u * lh : OOB;
         }
-        const float rfloor = p.relu ? 0.f : -__builtin_inff();
+        // The mask byte of a channel without compares: every value a of a window is <= its maximum m, so the
+        // sign of a - m is set exactly when a is NOT the maximum (a != m -> a - m != 0: denormals are kept;
+        // a == m -> +0: after the ReLU -- the host picks this epilogue for ReLU layers only -- no value is
+        // -0).  v_alignbit funnels the signs into one word, the upper row's with 6 bits of the difference,
+        // the lower row's with 2: signs at bits 8 q + 5 / 8 q + 7, junk (exponent bits) between them; one
+        // shift, one v_bfi (~x & pattern) later the word is what the compare / select / or chain built --
+        // 2 instead of 3.5 vector instructions per value and no VCC round trips (RECT forms: the shallow,
+        // issue-bound layers; conv1_1 0.111 -> 0.109 ms).
         const unsigned xsh = (unsigned)(l31 & 1);
+        const unsigned nsh = 5u - xsh, pat = 0x05050505u << xsh;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -600,17 +608,39 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
                 const int so_p = (int)((unsigned)(c8 * PPL) * 16u);
 #pragma unroll
                 for (int jp = 0; jp < TN / 2; ++jp) {
-                    f32x4 m;
-                    unsigned own = 0;
+                    f32x4 m, a0, a1;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float a0 = fmaxf(acc[i][2 * jp][g * 4 + q], rfloor);
-                        const float a1 = fmaxf(acc[i][2 * jp + 1][g * 4 + q], rfloor);
-                        const float mv = fmaxf(a0, a1);
-                        m[q] = fmaxf(mv, dpp_xor1(mv));
-                        own |= ((a0 == m[q] ? 1u : 0u) | (a1 == m[q] ? 4u : 0u)) << (8 * q);
+                        a0[q] = fmaxf(acc[i][2 * jp][g * 4 + q], 0.f);
+                        a1[q] = fmaxf(acc[i][2 * jp + 1][g * 4 + q], 0.f);
                     }
-                    own <<= xsh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float mv = fmaxf(a0[q], a1[q]);
+                        m[q] = fmaxf(mv, dpp_xor1(mv));
+                    }
+                    unsigned own;
+                    if constexpr (!FLAT) {
+                        // (two chains of four, joined by one shift-or: half the dependent depth)
+                        unsigned nbh = 0, nbl = 0;
+#pragma unroll
+                        for (int q = 1; q >= 0; --q) {
+                            nbh = __builtin_amdgcn_alignbit(nbh, __builtin_bit_cast(unsigned, a1[q + 2] - m[q + 2]), 30);
+                            nbl = __builtin_amdgcn_alignbit(nbl, __builtin_bit_cast(unsigned, a1[q] - m[q]), 30);
+                            nbh = __builtin_amdgcn_alignbit(nbh, __builtin_bit_cast(unsigned, a0[q + 2] - m[q + 2]), 26);
+                            nbl = __builtin_amdgcn_alignbit(nbl, __builtin_bit_cast(unsigned, a0[q] - m[q]), 26);
+                        }
+                        own = ~(((nbh << 16) | nbl) >> nsh) & pat;
+                    } else {
+                        // (the flat form -- deep layers, two waves per SIMD next to a partner workgroup's MFMAs --
+                        // measured 1-2 % FASTER with the compare / select chain than with the denser code above:
+                        // fcn conv4_3 0.378 against 0.381 ms, dae conv6_1 0.279 against 0.284)
+                        own = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            own |= ((a0[q] == m[q] ? 1u : 0u) | (a1[q] == m[q] ? 4u : 0u)) << (8 * q);
+                        own <<= xsh;
+                    }
                     const unsigned mb = own | dpp_xor1(own);
                     u32x2 w2;
                     w2[0] = pack_bf16(m[0], m[1]); w2[1] = pack_bf16(m[2], m[3]);
@@ -1155,7 +1185,7 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
     if constexpr (BM == 64 && !OUTF32) {
         int epi = EPI_GENERIC;
         if (epi_env) {
-            if (p.pool && !p.out && !p.add && !unpool) epi = EPI_POOL;
+            if (p.pool && !p.out && !p.add && !unpool && p.relu) epi = EPI_POOL;
             else if (!p.pool && p.out && p.out_kind == 1 && !p.add && !unpool) epi = EPI_STORE;
             else if (!p.pool && p.out && p.out_kind == 1 && p.add && p.add_kind == 1) epi = EPI_STORE_ADD;
         }
