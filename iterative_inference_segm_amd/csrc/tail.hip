@@ -14,21 +14,61 @@ __device__ inline double exp_t(double x) { return exp(x); }
 __device__ inline float sqrt_t(float x) { return sqrtf(x); }
 __device__ inline double sqrt_t(double x) { return sqrt(x); }
 
+// Channel columns through buffer descriptors.  One pixel per thread means C loads (stores) a plane apart per
+// tensor; written as `if (c < C) v[c] = p[c * stride]` every load sat in a basic block of its own behind an
+// s_waitcnt vmcnt(0) -- up to 33 dependent memory round trips per thread (refine_update: 0.125 ms for 526 MB).
+// Here the offset of a channel past C, of a pixel past the map, or of a store to a stopped image is the
+// out-of-range offset instead of a branch: all loads of a thread are issued back to back, the arithmetic
+// follows, then the stores.  One descriptor per image and tensor (32-bit byte offsets: the host checks).
+constexpr unsigned T_OOB = 0x80000000u;
+typedef unsigned t_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t t_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00027000);
+}
+__device__ __forceinline__ void t_load(__amdgpu_buffer_rsrc_t r, unsigned off, float& v) {
+    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void t_load(__amdgpu_buffer_rsrc_t r, unsigned off, double& v) {
+    v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void t_store(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void t_store(__amdgpu_buffer_rsrc_t r, unsigned off, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(t_u32x2, v), r, (int)off, 0, 0);
+}
+// v[c] = plane c of the tensor at byte offset off0 (channels >= C, or off0 out of range: 0, no memory access)
 template <int CMAX, typename T>
-__device__ inline void load_softmax(const T* sp, size_t cstride, int C, T (&r)[CMAX]) {
+__device__ __forceinline__ void load_column(__amdgpu_buffer_rsrc_t r, unsigned off0, unsigned plane_bytes, int C,
+                                            T (&v)[CMAX]) {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        t_load(r, (c < C && off0 != T_OOB) ? off0 + (unsigned)c * plane_bytes : T_OOB, v[c]);
+}
+template <int CMAX, typename T>
+__device__ __forceinline__ void store_column(__amdgpu_buffer_rsrc_t r, unsigned off0, unsigned plane_bytes, int C,
+                                             const T (&v)[CMAX]) {
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        t_store(r, (c < C && off0 != T_OOB) ? off0 + (unsigned)c * plane_bytes : T_OOB, v[c]);
+}
+
+// r <- softmax over the first C entries (same order of operations as ever: max, exp(v - max), sum in
+// channel order, one reciprocal); entries >= C become 0
+template <int CMAX, typename T>
+__device__ inline void softmax_column(int C, T (&r)[CMAX]) {
     T m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-        if (c < C) {
-            r[c] = sp[(size_t)c * cstride];
-            m = r[c] > m ? r[c] : m;
-        }
+        if (c < C) m = r[c] > m ? r[c] : m;
     T s = 0;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) {
             r[c] = exp_t(r[c] - m);
             s += r[c];
+        } else {
+            r[c] = 0;
         }
     const T inv = (T)1 / s;
 #pragma unroll
@@ -36,25 +76,43 @@ __device__ inline void load_softmax(const T* sp, size_t cstride, int C, T (&r)[C
         if (c < C) r[c] *= inv;
 }
 
+// the thread's pixel: byte offsets inside image b's score window / inside a (C, H, W) map, or T_OOB
+struct TailPix {
+    unsigned so, po;
+    bool inb;
+};
+template <typename T>
+__device__ __forceinline__ TailPix tail_pixel(int SW, int sy0, int sx0, int H, int W) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    TailPix t;
+    t.inb = pix < H * W;
+    const int y = pix / W, x = pix - y * W;
+    t.so = t.inb ? (unsigned)((sy0 + y) * SW + sx0 + x) * (unsigned)sizeof(T) : T_OOB;
+    t.po = t.inb ? (unsigned)pix * (unsigned)sizeof(T) : T_OOB;
+    return t;
+}
+
 template <int CMAX, typename T>
 __global__ __launch_bounds__(256) void crop_softmax_kernel(const T* __restrict__ score,
                                                            const T* __restrict__ minuend,
                                                            T* __restrict__ out, int C, int SH,
                                                            int SW, int sy0, int sx0, int H, int W) {
-    const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (pix >= HW) return;
-    const int y = pix / W, x = pix - y * W;
-    const size_t SHW = (size_t)SH * SW;
-    const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
-    T r[CMAX];
-    load_softmax<CMAX, T>(sp, SHW, C, r);
-    T* op = out + (size_t)b * C * HW + pix;
-    const T* mp = minuend ? minuend + (size_t)b * C * HW + pix : nullptr;
+    const int HW = H * W, b = blockIdx.y;
+    const unsigned SB = (unsigned)(SH * SW) * (unsigned)sizeof(T), PB = (unsigned)HW * (unsigned)sizeof(T);
+    const TailPix t = tail_pixel<T>(SW, sy0, sx0, H, W);
+    const __amdgpu_buffer_rsrc_t rs = t_rsrc(score + (size_t)b * C * SH * SW, (unsigned)C * SB);
+    const __amdgpu_buffer_rsrc_t rm = t_rsrc(minuend ? minuend + (size_t)b * C * HW : nullptr, minuend ? (unsigned)C * PB : 0u);
+    const __amdgpu_buffer_rsrc_t ro = t_rsrc(out + (size_t)b * C * HW, (unsigned)C * PB);
+    T r[CMAX], mv[CMAX];
+    load_column<CMAX, T>(rs, t.so, SB, C, r);
+    load_column<CMAX, T>(rm, t.po, PB, C, mv);     // (no minuend: an empty descriptor, zeros)
+    __builtin_amdgcn_sched_barrier(0);     // (every load of the thread in flight before the first use)
+    softmax_column<CMAX, T>(C, r);
+    if (minuend) {
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) op[(size_t)c * HW] = mp ? mp[(size_t)c * HW] - r[c] : r[c];
+        for (int c = 0; c < CMAX; ++c) r[c] = mv[c] - r[c];
+    }
+    store_column<CMAX, T>(ro, t.po, PB, C, r);
 }
 
 __device__ __forceinline__ unsigned pack_bf16_t(float lo, float hi) {
@@ -72,47 +130,44 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
                                                             int W, T step, uint4* __restrict__ y8,
                                                             int C8n) {
     __shared__ double red[4];
-    const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
+    const int HW = H * W, b = blockIdx.y;
+    const unsigned SB = (unsigned)(SH * SW) * (unsigned)sizeof(T), PB = (unsigned)HW * (unsigned)sizeof(T);
     const bool act = active[b] != 0;
-    T nrm = 0;
-    if (pix < HW) {
-        const int y = pix / W, x = pix - y * W;
-        const size_t SHW = (size_t)SH * SW;
-        const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
-        T r[CMAX];
-        load_softmax<CMAX, T>(sp, SHW, C, r);
-        T* yp = yio + (size_t)b * C * HW + pix;
-        T ss = 0;
-        float ynew[CMAX];
+    const TailPix t = tail_pixel<T>(SW, sy0, sx0, H, W);
+    const __amdgpu_buffer_rsrc_t rs = t_rsrc(score + (size_t)b * C * SH * SW, (unsigned)C * SB);
+    const __amdgpu_buffer_rsrc_t ry = t_rsrc(yio + (size_t)b * C * HW, (unsigned)C * PB);
+    T r[CMAX], yv[CMAX];
+    load_column<CMAX, T>(rs, t.so, SB, C, r);
+    load_column<CMAX, T>(ry, t.po, PB, C, yv);
+    __builtin_amdgcn_sched_barrier(0);     // (every load of the thread in flight before the first use)
+    softmax_column<CMAX, T>(C, r);
+    T ss = 0;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c) {
-            ynew[c] = 0.f;
-            if (c < C) {
-                const T yv = yp[(size_t)c * HW];
-                const T de = yv - r[c];  // iterative_inference.py:203-204
-                ss = fma(de, de, ss);
-                T yn = yv;
-                if (act) {
-                    yn = yv - step * de;  // :270
-                    yn = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);  // :273
-                    yp[(size_t)c * HW] = yn;
-                }
-                ynew[c] = (float)yn;
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            const T de = yv[c] - r[c];  // iterative_inference.py:203-204
+            ss = fma(de, de, ss);
+            if (act) {
+                T yn = yv[c] - step * de;  // :270
+                yv[c] = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);  // :273
             }
         }
-        nrm = sqrt_t(ss);  // np.linalg.norm(grad, axis=1), :275
-        // bf16 C8 copy of the updated map for the next DAE forward (mma='bf16c8': saves the
-        // nchw_to_c8 pass per step); chunk j = channels 8 j .. 8 j + 7, zeros beyond C
-        if (y8) {
+    store_column<CMAX, T>(ry, act ? t.po : T_OOB, PB, C, yv);
+    const T nrm = t.inb ? sqrt_t(ss) : (T)0;  // np.linalg.norm(grad, axis=1), :275
+    // bf16 C8 copy of the updated map for the next DAE forward (mma='bf16c8': saves the
+    // nchw_to_c8 pass per step); chunk j = channels 8 j .. 8 j + 7, zeros beyond C
+    if (y8 && t.inb) {
+        const int pix = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
-            for (int j = 0; j < CMAX / 8; ++j)
-                if (j < C8n)
-                    y8[((size_t)b * C8n + j) * HW + pix] =
-                        make_uint4(pack_bf16_t(ynew[8 * j], ynew[8 * j + 1]), pack_bf16_t(ynew[8 * j + 2], ynew[8 * j + 3]),
-                                   pack_bf16_t(ynew[8 * j + 4], ynew[8 * j + 5]), pack_bf16_t(ynew[8 * j + 6], ynew[8 * j + 7]));
-        }
+        for (int j = 0; j < CMAX / 8; ++j)
+            if (j < C8n) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = 8 * j + e < C ? (float)yv[8 * j + e] : 0.f;
+                y8[((size_t)b * C8n + j) * HW + pix] =
+                    make_uint4(pack_bf16_t(f[0], f[1]), pack_bf16_t(f[2], f[3]), pack_bf16_t(f[4], f[5]),
+                               pack_bf16_t(f[6], f[7]));
+            }
     }
     double d = wave_sum((double)nrm);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
@@ -129,27 +184,28 @@ __global__ __launch_bounds__(256) void sqerr_softmax_bwd_kernel(const T* __restr
                                                                 const T* __restrict__ yin,
                                                                 T* __restrict__ gscore, int C, int SH,
                                                                 int SW, int sy0, int sx0, int H, int W) {
-    const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (pix >= HW) return;
-    const int y = pix / W, x = pix - y * W;
-    const size_t SHW = (size_t)SH * SW;
-    const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
+    const int HW = H * W, b = blockIdx.y;
+    const unsigned SB = (unsigned)(SH * SW) * (unsigned)sizeof(T), PB = (unsigned)HW * (unsigned)sizeof(T);
+    const TailPix t = tail_pixel<T>(SW, sy0, sx0, H, W);
+    const __amdgpu_buffer_rsrc_t rs = t_rsrc(score + (size_t)b * C * SH * SW, (unsigned)C * SB);
+    const __amdgpu_buffer_rsrc_t ry = t_rsrc(yin + (size_t)b * C * HW, (unsigned)C * PB);
+    const __amdgpu_buffer_rsrc_t rg = t_rsrc(gscore + (size_t)b * C * HW, (unsigned)C * PB);
     T r[CMAX], g[CMAX];
-    load_softmax<CMAX, T>(sp, SHW, C, r);
-    const T* yp = yin + (size_t)b * C * HW + pix;
+    load_column<CMAX, T>(rs, t.so, SB, C, r);
+    load_column<CMAX, T>(ry, t.po, PB, C, g);
+    __builtin_amdgcn_sched_barrier(0);     // (every load of the thread in flight before the first use)
+    softmax_column<CMAX, T>(C, r);
     T dot = 0;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
         if (c < C) {
-            g[c] = (T)2 * (r[c] - yp[(size_t)c * HW]);
+            g[c] = (T)2 * (r[c] - g[c]);
             dot = fma(r[c], g[c], dot);
         }
-    T* gp = gscore + (size_t)b * C * HW + pix;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-        if (c < C) gp[(size_t)c * HW] = r[c] * (g[c] - dot);
+        if (c < C) g[c] = r[c] * (g[c] - dot);
+    store_column<CMAX, T>(rg, t.po, PB, C, g);
 }
 
 // grad = gthrough - 2 (r - y)  (gthrough = the part of dE/dy that flows back through the DAE);
@@ -163,34 +219,32 @@ __global__ __launch_bounds__(256) void grad_update_kernel(const T* __restrict__ 
                                                           int SW, int sy0, int sx0, int H, int W,
                                                           T step) {
     __shared__ double red[4];
-    const int HW = H * W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
+    const int HW = H * W, b = blockIdx.y;
+    const unsigned SB = (unsigned)(SH * SW) * (unsigned)sizeof(T), PB = (unsigned)HW * (unsigned)sizeof(T);
     const bool act = active[b] != 0;
-    T nrm = 0;
-    if (pix < HW) {
-        const int y = pix / W, x = pix - y * W;
-        const size_t SHW = (size_t)SH * SW;
-        const T* sp = score + (size_t)b * C * SHW + (size_t)(sy0 + y) * SW + sx0 + x;
-        T r[CMAX];
-        load_softmax<CMAX, T>(sp, SHW, C, r);
-        T* yp = yio + (size_t)b * C * HW + pix;
-        const T* gp = gthrough + (size_t)b * C * HW + pix;
-        T ss = 0;
+    const TailPix t = tail_pixel<T>(SW, sy0, sx0, H, W);
+    const __amdgpu_buffer_rsrc_t rs = t_rsrc(score + (size_t)b * C * SH * SW, (unsigned)C * SB);
+    const __amdgpu_buffer_rsrc_t rg = t_rsrc(gthrough + (size_t)b * C * HW, (unsigned)C * PB);
+    const __amdgpu_buffer_rsrc_t ry = t_rsrc(yio + (size_t)b * C * HW, (unsigned)C * PB);
+    T r[CMAX], yv[CMAX], gt[CMAX];
+    load_column<CMAX, T>(rs, t.so, SB, C, r);
+    load_column<CMAX, T>(ry, t.po, PB, C, yv);
+    load_column<CMAX, T>(rg, t.po, PB, C, gt);
+    __builtin_amdgcn_sched_barrier(0);     // (every load of the thread in flight before the first use)
+    softmax_column<CMAX, T>(C, r);
+    T ss = 0;
 #pragma unroll
-        for (int c = 0; c < CMAX; ++c)
-            if (c < C) {
-                const T yv = yp[(size_t)c * HW];
-                const T g = gp[(size_t)c * HW] - (T)2 * (r[c] - yv);
-                ss = fma(g, g, ss);
-                if (act) {
-                    T yn = yv - step * g;
-                    yn = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);
-                    yp[(size_t)c * HW] = yn;
-                }
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            const T g = gt[c] - (T)2 * (r[c] - yv[c]);
+            ss = fma(g, g, ss);
+            if (act) {
+                T yn = yv[c] - step * g;
+                yv[c] = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);
             }
-        nrm = sqrt_t(ss);
-    }
+        }
+    store_column<CMAX, T>(ry, act ? t.po : T_OOB, PB, C, yv);
+    const T nrm = t.inb ? sqrt_t(ss) : (T)0;
     double d = wave_sum((double)nrm);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
     __syncthreads();
@@ -224,7 +278,8 @@ int crop_softmax(void* stream, const T* score, const T* minuend, T* out, int32_t
     if (!score || !out) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
         return IISEG_ERR_SHAPE;
-    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    // (one image of every tensor is addressed with 32-bit byte offsets)
+    if (C > 32 || B > 65535 || (int64_t)C * SH * SW * (int64_t)sizeof(T) >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
         IISEG_LAUNCH((crop_softmax_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
@@ -243,7 +298,8 @@ int refine_update(void* stream, const T* score, T* y, const int32_t* active, dou
     if (y8 && (C8n * 8 < C || C8n > 4 || ((uintptr_t)y8 & 15))) return IISEG_ERR_SHAPE;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
         return IISEG_ERR_SHAPE;
-    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    // (one image of every tensor is addressed with 32-bit byte offsets)
+    if (C > 32 || B > 65535 || (int64_t)C * SH * SW * (int64_t)sizeof(T) >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
         IISEG_LAUNCH((refine_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
@@ -262,7 +318,8 @@ int sqerr_softmax_bwd(void* stream, const T* score, const T* y, T* gscore, int32
     if (!score || !y || !gscore) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
         return IISEG_ERR_SHAPE;
-    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    // (one image of every tensor is addressed with 32-bit byte offsets)
+    if (C > 32 || B > 65535 || (int64_t)C * SH * SW * (int64_t)sizeof(T) >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
         IISEG_LAUNCH((sqerr_softmax_bwd_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream,
@@ -280,7 +337,8 @@ int grad_update(void* stream, const T* score, const T* gthrough, T* y, const int
     if (!score || !gthrough || !y || !active || !partial) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || sy0 < 0 || sx0 < 0 || sy0 + H > SH || sx0 + W > SW)
         return IISEG_ERR_SHAPE;
-    if (C > 32 || B > 65535) return IISEG_ERR_UNSUPPORTED;
+    // (one image of every tensor is addressed with 32-bit byte offsets)
+    if (C > 32 || B > 65535 || (int64_t)C * SH * SW * (int64_t)sizeof(T) >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     const dim3 grid((H * W + 255) / 256, B);
     if (C <= 16)
         IISEG_LAUNCH((grad_update_kernel<16, T>), grid, dim3(256), 0, (hipStream_t)stream, score,
