@@ -455,6 +455,22 @@ typedef struct iiseg_deconv_desc {
 int iiseg_deconv_f32(void* stream, const iiseg_deconv_desc* d, const float* x, const float* w,
                      const float* bias, const float* add, float* out);
 
+/* The same layer by output phase (csrc/deconv_phase.hip): K = 2 * stride, stride 2 or 8, at most 16 channels
+ * on either side -- the three FCN-8 upsamplers (models/fcn8.py:90,100,109).  A thread owns an input position
+ * and a row phase; the weights are scalar operands.  Same sums in the same order as iiseg_deconv_*.
+ * iiseg_deconv_phase_supported: 1 when the request (with / without a skip tensor, f32 / f64) has this form;
+ * iiseg_deconv_phase_weight_elems: elements of the packed weight buffer [py][dy][dx][Cin][px][Cout padded];
+ * iiseg_deconv_phase_pack_*: W[Cin][Cout][K][K] -> that buffer (once per layer);
+ * iiseg_deconv_phase_*: the launch, arguments as iiseg_deconv_* with the packed weights for w. */
+int iiseg_deconv_phase_supported(const iiseg_deconv_desc* d, int has_add, int is_f64);
+int64_t iiseg_deconv_phase_weight_elems(const iiseg_deconv_desc* d);
+int iiseg_deconv_phase_pack_f32(void* stream, const iiseg_deconv_desc* d, const float* w, float* wp);
+int iiseg_deconv_phase_pack_f64(void* stream, const iiseg_deconv_desc* d, const double* w, double* wp);
+int iiseg_deconv_phase_f32(void* stream, const iiseg_deconv_desc* d, const float* x, const float* wp,
+                           const float* bias, const float* add, float* out);
+int iiseg_deconv_phase_f64(void* stream, const iiseg_deconv_desc* d, const double* x, const double* wp,
+                           const double* bias, const double* add, double* out);
+
 /* ---------------------------------------------------------------------------------------
  * Channel softmax of a center-cropped score map.  Replaces the crop + dimshuffle + reshape +
  * softmax + reshape + dimshuffle tail of models/fcn8.py:115-130,187-191 and

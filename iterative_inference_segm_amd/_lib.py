@@ -115,6 +115,12 @@ SIGNATURES = {
     'iiseg_unpool_eqmask_window_f32': (C.c_int, [_vp] * 5 + [_i32] * 7),
     'iiseg_unpool_eqmask_window_f64': (C.c_int, [_vp] * 5 + [_i32] * 7),
     'iiseg_deconv_f32': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),
+    'iiseg_deconv_phase_supported': (C.c_int, [C.POINTER(DeconvDesc), C.c_int, C.c_int]),
+    'iiseg_deconv_phase_weight_elems': (C.c_int64, [C.POINTER(DeconvDesc)]),
+    'iiseg_deconv_phase_pack_f32': (C.c_int, [_vp, C.POINTER(DeconvDesc), _vp, _vp]),
+    'iiseg_deconv_phase_pack_f64': (C.c_int, [_vp, C.POINTER(DeconvDesc), _vp, _vp]),
+    'iiseg_deconv_phase_f32': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),
+    'iiseg_deconv_phase_f64': (C.c_int, [_vp, C.POINTER(DeconvDesc)] + [_vp] * 5),
     'iiseg_crop_softmax_f32': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8),
     'iiseg_refine_partials': (C.c_int, [_i32, _i32]),
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),

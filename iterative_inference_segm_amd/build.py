@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libiiseg_hip.so')
-SOURCES = ['abi.hip', 'conv_igemm.hip', 'conv_taps.hip', 'conv_wino.hip', 'conv_wino_bf16.hip', 'conv_halo.hip', 'conv_small.hip', 'conv_halo_bf16.hip', 'conv_c8_bf16.hip', 'conv_c8_m16.hip', 'conv1x1_c8.hip', 'conv_f64.hip', 'conv_halo_f64.hip', 'conv_wino_f64.hip', 'pool_unpool.hip', 'deconv.hip', 'tail.hip', 'metrics.hip', 'bn.hip']
+SOURCES = ['abi.hip', 'conv_igemm.hip', 'conv_taps.hip', 'conv_wino.hip', 'conv_wino_bf16.hip', 'conv_halo.hip', 'conv_small.hip', 'conv_halo_bf16.hip', 'conv_c8_bf16.hip', 'conv_c8_m16.hip', 'conv1x1_c8.hip', 'conv_f64.hip', 'conv_halo_f64.hip', 'conv_wino_f64.hip', 'pool_unpool.hip', 'deconv.hip', 'deconv_phase.hip', 'tail.hip', 'metrics.hip', 'bn.hip']
 ARCH = 'gfx950'
 
 

@@ -1108,6 +1108,9 @@ class Conv:
         return out
 
 
+DECONV_PHASE = True      # K = 2 stride layers on the output-phase kernel (csrc/deconv_phase.hip)
+
+
 class Deconv:
     """Small-channel transposed convolution (Lasagne Deconv2DLayer W[in,out,k,k], P3)."""
 
@@ -1119,6 +1122,8 @@ class Deconv:
         if k2 != self.K:
             raise RuntimeError('square kernels only')
         self.stride = int(stride)
+        self._wp = None             # weights packed for the output-phase kernel (first call)
+        self.last_form = None
 
     def out_hw(self, H, W):
         return (H - 1) * self.stride + self.K, (W - 1) * self.stride + self.K
@@ -1139,8 +1144,21 @@ class Deconv:
                 raise RuntimeError('add tensor shape %s' % (tuple(add.shape),))
         if out is None:
             out = torch.empty((B, self.Cout, OH, OW), dtype=dt, device=x.device)
+        lib = _lib.load()
+        # K = 2 stride (the FCN-8 upsamplers): the output-phase kernel, weights packed once per layer
+        if DECONV_PHASE and lib.iiseg_deconv_phase_supported(C.byref(d), 0 if add is None else 1,
+                                                             1 if dt == torch.float64 else 0):
+            if self._wp is None:
+                self._wp = torch.empty(lib.iiseg_deconv_phase_weight_elems(C.byref(d)), dtype=dt, device=x.device)
+                check(_fn('deconv_phase_pack', dt)(_stream(), C.byref(d), _ptr(self.W, dt), _ptr(self._wp, dt)),
+                      'iiseg_deconv_phase_pack')
+            check(_fn('deconv_phase', dt)(_stream(), C.byref(d), _ptr(x, dt), _ptr(self._wp, dt),
+                                          _ptr(self.b, dt), _ptr(add, dt), _ptr(out, dt)), 'iiseg_deconv_phase')
+            self.last_form = 'phase'
+            return out
         check(_fn('deconv', dt)(_stream(), C.byref(d), _ptr(x, dt), _ptr(self.W, dt),
                                 _ptr(self.b, dt), _ptr(add, dt), _ptr(out, dt)), 'iiseg_deconv')
+        self.last_form = 'gather'
         return out
 
 

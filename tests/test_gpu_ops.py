@@ -385,6 +385,56 @@ def test_deconv_flip_and_crop_add(ops, k, s, H, W):
     assert np.abs(got2 - ref2).max() <= 1e-5 * (1 + np.abs(ref2).max())
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'f64'])
+@pytest.mark.parametrize('case', [  # k, s, B, Cin, Cout, H, W, window (None = full), add
+    (16, 8, 3, 11, 11, 9, 11, None, False), (16, 8, 2, 11, 11, 9, 11, (19, 27, 40, 37), False),
+    (16, 8, 2, 5, 16, 4, 3, (1, 2, 30, 21), False), (16, 8, 1, 11, 11, 31, 31, (31, 31, 224, 224), False),
+    (4, 2, 3, 11, 11, 7, 9, None, False), (4, 2, 2, 11, 11, 7, 9, (3, 1, 11, 14), True),
+    (4, 2, 2, 16, 13, 16, 5, (0, 5, 34, 6), True), (4, 2, 70, 11, 11, 3, 3, None, True)])
+def test_deconv_output_phase_kernel(ops, case, dtype, monkeypatch):
+    """K = 2 stride layers (the three FCN-8 upsamplers, models/fcn8.py:90,100,109) run on the output-phase
+    kernel (csrc/deconv_phase.hip): exact on integer data against the oracle, and the same bits as the gather
+    kernel on random data -- same sums in the same order -- for full maps, windows that start and end inside a
+    phase period, a fused skip tensor (stride 2), float32 and float64."""
+    k, s, B, Cin, Cout, H, W, window, with_add = case
+    dt = torch.float32 if dtype == 'f32' else torch.float64
+    npdt = np.float32 if dtype == 'f32' else np.float64
+    rng = np.random.default_rng(k + H)
+    fh, fw = (H - 1) * s + k, (W - 1) * s + k
+    oy0, ox0, oh, ow = window if window is not None else (0, 0, fh, fw)
+    for integer in (True, False):
+        if integer:
+            x = rng.integers(-3, 4, (B, Cin, H, W)).astype(npdt)
+            Wt = rng.integers(-2, 3, (Cin, Cout, k, k)).astype(npdt)
+            b = rng.integers(-2, 3, Cout).astype(npdt)
+            other = rng.integers(-5, 6, (B, Cout, oh + 3, ow + 2)).astype(npdt)
+        else:
+            x, Wt, b = rnd(rng, B, Cin, H, W).astype(npdt), rnd(rng, Cin, Cout, k, k).astype(npdt), rnd(rng, Cout).astype(npdt)
+            other = rnd(rng, B, Cout, oh + 3, ow + 2).astype(npdt)
+        d = ops.Deconv(Wt, b, s, dtype=dt)
+        kw = dict(window=(oy0, ox0, oh, ow))
+        if with_add:
+            kw.update(add=torch.from_numpy(other).cuda(), add_off=(2, 1))
+        xd = torch.from_numpy(x).cuda()
+        got = host(d(xd, **kw))
+        assert d.last_form == 'phase'
+        monkeypatch.setattr(ops, 'DECONV_PHASE', False)
+        gather = host(d(xd, **kw))
+        assert d.last_form == 'gather'
+        monkeypatch.setattr(ops, 'DECONV_PHASE', True)
+        assert np.array_equal(got, gather), np.abs(got - gather).max()
+        if integer:
+            ref = onn.deconv2d(x.astype(np.float64), Wt.astype(np.float64), b.astype(np.float64), stride=s)
+            ref = ref[:, :, oy0:oy0 + oh, ox0:ox0 + ow]
+            if with_add:
+                ref = ref + other[:, :, 2:2 + oh, 1:1 + ow]
+            assert np.array_equal(got.astype(np.float64), ref)
+    # placement: a caller's output buffer is written inside the window only
+    out = torch.full((B, Cout, oh, ow), -9.0, dtype=dt, device='cuda')
+    d(xd, out=out, **kw)
+    assert np.array_equal(host(out), got)
+
+
 def test_deconv_21_classes(ops):
     """The reference's default n_classes=21 (models/fcn8.py:17): the gather-form transposed conv
     takes up to 32 channels (the 32-channel instantiation), k16 s8 and k4 s2."""
