@@ -163,6 +163,17 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv1x1_c8_kernel(const 
     }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // The lane's bias values, all loaded before the first store (index clamped, not branched): a load placed
+    // between two stores stays there -- one memory round trip per output element otherwise.
+    float bias_r[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            bias_r[i][r] = p.bias ? p.bias[co < p.Cout ? co : p.Cout - 1] : 0.f;
+        }
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (POOL) {
         if (!valid[0]) return;
         const size_t qpl = (size_t)p.QH * p.QW;
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv1x1_c8_kernel(const 
                     const int co = cbase + 4 * g + k;
                     const float v = fmaxf(fmaxf(acc[i][0][r], acc[i][1][r]), fmaxf(acc[i][2][r], acc[i][3][r]));
                     // channels the layer does not have stay exact zeros (padding of the chunk)
-                    m[k] = co < p.Cout ? v + (p.bias ? p.bias[co] : 0.f) : 0.f;
+                    m[k] = co < p.Cout ? v + bias_r[i][r] : 0.f;
                 }
                 u32x2 w2;
                 w2[0] = pack_bf16(m[0], m[1]);
@@ -189,19 +200,24 @@ __global__ __launch_bounds__(256, TM == 1 ? 3 : 2) void conv1x1_c8_kernel(const 
                 *reinterpret_cast<u32x2*>(ob8 + (size_t)(cbase >> 3) * qpl * 16) = w2;
             }
     } else {
-        float* outf = (float*)p.out;
+        // (stores through a buffer descriptor, the out-of-range offset instead of a branch per element: behind
+        // per-lane branches hipcc waits for the previous store before every next one)
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+            p.out, 0, (int)((unsigned)p.N * (unsigned)p.Cout * 4u), 0x00027000);
 #pragma unroll
         for (int q = 0; q < TN; ++q) {
-            if (!valid[q]) continue;
             const int px = pt * 512 + wave * 128 + q * 32 + col;
-            const int b = px / HW, pix = px - b * HW;
+            const int pp = valid[q] ? px : 0;
+            const int b = pp / HW, pix = pp - b * HW;
+            const unsigned o0 = (unsigned)(b * p.Cout * HW + pix) * 4u;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                    if (co < p.Cout)
-                        outf[((size_t)b * p.Cout + co) * HW + pix] = acc[i][q][r] + (p.bias ? p.bias[co] : 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, acc[i][q][r] + bias_r[i][r]), ro,
+                        (int)((valid[q] && co < p.Cout) ? o0 + (unsigned)(co * HW) * 4u : 0x80000000u), 0, 0);
                 }
         }
     }
@@ -280,7 +296,8 @@ extern "C" int iiseg_conv1x1_c8(void* stream, const void* x, int B, int Cin, int
         const dim3 grid(p.n_ptiles * p.n_mtiles);
         if (bn_a) C1X1_LAUNCH(true, true); else C1X1_LAUNCH(true, false);
     } else {
-        // fp32 NCHW output (B, Cout, H, W)
+        // fp32 NCHW output (B, Cout, H, W), addressed with 32-bit byte offsets
+        if ((int64_t)B * H * W * Cout * 4 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
         p.N = B * H * W;
         p.n_ptiles = (p.N + 511) / 512;
         const dim3 grid(p.n_ptiles * p.n_mtiles);

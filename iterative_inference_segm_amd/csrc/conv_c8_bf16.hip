@@ -877,8 +877,11 @@ __global__ __launch_bounds__(256) void nchw_to_c8_kernel(const float* __restrict
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // (unconditional loads, channels past C clamped and zeroed afterwards: a conditional load sits in a
+            // basic block of its own behind a full wait -- eight memory round trips in a row)
             const int c = c8 * 8 + j;
-            v[j] = c < C ? x[(b * C + c) * HW + pix] : 0.f;
+            const float t8 = x[(b * C + (c < C ? c : C - 1)) * HW + pix];
+            v[j] = c < C ? t8 : 0.f;
         }
         const uint4 hi = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]),
                                     pack_bf16(v[6], v[7]));

@@ -267,8 +267,12 @@ __global__ __launch_bounds__(NT) void wino_input_lds_kernel(const WinoParams p, 
         } else {
             const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
                                         : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+            // (unconditional loads at clamped offsets, masked afterwards -- as above: one batch in flight)
+            float pv[ILDS_E];
 #pragma unroll
-            for (int i = 0; i < ILDS_E; ++i) v[i] = goff[i] >= 0 ? src[goff[i]] : 0.f;
+            for (int i = 0; i < ILDS_E; ++i) pv[i] = src[goff[i] >= 0 ? goff[i] : 0];
+#pragma unroll
+            for (int i = 0; i < ILDS_E; ++i) v[i] = goff[i] >= 0 ? pv[i] : 0.f;
         }
     };
 
@@ -607,6 +611,17 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const Wi
     typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
     const int ntt = p.nty * p.ntx;
     const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    // The tile's BM bias values go through LDS (free after the last k-tile's barrier): read from global per
+    // (i, r) each of them is a vector load that cannot move above the stores in front of it -- 16 TM TN
+    // dependent memory round trips at the end of every workgroup; LDS reads are not held back by global stores.
+    float* Lbias = &As[0][0][0];
+    for (int f = tid; f < BM; f += NT) Lbias[f] = (p.bias && m0 + f < p.Cout) ? p.bias[m0 + f] : 0.f;
+    __syncthreads();
+    float bias_r[TM][16];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[i][r] = Lbias[wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int t = t0 + wn * WTN + j * 32 + l31;
@@ -629,7 +644,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINW) void wino_fused_kernel(const Wi
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Cout) continue;
-                const float bias = p.bias ? p.bias[co] : 0.f;
+                const float bias = bias_r[i][r];
                 float* oc = ob + (size_t)co * OPL;
                 const float* ac = ab ? ab + (size_t)co * APL : nullptr;
 #pragma unroll

@@ -293,8 +293,11 @@ __global__ __launch_bounds__(NT) void wino_input_lds_bf16_kernel(const WinoBfPar
         } else {
             const float* src = c < p.C1 ? p.x1 + ((size_t)b * p.C1 + c) * HW
                                         : p.x2 + ((size_t)b * p.C2 + (c - p.C1)) * HW;
+            float pv[IBF_E];                   // (unconditional loads at clamped offsets, masked afterwards)
 #pragma unroll
-            for (int i = 0; i < IBF_E; ++i) v[i] = goff[i] >= 0 ? src[goff[i]] : 0.f;
+            for (int i = 0; i < IBF_E; ++i) pv[i] = src[goff[i] >= 0 ? goff[i] : 0];
+#pragma unroll
+            for (int i = 0; i < IBF_E; ++i) v[i] = goff[i] >= 0 ? pv[i] : 0.f;
         }
     };
 
@@ -1066,7 +1069,8 @@ __global__ __launch_bounds__(256) void gemm_im2col_bf16_kernel(const float* __re
             const int k = kc * 8 + j;
             const int c = k / KK, tap = k - c * KK;
             const int ky = tap / KW, kx = tap - ky * KW;
-            v[j] = k < K ? xb[(size_t)c * H * W + ky * W + kx] : 0.f;
+            const float t8 = xb[k < K ? (size_t)c * H * W + ky * W + kx : 0];     // (no conditional loads)
+            v[j] = k < K ? t8 : 0.f;
         }
         V[(size_t)kc * Tpad + t] = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
                                               pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));

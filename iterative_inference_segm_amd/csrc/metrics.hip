@@ -4,13 +4,18 @@
 // Replaces val_fn (reference iterative_inference.py:206-210): metrics.py:11-37 (jaccard's 121
 // masked reductions), :40-65 (accuracy), :144-156 (squared_error).
 #include "common.h"
+#include "column_io.h"
 
 namespace {
 
 constexpr int MAXC = 32;
 constexpr int PPT = 8;   // pixels per thread
 
-template <typename T>
+// CMAX: planes of a pixel held in registers (C + 1 <= CMAX).  The C prediction and C + 1 target values of a pixel
+// are loaded as two channel columns through buffer descriptors (column_io.h) -- all in flight before the
+// first compare; with a run-time channel loop the loads went out two at a time, each pair waited for
+// (0.115 ms for 295 MB).
+template <typename T, int CMAX>
 __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
                                                         const T* __restrict__ t,
                                                         const int* __restrict__ active,
@@ -26,32 +31,42 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
     // images whose flag is 0 are skipped (per-iteration metrics of the validation driver only
     // count images still being refined, iterative_inference_valid.py:280-288)
     const bool on = !active || active[b] != 0;
+    const unsigned PB = (unsigned)HW * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t ry = t_rsrc(y + (size_t)b * C * HW, (unsigned)C * PB);
+    const __amdgpu_buffer_rsrc_t rt = t_rsrc(t + (size_t)b * (C + 1) * HW, (unsigned)(C + 1) * PB);
     // PPT pixels per thread: 8x fewer blocks, i.e. 8x fewer global atomics on the two `sums` words
     // and the bins every block ends with (12 544 blocks hitting two addresses made this kernel 5x
     // slower than its 0.3 GB of traffic)
-#pragma unroll 2
+#pragma unroll 1
     for (int q = 0; q < PPT; ++q) {
-    const int pix = (blockIdx.x * PPT + q) * 256 + threadIdx.x;
-    if (pix < HW && on) {
-        const T* yp = y + (size_t)b * C * HW + pix;
-        const T* tp = t + (size_t)b * (C + 1) * HW + pix;
+        const int pix = (blockIdx.x * PPT + q) * 256 + threadIdx.x;
+        const bool live = pix < HW && on;
+        T yv[CMAX], tv[CMAX];
+        load_column<CMAX, T>(ry, live ? (unsigned)pix * (unsigned)sizeof(T) : T_OOB, PB, C, yv);
+        load_column<CMAX, T>(rt, live ? (unsigned)pix * (unsigned)sizeof(T) : T_OOB, PB, C + 1, tv);
+        __builtin_amdgcn_sched_barrier(0);
         // argmax returns the FIRST maximal index (T.argmax / np.argmax)
         int ip = 0, it = 0;
-        T bp = yp[0], bt = tp[0];
+        T bp = yv[0], bt = tv[0];
         T msum = 0, esum = 0;
-        for (int c = 0; c < C; ++c) {
-            const T yv = yp[(size_t)c * HW], tv = tp[(size_t)c * HW];
-            if (yv > bp) { bp = yv; ip = c; }
-            if (tv > bt) { bt = tv; it = c; }
-            msum += tv;                       // mask = y_true[:, :void].sum(1)   metrics.py:148
-            esum = fma(yv - tv, yv - tv, esum);
-        }
-        const T tvoid = tp[(size_t)C * HW];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+            if (c < C) {
+                if (yv[c] > bp) { bp = yv[c]; ip = c; }
+                if (tv[c] > bt) { bt = tv[c]; it = c; }
+                msum += tv[c];                    // mask = y_true[:, :void].sum(1)   metrics.py:148
+                esum = fma(yv[c] - tv[c], yv[c] - tv[c], esum);
+            }
+        T tvoid = 0;
+#pragma unroll
+        for (int c = 1; c < CMAX; ++c)
+            if (c == C) tvoid = tv[c];
         if (tvoid > bt) it = C;
-        atomicAdd(&bins[ip * (C + 1) + it], 1u);
-        se += (double)(esum / (T)C) * (double)msum;  // .mean(axis=1) * mask   :147,153
-        mk += (double)msum;
-    }
+        if (live) {
+            atomicAdd(&bins[ip * (C + 1) + it], 1u);
+            se += (double)(esum / (T)C) * (double)msum;  // .mean(axis=1) * mask   :147,153
+            mk += (double)msum;
+        }
     }
     se = wave_sum(se);
     mk = wave_sum(mk);
@@ -73,10 +88,15 @@ int confusion(void* stream, const T* y, const T* t, const int32_t* active, int64
               int32_t B, int32_t C, int32_t HW) {
     if (!y || !t || !cm || !sums) return IISEG_ERR_NULL;
     if (B <= 0 || C <= 0 || HW <= 0) return IISEG_ERR_SHAPE;
-    if (C >= MAXC || B > 65535) return IISEG_ERR_UNSUPPORTED;
-    IISEG_LAUNCH(confusion_kernel<T>, dim3((HW + 256 * PPT - 1) / (256 * PPT), B), dim3(256), 0,
-                       (hipStream_t)stream, y, t, active,
-                       reinterpret_cast<unsigned long long*>(cm), sums, C, HW);
+    // (one image of either tensor is addressed with 32-bit byte offsets)
+    if (C >= MAXC || B > 65535 || (int64_t)(C + 1) * HW * (int64_t)sizeof(T) >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
+    const dim3 grid((HW + 256 * PPT - 1) / (256 * PPT), B);
+    if (C + 1 <= 16)
+        IISEG_LAUNCH((confusion_kernel<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, y, t, active,
+                     reinterpret_cast<unsigned long long*>(cm), sums, C, HW);
+    else
+        IISEG_LAUNCH((confusion_kernel<T, 32>), grid, dim3(256), 0, (hipStream_t)stream, y, t, active,
+                     reinterpret_cast<unsigned long long*>(cm), sums, C, HW);
     return iiseg_check_launch();
 }
 
