@@ -346,6 +346,16 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
                     const int r = h * RN + rr;
                     bv[rr] = buf_ld(r_bias, 4u * (unsigned)(m0 + wmr * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh), 0);
                 }
+                // the skip-add pieces of the round's NSP store passes, in flight while the tile goes through
+                // LDS (loaded inside the pass each of them followed the previous pass's store: a load cannot
+                // move above an earlier store -- NSP memory round trips in a row)
+                f32x4 a4r[NSP];
+#pragma unroll
+                for (int k = 0; k < NSP; ++k) {
+                    const bool ok = s_ok && m0 + cb + CPP * k + s_c < p.Cout;
+                    a4r[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        r_add, (int)((p.add && ok && s_nv == 4) ? s_add0 + 4u * (unsigned)((cb + CPP * k) * APL) : OOB), 0, 0));
+                }
                 __syncthreads();                   // previous users of these LDS bytes are done
                 if (wm == wmr) {
 #pragma unroll
@@ -367,11 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_f32_kernel(const ConvParams 
                     f32x4 v = *reinterpret_cast<const f32x4*>(Cs + (c * TH + s_row) * 32 + s_x4);
                     const unsigned oo = s_out0 + 4u * (unsigned)((cb + CPP * k) * OPL);
                     const unsigned ao = s_add0 + 4u * (unsigned)((cb + CPP * k) * APL);
-                    if (p.add) {
-                        const f32x4 a4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            r_add, (int)((ok && s_nv == 4) ? ao : OOB), 0, 0));
-                        v += a4;
-                    }
+                    if (p.add) v += a4r[k];
                     if (ok && s_nv < 4) {          // ragged right edge of the window: element by element
                         for (int e = 0; e < s_nv; ++e) {
                             float t = v[e];
