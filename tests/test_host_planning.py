@@ -74,3 +74,45 @@ def test_kernel_form_queries_follow_the_layer_not_the_window(lib):
     d = desc(2, 64, 60, 70, 128, dil=2)
     assert lib.iiseg_conv_plan_f64(C.byref(d)) == 0
     assert lib.iiseg_conv_halo_f64_supported(C.byref(d)) == 0   # dilated float64: the static-tap kernel
+
+
+def test_deconv_output_phase_form_is_a_function_of_the_layer(lib):
+    """iiseg_deconv_phase_supported: K = 2 stride at stride 2 / 8 with at most 16 channels on either side (the three
+    FCN-8 upsamplers, models/fcn8.py:90,100,109) -- whatever the batch, the map or the window, so a window and the
+    full map of a layer come from the same kernel; a skip tensor only at stride 2; packed-weight size
+    [stride][2][2][Cin][stride][Cout padded to 12 / 16]."""
+    from iterative_inference_segm_amd._lib import DeconvDesc
+
+    def dd(B, Cin, H, W, Cout, K, s, window=None):
+        d = DeconvDesc()
+        d.B, d.Cin, d.H, d.W, d.Cout, d.K, d.stride = B, Cin, H, W, Cout, K, s
+        fh, fw = (H - 1) * s + K, (W - 1) * s + K
+        d.oy0, d.ox0, d.OH, d.OW = window if window is not None else (0, 0, fh, fw)
+        return d
+
+    for B in (1, 10, 64):
+        for hw in (3, 28, 60):
+            for win in (None, (1, 2, 5, 7)):
+                assert lib.iiseg_deconv_phase_supported(C.byref(dd(B, 11, hw, hw, 11, 16, 8, win)), 0, 0) == 1
+                assert lib.iiseg_deconv_phase_supported(C.byref(dd(B, 11, hw, hw, 11, 16, 8, win)), 0, 1) == 1
+                assert lib.iiseg_deconv_phase_supported(C.byref(dd(B, 11, hw, hw, 11, 16, 8, win)), 1, 0) == 0
+                assert lib.iiseg_deconv_phase_supported(C.byref(dd(B, 11, hw, hw, 11, 4, 2, win)), 1, 0) == 1
+    assert lib.iiseg_deconv_phase_supported(C.byref(dd(2, 11, 8, 8, 11, 3, 2)), 0, 0) == 0      # K != 2 stride
+    assert lib.iiseg_deconv_phase_supported(C.byref(dd(2, 11, 8, 8, 11, 8, 4)), 0, 0) == 0      # stride 4: no form
+    assert lib.iiseg_deconv_phase_supported(C.byref(dd(2, 21, 8, 8, 21, 4, 2)), 0, 0) == 0      # 21 classes: gather
+    assert lib.iiseg_deconv_phase_weight_elems(C.byref(dd(2, 11, 8, 8, 11, 16, 8))) == 8 * 4 * 11 * 8 * 12
+    assert lib.iiseg_deconv_phase_weight_elems(C.byref(dd(2, 5, 8, 8, 16, 4, 2))) == 2 * 4 * 5 * 2 * 16
+    assert lib.iiseg_deconv_phase_weight_elems(C.byref(dd(2, 11, 8, 8, 11, 3, 2))) == 0
+
+
+def test_relaxed_nan_flag_stays_off_the_sources_that_use_nan():
+    """build.EXTRA_FLAGS: -fno-honor-nans only on sources whose kernels never use NaN as a value -- the float64
+    Winograd transforms mark 'outside the pooled map' with a NaN that must never compare equal."""
+    import os
+    from iterative_inference_segm_amd import build
+    for src, flags in build.EXTRA_FLAGS.items():
+        assert src in build.SOURCES
+        if '-fno-honor-nans' in flags:
+            text = open(os.path.join(build.CSRC, src)).read()
+            assert '__builtin_nan' not in text and 'isnan' not in text and 'NAN' not in text, src
+    assert 'conv_wino_f64.hip' not in build.EXTRA_FLAGS
