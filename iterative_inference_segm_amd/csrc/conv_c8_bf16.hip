@@ -520,25 +520,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             ab[j] = eok[j] ? apix * 16u + 8u * lh : OOB;
         }
         const float rfloor = p.relu ? 0.f : -__builtin_inff();
+        // (every load first: a buffer load cannot move above an earlier buffer store.  Plain mode: the skip
+        // pieces of BOTH 32-channel blocks before the first store -- one memory round trip per workgroup instead
+        // of one per block; the pair mode loads per block, twice the pieces)
+        constexpr int AB = X3 ? 1 : TM;              // blocks whose addend pieces are in flight together
+        u32x2 adA[AB][4][TN], adl[X3 ? 4 : 1][TN];
+        auto load_add = [&](int i, int slot) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            // (every load of the block first: a buffer load cannot move above an earlier buffer store)
-            u32x2 ad[4][TN], adl[X3 ? 4 : 1][TN];
-            if constexpr (EPI == EPI_STORE_ADD) {
+            for (int g = 0; g < 4; ++g) {
+                const int c8 = ((m0 + i * 32) >> 3) + g;
+                const int so_a = (int)((unsigned)(c8 * APL) * 16u);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c8 = ((m0 + i * 32) >> 3) + g;
-                    const int so_a = (int)((unsigned)(c8 * APL) * 16u);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        ad[g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                            r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a, 0));
-                        if constexpr (X3)
-                            adl[g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                                r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a + (int)((unsigned)(co8 * APL) * 16u), 0));
-                    }
+                for (int j = 0; j < TN; ++j) {
+                    adA[slot][g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                        r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a, 0));
+                    if constexpr (X3)
+                        adl[g][j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
+                            r_add, (int)(c8 < co8 ? ab[j] : OOB), so_a + (int)((unsigned)(co8 * APL) * 16u), 0));
                 }
             }
+        };
+        if constexpr (EPI == EPI_STORE_ADD && !X3) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_add(i, i);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (EPI == EPI_STORE_ADD && X3) load_add(i, 0);
+            auto& ad = adA[X3 ? 0 : i];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;

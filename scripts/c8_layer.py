@@ -47,7 +47,11 @@ if kind == 'unpool':
     h2 = H // 2
     up8 = ops.nchw_to_c8(torch.rand(B, cin, h2, h2, device='cuda', generator=g))
     mask = torch.randint(0, 16, (B, ops.c8_chunks(cin), h2, h2, 8), device='cuda', generator=g, dtype=torch.uint8)
-    f = lambda: conv(up8, mask_in=mask, unpool_hw=(H, H), window=window)
+    # (the decoder layers of the bench config carry a skip tensor: the store + bf16 C8 addend epilogue)
+    fh = H + 2 * pad - 2
+    skip8 = ops.nchw_to_c8(torch.rand(B, cout, fh, fh, device='cuda', generator=g)) if cout > 16 else None
+    f = (lambda: conv(up8, mask_in=mask, unpool_hw=(H, H), window=window, add=skip8, add_off=(org, org))) \
+        if skip8 is not None else (lambda: conv(up8, mask_in=mask, unpool_hw=(H, H), window=window))
 else:
     x8 = ops.nchw_to_c8(torch.rand(B, cin, H, H, device='cuda', generator=g))
     fh = H + 2 * pad - 2
