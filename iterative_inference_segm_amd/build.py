@@ -77,7 +77,7 @@ def _hipcc_version(hipcc):
     return _HIPCC_VERSION[hipcc]
 
 
-# Per-source flags.  The bf16 C8 kernels are compiled with relaxed NaN handling: their ReLU / max-pool
+# Per-source flags.  The bf16 C8 kernels (and the fp32 halo / Winograd kernels) are compiled with relaxed NaN handling: their ReLU / max-pool
 # epilogues are v_max_f32 straight on MFMA results, and under strict NaN rules hipcc puts a quieting pass
 # (v_max_f32 v, v, v) in front of every one of them and cannot fold the lane exchange of the pool into the
 # max (conv1_1 of the DAE: 725 -> 589 vector instructions per wave).  Results for non-NaN data are the same
