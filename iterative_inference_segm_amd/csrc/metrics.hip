@@ -5,6 +5,7 @@
 // masked reductions), :40-65 (accuracy), :144-156 (squared_error).
 #include "common.h"
 #include "column_io.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -37,36 +38,52 @@ __global__ __launch_bounds__(256) void confusion_kernel(const T* __restrict__ y,
     // PPT pixels per thread: 8x fewer blocks, i.e. 8x fewer global atomics on the two `sums` words
     // and the bins every block ends with (12 544 blocks hitting two addresses made this kernel 5x
     // slower than its 0.3 GB of traffic)
-#pragma unroll 1
-    for (int q = 0; q < PPT; ++q) {
+    // software pipeline: the 2 C + 1 loads of pixel q + 1 are in flight while pixel q is compared and binned
+    T yv[2][CMAX], tv[2][CMAX];
+    auto fetch = [&](int q, auto S) __attribute__((always_inline)) {
+        constexpr int sl = decltype(S)::value;
+        const int pix = (blockIdx.x * PPT + q) * 256 + threadIdx.x;
+        const unsigned off = (q < PPT && pix < HW && on) ? (unsigned)pix * (unsigned)sizeof(T) : T_OOB;
+        load_column<CMAX, T>(ry, off, PB, C, yv[sl]);
+        load_column<CMAX, T>(rt, off, PB, C + 1, tv[sl]);
+    };
+    auto bin = [&](int q, auto S) __attribute__((always_inline)) {
+        constexpr int sl = decltype(S)::value;
         const int pix = (blockIdx.x * PPT + q) * 256 + threadIdx.x;
         const bool live = pix < HW && on;
-        T yv[CMAX], tv[CMAX];
-        load_column<CMAX, T>(ry, live ? (unsigned)pix * (unsigned)sizeof(T) : T_OOB, PB, C, yv);
-        load_column<CMAX, T>(rt, live ? (unsigned)pix * (unsigned)sizeof(T) : T_OOB, PB, C + 1, tv);
-        __builtin_amdgcn_sched_barrier(0);
         // argmax returns the FIRST maximal index (T.argmax / np.argmax)
         int ip = 0, it = 0;
-        T bp = yv[0], bt = tv[0];
+        T bp = yv[sl][0], bt = tv[sl][0];
         T msum = 0, esum = 0;
 #pragma unroll
         for (int c = 0; c < CMAX; ++c)
             if (c < C) {
-                if (yv[c] > bp) { bp = yv[c]; ip = c; }
-                if (tv[c] > bt) { bt = tv[c]; it = c; }
-                msum += tv[c];                    // mask = y_true[:, :void].sum(1)   metrics.py:148
-                esum = fma(yv[c] - tv[c], yv[c] - tv[c], esum);
+                if (yv[sl][c] > bp) { bp = yv[sl][c]; ip = c; }
+                if (tv[sl][c] > bt) { bt = tv[sl][c]; it = c; }
+                msum += tv[sl][c];                    // mask = y_true[:, :void].sum(1)   metrics.py:148
+                esum = fma(yv[sl][c] - tv[sl][c], yv[sl][c] - tv[sl][c], esum);
             }
         T tvoid = 0;
 #pragma unroll
         for (int c = 1; c < CMAX; ++c)
-            if (c == C) tvoid = tv[c];
+            if (c == C) tvoid = tv[sl][c];
         if (tvoid > bt) it = C;
         if (live) {
             atomicAdd(&bins[ip * (C + 1) + it], 1u);
             se += (double)(esum / (T)C) * (double)msum;  // .mean(axis=1) * mask   :147,153
             mk += (double)msum;
         }
+    };
+    static_assert(PPT % 2 == 0, "two pixels per trip");
+    fetch(0, iiseg::ic<0>{});
+#pragma unroll 1
+    for (int q = 0; q < PPT; q += 2) {
+        fetch(q + 1, iiseg::ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        bin(q, iiseg::ic<0>{});
+        fetch(q + 2, iiseg::ic<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        bin(q + 1, iiseg::ic<1>{});
     }
     se = wave_sum(se);
     mk = wave_sum(mk);
