@@ -235,10 +235,18 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
         for (int h = 0; h < 2; ++h) {
             float sa[8], sb[8];
             if constexpr (MODE == M16_BNRELU) {
-                // the 8 channels of this half: wave-uniform addresses -> scalar loads
+                // the 8 channels of this half: wave-uniform addresses, read through the CONSTANT address space so
+                // that they ARE scalar loads (s_load_dwordx8, lgkmcnt): through the generic pointers hipcc made them
+                // four global_load_dwordx4 with a full vmcnt wait in front of the LDS writes of every k-tile (the
+                // (a, b) table is written by an earlier kernel, never here).  FC-DenseNet103 forward 7.78 -> 7.32 ms;
+                // issued earlier still (with the activation loads, live across the MFMAs) they spill scalar
+                // registers: 7.32-7.62 ms
+                typedef const float __attribute__((address_space(4))) cfloat;
                 const int c0 = __builtin_amdgcn_readfirstlane((kc + h) * 8);
+                cfloat* ca = (cfloat*)(uintptr_t)p.bn_a;
+                cfloat* cb = (cfloat*)(uintptr_t)p.bn_b;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { sa[q] = p.bn_a[c0 + q]; sb[q] = p.bn_b[c0 + q]; }
+                for (int q = 0; q < 8; ++q) { sa[q] = ca[c0 + q]; sb[q] = cb[c0 + q]; }
             }
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {

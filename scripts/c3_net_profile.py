@@ -3,6 +3,9 @@ conv launch behind a blocked stream, merged by (kernel, Cin, map).  Usage: pytho
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get('AB_LIB'):          # A/B of two builds of the library in one gpurun call
+    from iterative_inference_segm_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
 from iterative_inference_segm_amd import ops, synthetic as S
 from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
 
