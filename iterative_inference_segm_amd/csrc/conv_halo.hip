@@ -677,6 +677,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
 
     // C/D layout of the 16x16 MFMA: column = lane & 15 (pixel), row = 4 * (lane >> 4) + r (channel)
     const size_t OPL = (size_t)p.out_H * p.out_W, APL = (size_t)p.AH * p.AW;
+    // (the lane's four bias values before the first store, index clamped instead of branched: loaded inside
+    // the loop each of them sat between two stores behind a full wait -- 4 TN memory round trips in a row)
+    float bias_r[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = m0 + 4 * kq + r;
+        bias_r[r] = p.bias ? p.bias[co < p.Cout ? co : p.Cout - 1] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int wy = wy0 + wave * RW + (j >> 1), wx = wx0 + (j & 1) * 16 + n;
@@ -690,8 +698,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo16_f32_kernel(const ConvParam
         for (int r = 0; r < 4; ++r) {
             const int co = m0 + 4 * kq + r;
             if (co < p.Cout) {
-                float v = acc[j][r];
-                if (p.bias) v += p.bias[co];
+                float v = acc[j][r] + bias_r[r];
                 if (addp) v += addp[(size_t)co * APL];
                 if (p.relu) v = fmaxf(v, 0.f);
                 outp[(size_t)co * OPL] = v;
