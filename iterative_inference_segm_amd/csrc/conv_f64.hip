@@ -416,6 +416,10 @@ extern "C" int iiseg_conv_mask_f64(void* stream, const iiseg_conv_desc* d, const
     hipStream_t s = (hipStream_t)stream;
     // plain 3x3 layers: the halo-tile kernel (conv_halo_f64.hip), bit-identical to the static-tap one
     if (iiseg_conv_halo_f64_ok(p, d->KH, d->KW)) return iiseg_launch_conv_halo_f64(s, p, unpool);
+    // (the static-tap kernel knows neither mask bytes nor the fused pool: a request that carries them and is
+    // refused by the halo kernel only on the limits that depend on the pointers set above -- the size of the
+    // skip-add tensor -- must not fall through to it)
+    if (mask_in || mask_out || pool_out) return IISEG_ERR_UNSUPPORTED;
     if (d->KH == 3) return launch64<3, 3, 4>(s, p, unpool);
     return launch64<1, 1, 16>(s, p, unpool);
 }

@@ -193,20 +193,29 @@ class _LaunchMark:
         return float(sum(PROFILE_MS[self.n:other.n]))
 
 
+_PROFILE_CAP = [16384]
+
+
 def profile_begin(capacity=16384):
     check(_lib.load().iiseg_profile_begin(int(capacity)), 'iiseg_profile_begin')
     _DISPATCH_TIMING[0] = True
+    _PROFILE_CAP[0] = int(capacity)
     del PROFILE_MS[:]
 
 
 def profile_end():
-    """Ends the pass and fills PROFILE_MS (one entry per launch of the library, in launch order)."""
+    """Ends the pass and fills PROFILE_MS (one entry per launch of the library, in launch order).  A pass
+    that filled the event table raises: launches past the capacity carry no events, and a roofline built
+    on such a pass would silently under-report kernel time."""
     _DISPATCH_TIMING[0] = False
-    cap = 16384
+    cap = _PROFILE_CAP[0]
     buf = (C.c_float * cap)()
     n = _lib.load().iiseg_profile_end(buf, cap)
     if n < 0:
         raise RuntimeError('iiseg_profile_end: %d' % n)
+    if n >= cap:
+        raise RuntimeError('profiling pass reached its capacity of %d launches: later launches were not '
+                           'timed (raise profile_begin(capacity))' % cap)
     PROFILE_MS[:] = list(buf[:n])
     return n
 
@@ -321,7 +330,6 @@ class Conv:
         self._U16 = None
         self._W16 = None
         self._W16c8 = None
-        self._W16c8_cin = None
         self._form_cache = {}
         self._plans = {}
         self._packs = {}
@@ -700,6 +708,23 @@ class Conv:
             ok = self._form_cache[key] = bool(supported(C.byref(full)))
         return ok
 
+    def _f64_halo_runs(self):
+        """float64: does the LIBRARY run this layer on the halo-tile kernel (the only float64 kernel with the
+        fused pool and the mask bytes)?  Asked once per layer on a representative request -- the switch
+        IISEG_F64_HALO, the packed-weight shape (Kpad % 36, Mpad % 64) -- so that `pool_fusable` / `mask_ok`
+        never promise what iiseg_conv_pool_f64 / iiseg_conv_mask_f64 would refuse."""
+        ok = self._form_cache.get('f64_halo')
+        if ok is None:
+            d = ConvDesc()
+            d.B, d.C1, d.C2, d.H, d.W = 1, self.Cin, 0, 16, 16
+            d.Cout, d.KH, d.KW, d.pad, d.dil = self.Cout, self.KH, self.KW, self.pad, self.dil
+            d.OH, d.OW = self.out_hw(16, 16)
+            d.flags = CONV_RELU if self.relu else 0
+            ok = self.lib.iiseg_conv_plan_f64(C.byref(d)) == 0 and \
+                bool(self.lib.iiseg_conv_halo_f64_supported(C.byref(d)))
+            self._form_cache['f64_halo'] = ok
+        return ok
+
     def pool_fusable(self, c8=None):
         """True if this layer runs on a halo kernel whose epilogue can do the 2x2 max-pool.  `c8`:
         whether the call will hand it a C8 tensor (None: the form the layer was built for) -- a
@@ -710,7 +735,7 @@ class Conv:
         if self.dtype == torch.float64:
             # float64: the halo-tile kernel's epilogue (conv_halo_f64.hip), layers it runs with > 16 output channels
             return F64_POOL_FUSE and (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed and \
-                not self.wino_f64 and self.Cout > 16
+                not self.wino_f64 and self.Cout > 16 and self._f64_halo_runs()
         if self.dtype != torch.float32:
             return False
         if self.c8 and c8 is not False:
@@ -728,7 +753,7 @@ class Conv:
         if self.dtype == torch.float64:
             # float64: layers of the halo-tile kernel (the mask bytes hold float64 comparisons)
             return F64_MASKS and (self.KH, self.KW) == (3, 3) and self.dil == 1 and not self.transposed and \
-                not self.wino_f64
+                not self.wino_f64 and self._f64_halo_runs()
         if self.dtype != torch.float32 or (self.KH, self.KW) != (3, 3) or self.dil != 1 or \
                 self.transposed or self.kernel != 'conv_halo_f32_kernel' or self.wino_bf16:
             return False
@@ -816,7 +841,8 @@ class Conv:
         if bn is not None:
             if len(bn) != 2 or any(t.dtype != torch.float32 or t.numel() < C1 for t in bn):
                 raise RuntimeError('bn = (a, b): float32, at least %d entries' % C1)
-        if self._W16c8 is None or self._W16c8_cin != C1:
+        if self._W16c8 is None:     # (packed once per layer, for the REAL channel count, shared with _call_c8:
+            #                          a captured graph may point at it -- never replaced after first use)
             dp = ConvDesc()
             dp.B, dp.C1, dp.C2, dp.H, dp.W = 1, self.Cin, 0, 8, 8
             dp.Cout, dp.KH, dp.KW, dp.pad, dp.dil = self.Cout, 3, 3, 1, 1
@@ -826,7 +852,6 @@ class Conv:
             check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(self.W), self.so, self.sc,
                                                 _ptr(self._W16c8, torch.bfloat16)),
                   'iiseg_conv_halo_bf16_pack')
-            self._W16c8_cin = C1
         dtp = lambda t: None if t is None else _ptr(t, t.dtype)
         prof = CONV_PROFILE
         ev0 = _ev() if prof is not None else None
