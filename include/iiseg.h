@@ -77,6 +77,11 @@ int iiseg_profile_end(float* ms, int capacity);
  * that way with iiseg_conv_halo_bf16_pack); the layer accumulates x_lo W_hi + x_hi W_lo + x_hi W_hi
  * in fp32.  d->C1 stays the logical channel count; C2 must be 0. */
 #define IISEG_CONV_X3 8u
+/* iiseg_conv_c8_slice only: the logical input is x1 with one zero inserted between neighbouring pixels and a
+ * two-pixel zero frame, z[2 i + 2][2 j + 2] = x1[i][j] on (H, W) = (2 h + 3, 2 w + 3) -- a 'valid' 3x3
+ * correlation of z with the in / out-swapped filter IS the 3x3 stride-2 'valid' transposed convolution of
+ * FC-DenseNet's TransitionUp (models/FCDenseNet.py:118-121; Deconv2DLayer, P3) */
+#define IISEG_CONV_ZINS 16u
 
 typedef struct iiseg_conv_desc {
     /* logical input (after concat / unpool): (B, C1 + C2, H, W) */
@@ -316,6 +321,15 @@ int iiseg_conv_c8_force_tiling(int kind, int th, int tw);
 int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void* x1, const void* x2,
                   const uint8_t* mask_in, const void* wp16, const float* bias, const void* add,
                   int add_kind, void* out, int out_kind, void* pool_out, uint8_t* mask_out);
+/* iiseg_conv_c8 with x1 a CHANNEL SLICE of a wider C8 tensor: x1 points at the slice's first chunk plane of
+ * image 0, x1_ctot = channels per image of the tensor it lies in (0: dense, d->C1) -- the conv reads a dense
+ * block's stack in place (models/FCDenseNet.py:92: the ConcatLayer costs no copy) -- and, with
+ * IISEG_CONV_ZINS, zero-inserted (d->H, d->W = the zero-inserted size, d->pad = 0).  Plain bf16 launches only
+ * (no IISEG_CONV_UNPOOL / IISEG_CONV_X3, d->C2 == 0 with IISEG_CONV_ZINS). */
+int iiseg_conv_c8_slice(void* stream, const iiseg_conv_desc* d, const void* x1, int32_t x1_ctot,
+                        const void* x2, const uint8_t* mask_in, const void* wp16, const float* bias,
+                        const void* add, int add_kind, void* out, int out_kind, void* pool_out,
+                        uint8_t* mask_out);
 /* The same layer for AT MOST 16 OUTPUT CHANNELS (csrc/conv_c8_m16.hip: v_mfma_f32_16x16x32_bf16, M = 16
  * channels, 16-pixel blocks, 256-pixel th x tw tiles, three workgroups per CU): the DAE's class-score
  * layer (models/fcn_up.py:83-86) and FC-DenseNet's growth-rate-16 dense-block layers
@@ -507,6 +521,26 @@ int iiseg_refine_finalize(void* stream, const double* partial, int32_t* active, 
                           double* last_norm, int32_t B, int32_t nblk, int32_t HW, double eps);
 
 /* ---------------------------------------------------------------------------------------
+ * The context module's last layers and the refinement update as ONE launch.  Replaces
+ * models/contextmod_dae.py:98-105 (dilconv6: 3x3 'valid' + ReLU; dilconv7: 1x1 linear; softmax) followed
+ * by iterative_inference.py:203-204, 270-277 -- i.e. iiseg_conv_f32 (3x3) + iiseg_conv_f32 (1x1) +
+ * iiseg_refine_update_f32 -- for C <= 16 channels on either side (csrc/conv_small.hip):
+ *   t = relu(conv3x3_valid(x; wp6, b6)); score = conv1x1(t; wp7, b7); then the refinement step above on
+ *   y (B,C,H,W), in place, with the updated y of active images ALSO stored into channels
+ *   [cat_c0, cat_c0 + C) of ycat (B, cat_ctot, cat_H, cat_W) at (cat_y0, cat_x0) (the ConcatLayer((h, y))
+ *   buffer of contextmod_dae.py:55-59 the next step's first layer reads; NULL: no mirror).
+ * x (B, C, H + 2, W + 2); wp6 / wp7: Wp[K][Mpad] of iiseg_conv_pack_f32 for the two layers; partial
+ * (B, nblk) with nblk = iiseg_ctx_tail_partials(H, W) -- pass that nblk to iiseg_refine_finalize.
+ * y is bit-identical to the three separate launches; the partials are summed per 16 x 64 tile.
+ * ------------------------------------------------------------------------------------- */
+int iiseg_ctx_tail_partials(int32_t H, int32_t W);
+int iiseg_ctx_tail_f32(void* stream, const float* x, const float* wp6, int32_t Mpad6, const float* b6,
+                       const float* wp7, int32_t Mpad7, const float* b7, float* y, const int32_t* active,
+                       double* partial, float* ycat, int32_t cat_ctot, int32_t cat_c0, int32_t cat_H,
+                       int32_t cat_W, int32_t cat_y0, int32_t cat_x0, int32_t B, int32_t C, int32_t H,
+                       int32_t W, float step);
+
+/* ---------------------------------------------------------------------------------------
  * Metrics accumulator.  Replaces val_fn, iterative_inference.py:206-210 = metrics.py:11-37
  * (jaccard), :40-65 (accuracy), :144-156 (squared_error, int-void branch):
  *   cm[i*(C+1) + j] += #(argmax_c y == i  and  argmax_c t == j), i < C, j <= C (j == C: void)
@@ -525,6 +559,14 @@ int iiseg_confusion_masked_f32(void* stream, const float* y, const float* t, con
 int iiseg_confusion_masked_f64(void* stream, const double* y, const double* t,
                                const int32_t* active, int64_t* cm, double* sums, int32_t B,
                                int32_t C, int32_t HW);
+
+/* Non-finite input detection: *counter += number of NaN / Inf elements of x[0, n) (device counter, no
+ * synchronisation).  The fp32 / bf16 kernels do not promise to propagate a NaN that enters the network (their
+ * ReLU / max-pool epilogues are bare v_max_f32: build.py EXTRA_FLAGS), where the reference's Theano ops do
+ * (models/fcn_down.py:102-104 `rectify`); the product detects non-finite values where they enter instead:
+ * weights when a layer is built, image batches here. */
+int iiseg_count_nonfinite_f32(void* stream, const float* x, int64_t n, int32_t* counter);
+int iiseg_count_nonfinite_f64(void* stream, const double* x, int64_t n, int32_t* counter);
 
 /* ---------------------------------------------------------------------------------------
  * True-gradient mode (BASELINE north_star; NOT in the reference, whose

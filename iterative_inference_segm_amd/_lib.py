@@ -15,6 +15,7 @@ CONV_RELU = 1
 CONV_UNPOOL = 2
 CONV_X3 = 8
 CONV_TRANSPOSED2 = 4
+CONV_ZINS = 16
 
 
 class ConvDesc(C.Structure):
@@ -86,6 +87,7 @@ SIGNATURES = {
     'iiseg_conv_c8_force_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'iiseg_conv_c8_tiling': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int32)]),
     'iiseg_conv_c8': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 6 + [_i32, _vp, _i32, _vp, _vp]),
+    'iiseg_conv_c8_slice': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 5 + [_i32, _vp, _i32, _vp, _vp]),
     'iiseg_conv_c8_m16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_c8_m16': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 6 + [_i32]),
     'iiseg_conv_c8_m16_workspace_bytes': (_i64, [C.POINTER(ConvDesc)]),
@@ -126,6 +128,8 @@ SIGNATURES = {
     'iiseg_refine_update_f32': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f32]),
     'iiseg_refine_update_c8_f32': (C.c_int, [_vp] * 6 + [_i32] * 9 + [_f32]),
     'iiseg_refine_finalize': (C.c_int, [_vp] * 5 + [_i32] * 3 + [_f64]),
+    'iiseg_ctx_tail_partials': (C.c_int, [_i32, _i32]),
+    'iiseg_ctx_tail_f32': (C.c_int, [_vp] * 3 + [_i32] + [_vp] * 2 + [_i32] + [_vp] * 5 + [_i32] * 10 + [_f32]),
     'iiseg_confusion_f32': (C.c_int, [_vp] * 5 + [_i32] * 3),
     'iiseg_confusion_masked_f32': (C.c_int, [_vp] * 6 + [_i32] * 3),
     'iiseg_confusion_masked_f64': (C.c_int, [_vp] * 6 + [_i32] * 3),
@@ -167,6 +171,8 @@ SIGNATURES = {
     'iiseg_crop_softmax_f64': (C.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8),
     'iiseg_refine_update_f64': (C.c_int, [_vp] * 5 + [_i32] * 8 + [_f64]),
     'iiseg_confusion_f64': (C.c_int, [_vp] * 5 + [_i32] * 3),
+    'iiseg_count_nonfinite_f32': (C.c_int, [_vp, _vp, _i64, _vp]),
+    'iiseg_count_nonfinite_f64': (C.c_int, [_vp, _vp, _i64, _vp]),
 }
 
 _lib = None

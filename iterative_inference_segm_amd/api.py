@@ -33,10 +33,11 @@ class Metrics:
     """Result of one val_fn call kept on the device: confusion counts (C x (C+1), prediction x
     truth with the void column last) and [sum mask*mse_px, sum mask]."""
 
-    def __init__(self, n_classes, device):
+    def __init__(self, n_classes, device, nonfinite=None):
         self.C = n_classes
         self.cm = torch.zeros(n_classes * (n_classes + 1), dtype=torch.int64, device=device)
         self.sums = torch.zeros(2, dtype=torch.float64, device=device)
+        self.nonfinite = nonfinite      # the engine's device counter of non-finite input elements, or None
 
     @staticmethod
     def reduce_host(cm, sums, n_classes):
@@ -53,6 +54,9 @@ class Metrics:
         return acc, jacc, mse
 
     def result(self):
+        if self.nonfinite is not None and int(self.nonfinite.item()) != 0:
+            raise FloatingPointError('%d non-finite values (NaN / Inf) were fed to pred_fcn_fn since the '
+                                     'last check: results are undefined' % int(self.nonfinite.item()))
         return Metrics.reduce_host(self.cm.cpu().numpy(), self.sums.cpu().numpy(), self.C)
 
 
@@ -79,6 +83,21 @@ class IterativeInference:
         # scratch buffers (Winograd workspaces, ...) are per engine: two engines may run concurrently
         # on two streams (ops.workspace_tag)
         self._ws_tag = next(_ENGINE_IDS)
+        # Non-finite inputs: the conv kernels do not promise to propagate a NaN (a ReLU may swallow it; the
+        # reference's Theano graph would hand it through to the output), so they are counted where they
+        # enter -- every batch given to pred_fcn_fn, one HBM-bound pass, no synchronisation -- and reported
+        # when results are read (`val_fn`, `Metrics.result`, `check_finite`).  Weights: ops.Conv refuses them.
+        self._nonfinite = None
+
+    def check_finite(self):
+        """Raises FloatingPointError if any batch handed to pred_fcn_fn since the last call held NaN / Inf
+        (synchronises); resets the counter."""
+        if self._nonfinite is None:
+            return
+        n = int(self._nonfinite.item())
+        self._nonfinite.zero_()
+        if n:
+            raise FloatingPointError('%d non-finite values (NaN / Inf) in the images given to pred_fcn_fn' % n)
 
     def __del__(self):
         # the engine's scratch buffers go with it
@@ -133,7 +152,12 @@ class IterativeInference:
     # ---- reference function level -------------------------------------------------------
     def pred_fcn_fn(self, X):
         with ops.workspace_tag(self._ws_tag):
-            return self._remember(self.fcn(self._dev(X)))
+            X = self._dev(X)
+            if X.is_cuda:
+                if self._nonfinite is None:
+                    self._nonfinite = torch.zeros(1, dtype=torch.int32, device=X.device)
+                ops.count_nonfinite(X, self._nonfinite)
+            return self._remember(self.fcn(X))
 
     def pred_dae_fn(self, *args):
         with ops.workspace_tag(self._ws_tag):
@@ -149,7 +173,7 @@ class IterativeInference:
         return [acc, jacc, mse]
 
     def val_device(self, Y, T):
-        m = Metrics(self.n_classes, self.device)
+        m = Metrics(self.n_classes, self.device, nonfinite=self._nonfinite)
         ops.confusion_accumulate(self._dev(Y), self._dev(T), m.cm, m.sums)
         return m
 
@@ -233,7 +257,19 @@ class IterativeInference:
         sess = self.dae.new_session(H, y, tags=tags) if hasattr(self.dae, 'new_session') else None
         if hasattr(self.dae, 'keep_pre'):
             self.dae.keep_pre = mode == 'gradient'     # backward_y reads the pre-pool maps
+        fused = getattr(self.dae, 'fused_step', None) if mode == 'residual' else None
         for it in range(int(num_iter)):
+            if fused is not None and sess is not None and not (it == 0 and first_reconstruction):
+                # scores + update as the DAE's own fused step (context module: its last layers and the update
+                # are one launch)
+                nblk = fused(H, y, st, step, sess)
+                if nblk is not None:
+                    ops.refine_finalize(st, eps_eff, nblk=nblk)
+                    if per_iter is not None:
+                        ops.confusion_accumulate(y, T, per_iter[it], scratch, active=st.active)
+                    if early_stop and it + 1 < int(num_iter) and not bool(st.active.any()):
+                        break
+                    continue
             score = self.dae.scores(H, y, session=sess) if sess is not None \
                 else self.dae.scores(H, y)
             if it == 0 and first_reconstruction:
@@ -300,7 +336,14 @@ class IterativeInference:
         dae_scores = (lambda: self.dae.scores(H, y, session=sess)) if sess is not None else \
             (lambda: self.dae.scores(H, y))
 
+        fused = getattr(self.dae, 'fused_step', None)
+
         def one_step():
+            if fused is not None and sess is not None:
+                nblk = fused(H, y, st, step, sess)
+                if nblk is not None:
+                    _ops.refine_finalize(st, eps_eff, nblk=nblk)
+                    return None
             score = dae_scores()
             self._update(score, y, st, step, sess)
             _ops.refine_finalize(st, eps_eff)
@@ -360,6 +403,8 @@ class IterativeInference:
             self.dae.c8_fed(sess)
         else:
             ops.refine_update(score, y, st, step, off=(0, 0))
+        if sess is not None and hasattr(self.dae, 'y_updated'):
+            self.dae.y_updated(sess, y)     # (context module: the concat buffer's y channels follow y)
 
     def _launch_fingerprint(self, sess):
         """What a captured refinement step depends on besides shapes: the DAE's launch-structure

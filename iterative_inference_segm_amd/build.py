@@ -106,7 +106,7 @@ def build(force=False, verbose=False):
     LAST.update(compiled=[], reused=[], linked=False)
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'c8_common.h'), os.path.join(CSRC, 'conv_f64_common.h'), os.path.join(CSRC, 'column_io.h'),
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'), os.path.join(CSRC, 'c8_common.h'), os.path.join(CSRC, 'conv_f64_common.h'), os.path.join(CSRC, 'column_io.h'), os.path.join(CSRC, 'tail_math.h'),
                os.path.join(INCLUDE, 'iiseg.h')]
     flags = ['-O3', '--offload-arch=' + ARCH, '-fPIC', '-std=c++17', '-I' + INCLUDE, '-I' + CSRC,
              '-Wall', '-Wno-unused-function']

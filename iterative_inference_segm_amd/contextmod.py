@@ -42,6 +42,7 @@ class ContextModDAE:
         W, b = params['dilconv1']
         self.dil1_valid = ops.Conv(W, b, pad=0, relu=True, dil=DILATIONS[0], layout='iohw', device=device,
                                    dtype=dtype)
+        self._sessions = {}
 
     def conv_layers(self):
         d = {'conv1': self.conv1, 'dilconv7': self.last}
@@ -56,17 +57,29 @@ class ContextModDAE:
             return None
         h = h_list[0]
         B, ch, H, W = h.shape[0], h.shape[1], y.shape[2], y.shape[3]
-        # [h, y] with the one-pixel zero border of conv1's pad, and conv1's output inside PadLayer(32)'s zeros
-        cat = torch.zeros((B, ch + y.shape[1], H + 2, W + 2), dtype=y.dtype, device=y.device)
-        cat[:, :ch, 1:-1, 1:-1].copy_(h)
-        pad32 = torch.zeros((B, self.conv1.Cout, H + 64, W + 64), dtype=y.dtype, device=y.device)
-        return {'cat': cat, 'ch': ch, 'pad32': pad32}
+        # The buffers are kept per geometry and handed out again (a captured refinement step points into them:
+        # a new batch replays the same graph); what a call changes: the h channels (copied here) and the y
+        # channels (every step).  The zero borders are written once.
+        key = (B, ch, y.shape[1], H, W, y.dtype, str(y.device))
+        sess = self._sessions.get(key)
+        if sess is None:
+            # [h, y] with the one-pixel zero border of conv1's pad, and conv1's output inside PadLayer(32)'s zeros
+            cat = torch.zeros((B, ch + y.shape[1], H + 2, W + 2), dtype=y.dtype, device=y.device)
+            pad32 = torch.zeros((B, self.conv1.Cout, H + 64, W + 64), dtype=y.dtype, device=y.device)
+            while len(self._sessions) >= 4:
+                self._sessions.pop(next(iter(self._sessions)))
+            sess = self._sessions[key] = {'cat': cat, 'ch': ch, 'pad32': pad32}
+        sess['cat'][:, :ch, 1:-1, 1:-1].copy_(h)
+        sess['y_in_cat'] = False        # the y channels hold another loop's map
+        return sess
 
     def scores(self, h_list, y, mask_override=None, session=None):
         if len(h_list) != 1:
             raise ValueError('expected 1 h tensor, got %d' % len(h_list))
         if session is not None:
-            session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
+            if not session.get('y_in_cat'):
+                session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
+            session['y_in_cat'] = False      # (the caller's update changes y, not the buffer: see `fused_step`)
             self.conv1_valid(session['cat'], out=session['pad32'], place=(32, 32))
             t = self.dil1_valid(session['pad32'])
             rest = self.dil[1:]
@@ -76,6 +89,32 @@ class ContextModDAE:
         for conv in rest:
             t = conv(t)
         return self.last(t)
+
+    def y_updated(self, session, y):
+        """The caller has just updated y outside `fused_step` (the first step of a loop, which also hands out
+        the score map): refresh the y channels of the concat buffer, so that every later step -- eager or
+        replayed from a captured graph -- starts with the buffer equal to y."""
+        session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
+        session['y_in_cat'] = True
+
+    def fused_step(self, h_list, y, state, step, session):
+        """One refinement step (scores + softmax + update of y, in place) with the last two layers and the
+        update as one launch that also refreshes the y channels of the concat buffer (csrc/conv_small.hip
+        ctx_tail_kernel): bit-identical y, three launches and the per-step copy of y fewer.  Returns the number
+        of norm partials per image written (for ops.refine_finalize), or None when this geometry / dtype has no
+        fused form (the caller then runs scores + refine_update)."""
+        if session is None or not ops.ctx_tail_supported(self.dil[-1], self.last, y):
+            return None
+        if not session.get('y_in_cat'):
+            session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
+        self.conv1_valid(session['cat'], out=session['pad32'], place=(32, 32))
+        t = self.dil1_valid(session['pad32'])
+        for conv in self.dil[1:-1]:
+            t = conv(t)
+        nblk = ops.ctx_tail(self.dil[-1], self.last, t, y, state, step, ycat=session['cat'],
+                            cat_c0=session['ch'], cat_off=(1, 1))
+        session['y_in_cat'] = True
+        return nblk
 
     def __call__(self, *args):
         score = self.scores(args[:-1], args[-1])

@@ -99,6 +99,10 @@ struct C8Params {
     unsigned tw_magic;            // RECT: ceil(2^20 / (quad ? tw / 2 : tw))
     int x3;                       // split-operand mode (template X3)
     int debug;
+    int in_ct8;                   // chunk planes per image of the x1 TENSOR (>= C1 / 8: x1 may be a channel
+                                  // slice of a wider C8 tensor -- a dense block's stack); X3: 2 C1 / 8
+    int zins;                     // IISEG_CONV_ZINS: the logical input is the 2x zero-inserted x1,
+                                  // z[2 i + 2][2 j + 2] = x1[i][j] on (2 h2 + 3) x (2 w2 + 3) (h2, w2 = x1's size)
 };
 
 // BM: output channels per workgroup (64; 32 for the class-score layer).  4 waves, each BM channels x
@@ -133,11 +137,13 @@ struct C8Params {
 //   2  bf16 C8 store, no addend, no pool (the plain layers of the FCN-8)
 //   3  bf16 C8 store with a bf16 C8 skip addend (the decoder layers)
 // Same values, same comparisons, same stores as the generic epilogue.
-enum { EPI_GENERIC = 0, EPI_POOL = 1, EPI_STORE = 2, EPI_STORE_ADD = 3 };
+//   4  as 1, with an fp32 C8 addend summed in before the ReLU (the y half of the conv behind the h concat:
+//      its loop-invariant h half is a cached fp32 map)
+enum { EPI_GENERIC = 0, EPI_POOL = 1, EPI_STORE = 2, EPI_STORE_ADD = 3, EPI_POOL_ADD2 = 4 };
 template <int BM, int TN, bool FLAT, bool UNPOOL, bool OUTF32, bool X3, int NBUF = 2, int NW = 4, int EPI = EPI_GENERIC>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GENERIC ? 4 : 3) : 2)) void conv_c8_kernel(const C8Params p) {
     static_assert(EPI == EPI_GENERIC || !OUTF32, "specialised epilogues: bf16 C8 (or hi / lo pair) outputs");
-    static_assert(EPI != EPI_POOL || !UNPOOL, "pool-only epilogue: encoder layers");
+    static_assert((EPI != EPI_POOL && EPI != EPI_POOL_ADD2) || !UNPOOL, "pool-only epilogue: encoder layers");
     static_assert(!FLAT || TN == 2, "flat tiles are 256 pixels");
     static_assert(NW == 4 || (NW == 8 && TN == 2 && !FLAT), "eight waves: 512-pixel rect tiles");
     constexpr int NT = 64 * NW;
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
 
     // pixel order of a tile: known at compile time under a specialised epilogue (pooling-window order
     // exactly when a pool is fused)
-    const bool quad = EPI == EPI_POOL ? true : (EPI == EPI_GENERIC ? p.quad != 0 : false);
+    const bool quad = (EPI == EPI_POOL || EPI == EPI_POOL_ADD2) ? true : (EPI == EPI_GENERIC ? p.quad != 0 : false);
     int pt, mt;
     tile_of_block(blockIdx.x, gridDim.x, p.n_ptiles, p.n_mtiles, pt, mt);
     const int m0 = mt * BM;
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
     const int CCh = p.C1 >> 3;                               // chunks of the C1 channels
     const int CC1 = X3 ? 2 * CCh : CCh;                      // chunks per image of source 1
     const int kt1 = p.C1 >> 4;                               // X3: k-tiles per k-group
+    const int IC1 = p.in_ct8;                                // chunk planes per image of the x1 tensor (>= CC1)
 
     // ---- tile geometry -----------------------------------------------------------------------
     int tb = 0, wy0 = 0, wx0 = 0;     // RECT: image, tile origin in window coordinates
@@ -234,17 +241,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             // DePool2D (layers/mylayers.py:95-114): only the 2 h2 x 2 w2 region has pooling windows
             ok = ok && iy < 2 * p.h2 && ix < 2 * p.w2;
             const unsigned pq = (unsigned)((iy >> 1) * p.w2 + (ix >> 1));
-            voff[i] = ok ? ((unsigned)((b * CC1 + h) * hw2) + pq) * 16u : OOB;
+            voff[i] = ok ? ((unsigned)((b * IC1 + h) * hw2) + pq) * 16u : OOB;
             voffm[i] = ok ? ((unsigned)((b * CCh + h) * hw2) + pq) * 8u : OOB;
             bsel[i] = ((iy & 1) << 1) | (ix & 1);
+        } else if (p.zins) {
+            // FC-DenseNet's TransitionUp (models/FCDenseNet.py:118-121, a 3x3 stride-2 transposed convolution)
+            // as a 'valid' correlation of the zero-inserted block: three of four patch chunks are zeros that
+            // are never fetched (the out-of-range offset), the fourth comes straight from the block
+            ok = ok && !((iy | ix) & 1) && iy >= 2 && ix >= 2 && iy <= 2 * p.h2 && ix <= 2 * p.w2;
+            voff[i] = ok ? (unsigned)((b * IC1 + h) * hw2 + ((iy >> 1) - 1) * p.w2 + (ix >> 1) - 1) * 16u : OOB;
         } else {
-            voff[i] = ok ? (unsigned)((b * CC1 + h) * HW + iy * p.W + ix) * 16u : OOB;
+            voff[i] = ok ? (unsigned)((b * IC1 + h) * HW + iy * p.W + ix) * 16u : OOB;
         }
     }
     // sources: RECT = image tb of each tensor (32-bit offsets inside one image), FLAT = whole tensor
-    const int plane = UNPOOL ? hw2 : HW;
-    const char* base1 = (const char*)p.x1 + (FLAT ? (size_t)0 : (size_t)tb * CC1 * plane * 16);
-    const unsigned n1 = (unsigned)((FLAT ? p.B : 1) * CC1 * plane) * 16u;
+    const int plane = (UNPOOL || p.zins) ? hw2 : HW;
+    const char* base1 = (const char*)p.x1 + (FLAT ? (size_t)0 : (size_t)tb * IC1 * plane * 16);
+    // (a channel slice: the descriptor ends with the slice's last plane of the last image it covers)
+    const unsigned n1 = (unsigned)(((FLAT ? p.B : 1) - 1) * IC1 * plane + CC1 * plane) * 16u;
     const char* base2 = p.C2 > 0 ? (const char*)p.x2 + (size_t)tb * (p.C2 >> 3) * plane * 16 : base1;
     const unsigned n2 = p.C2 > 0 ? (unsigned)((p.C2 >> 3) * plane) * 16u : n1;
     const __amdgpu_buffer_rsrc_t r_x1 = mk_rsrc(base1, (p.debug & 2) ? 0u : n1);
@@ -579,8 +593,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
                 }
             }
         }
-    } else if constexpr (EPI == EPI_POOL) {
+    } else if constexpr (EPI == EPI_POOL || EPI == EPI_POOL_ADD2) {
+        constexpr bool ADD2 = EPI == EPI_POOL_ADD2;
         const int co8 = ((p.Cout + 15) >> 4) << 1;
+        // ADD2: the fp32 C8 addend (B, Cout / 8, AH, AW, 8) floats: a lane's four channels are 16 bytes
+        const __amdgpu_buffer_rsrc_t r_add2 =
+            mk_rsrc(ADD2 ? (const char*)p.add + (size_t)ib * co8 * APL * 32 : nullptr,
+                    ADD2 ? (unsigned)((FLAT ? p.B : 1) * co8 * APL) * 32u : 0u);
+        unsigned ab2[ADD2 ? TN : 1];
+        if constexpr (ADD2) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned apix = (unsigned)(eb[j] * co8 * APL + (p.ay0 + ey[j]) * p.AW + p.ax0 + ex[j]);
+                ab2[j] = eok[j] ? apix * 32u + 16u * lh : OOB;
+            }
+        }
+        constexpr int GHP = TN == 4 ? 2 : 4;       // chunks whose addend loads are in flight together
         const int co8P = X3 ? 2 * co8 : co8;       // X3: the pooled map is a hi / lo pair, the masks are not
         const __amdgpu_buffer_rsrc_t r_pool =
             mk_rsrc((const char*)p.pool + (size_t)ib * co8P * PPL * 16, (unsigned)((FLAT ? p.B : 1) * co8P * PPL) * 16u);
@@ -613,6 +641,24 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c8 = ((m0 + i * 32) >> 3) + g;
+                if constexpr (ADD2) {
+                    // (every load of a group of chunks before its first store: a buffer load cannot move above
+                    // an earlier buffer store; the sum acc + addend is the generic epilogue's)
+                    if (g % GHP == 0) {
+#pragma unroll
+                        for (int gg = g; gg < g + GHP; ++gg) {
+                            const int cg = ((m0 + i * 32) >> 3) + gg;
+                            const int so_a = (int)((unsigned)(cg * APL) * 32u);
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) {
+                                const f32x4 av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                    r_add2, (int)(cg < co8 ? ab2[j] : OOB), so_a, 0));
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) acc[i][j][gg * 4 + q] += av[q];
+                            }
+                        }
+                    }
+                }
                 if (c8 >= co8) continue;               // wave-uniform: chunks past the padded channels
                 const int so_p = (int)((unsigned)(c8 * PPL) * 16u);
 #pragma unroll
@@ -1198,6 +1244,8 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
         int epi = EPI_GENERIC;
         if (epi_env) {
             if (p.pool && !p.out && !p.add && !unpool && p.relu) epi = EPI_POOL;
+            else if (p.pool && !p.out && p.add && p.add_kind == 2 && !unpool && p.relu && !plan.single)
+                epi = EPI_POOL_ADD2;
             else if (!p.pool && p.out && p.out_kind == 1 && !p.add && !unpool) epi = EPI_STORE;
             else if (!p.pool && p.out && p.out_kind == 1 && p.add && p.add_kind == 1) epi = EPI_STORE_ADD;
         }
@@ -1221,6 +1269,8 @@ int launch_c8(hipStream_t s, C8Params& p, const C8Plan& plan, bool unpool) {
                 return iiseg_check_launch();
             }
             C8_LAUNCH_EPI(EPI_POOL, false);
+        } else if (epi == EPI_POOL_ADD2) {
+            C8_LAUNCH_EPI(EPI_POOL_ADD2, false);
         } else if (epi == EPI_STORE) {
             if (plan.single) {
                 IISEG_LAUNCH((conv_c8_kernel<64, 2, false, false, false, false, 1, 4, EPI_STORE>), dim3(grid), dim3(256), 0, s, p);
@@ -1302,6 +1352,14 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
                              const uint8_t* mask_in, const void* wp16, const float* bias,
                              const void* add, int add_kind, void* out, int out_kind, void* pool_out,
                              uint8_t* mask_out) {
+    return iiseg_conv_c8_slice(stream, d, x1, 0, x2, mask_in, wp16, bias, add, add_kind, out, out_kind, pool_out,
+                               mask_out);
+}
+
+extern "C" int iiseg_conv_c8_slice(void* stream, const iiseg_conv_desc* d, const void* x1, int32_t x1_ctot,
+                                   const void* x2, const uint8_t* mask_in, const void* wp16, const float* bias,
+                                   const void* add, int add_kind, void* out, int out_kind, void* pool_out,
+                                   uint8_t* mask_out) {
     C8Plan plan;
     const int st = c8_check(d, &plan, pool_out != nullptr);
     if (st) return st;
@@ -1310,6 +1368,14 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     const bool unpool = (d->flags & IISEG_CONV_UNPOOL) != 0;
     if (unpool != (mask_in != nullptr)) return IISEG_ERR_NULL;
     if ((uintptr_t)wp16 & 15) return IISEG_ERR_ALIGN;
+    const bool zins = (d->flags & IISEG_CONV_ZINS) != 0;
+    const bool x3f = (d->flags & IISEG_CONV_X3) != 0;
+    // x1 as a channel slice of a wider tensor / zero-inserted: plain single-source bf16 launches
+    if ((x1_ctot != 0 || zins) && (x3f || unpool)) return IISEG_ERR_UNSUPPORTED;
+    if (x1_ctot != 0 && (x1_ctot % 8 || x1_ctot < d->C1)) return IISEG_ERR_SHAPE;
+    if (zins && (d->C2 != 0 || d->pad != 0 || d->H < 5 || d->W < 5 || !(d->H & 1) || !(d->W & 1)))
+        return IISEG_ERR_SHAPE;
+    if (x1_ctot != 0 && (int64_t)d->B * x1_ctot * d->H * d->W * 2 >= (1ll << 31)) return IISEG_ERR_UNSUPPORTED;
     if (out_kind < 0 || out_kind > 3 || add_kind < 0 || add_kind > 2) return IISEG_ERR_UNSUPPORTED;
     if ((out_kind != 0) != (out != nullptr)) return IISEG_ERR_NULL;
     if ((add_kind != 0) != (add != nullptr)) return IISEG_ERR_NULL;
@@ -1337,6 +1403,9 @@ extern "C" int iiseg_conv_c8(void* stream, const iiseg_conv_desc* d, const void*
     p.pool = pool_out; p.mask_out = mask_out;
     p.B = d->B; p.C1 = d->C1; p.C2 = d->C2; p.H = d->H; p.W = d->W;
     p.h2 = d->H / 2; p.w2 = d->W / 2;
+    p.zins = zins ? 1 : 0;
+    if (zins) { p.h2 = (d->H - 3) / 2; p.w2 = (d->W - 3) / 2; }
+    p.in_ct8 = (x1_ctot ? x1_ctot : d->C1) / 8 * (x3f ? 2 : 1);
     p.Cout = d->Cout; p.OH = d->OH; p.OW = d->OW; p.oy0 = d->oy0; p.ox0 = d->ox0; p.pad = d->pad;
     p.AH = d->AH; p.AW = d->AW; p.ay0 = d->ay0; p.ax0 = d->ax0;
     p.x3 = (d->flags & IISEG_CONV_X3) ? 1 : 0;

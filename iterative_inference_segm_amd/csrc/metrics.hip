@@ -140,3 +140,42 @@ extern "C" int iiseg_confusion_masked_f64(void* stream, const double* y, const d
     if (!active) return IISEG_ERR_NULL;
     return confusion<double>(stream, y, t, active, cm, sums, B, C, HW);
 }
+
+// ---- non-finite inputs -----------------------------------------------------------------------------------------
+// The fp32 / bf16 convolution sources are built with relaxed NaN handling (build.py EXTRA_FLAGS: the ReLU and
+// max-pool epilogues are bare v_max_f32 on MFMA results), so a NaN that ENTERS the network is not guaranteed to
+// come out as a NaN -- the first ReLU may swallow it (the reference's Theano `maximum` propagates it).  What the
+// product promises instead: non-finite values are detected where they enter.  Weights are checked on the host
+// when a layer is built; every image batch is counted here (one HBM-bound pass, no synchronisation: the counter
+// stays on the device and is read with the results, api.Metrics.result / IterativeInference.check_finite).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const T* __restrict__ x, int64_t n, int* counter) {
+    int bad = 0;
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T v = x[i];
+        // (integer test of the exponent field: immune to the compiler's no-NaN assumptions)
+        if constexpr (sizeof(T) == 4)
+            bad += (__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0x7f800000u;
+        else
+            bad += (__builtin_bit_cast(unsigned long long, v) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull;
+    }
+    if (__any(bad != 0) && bad) atomicAdd(counter, bad);
+}
+template <typename T>
+int count_nonfinite(void* stream, const T* x, int64_t n, int32_t* counter) {
+    if (!x || !counter) return IISEG_ERR_NULL;
+    if (n <= 0) return IISEG_ERR_SHAPE;
+    const int64_t blocks = (n + 255) / 256;
+    const int grid = (int)(blocks < 4096 ? blocks : 4096);
+    IISEG_LAUNCH(count_nonfinite_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, counter);
+    return iiseg_check_launch();
+}
+}  // namespace
+
+extern "C" int iiseg_count_nonfinite_f32(void* stream, const float* x, int64_t n, int32_t* counter) {
+    return count_nonfinite<float>(stream, x, n, counter);
+}
+extern "C" int iiseg_count_nonfinite_f64(void* stream, const double* x, int64_t n, int32_t* counter) {
+    return count_nonfinite<double>(stream, x, n, counter);
+}

@@ -7,36 +7,9 @@
 // softmax); iterative_inference.py:203-204,270-277 (update, clip, norm, early stop).
 #include "common.h"
 #include "column_io.h"
+#include "tail_math.h"
 
 namespace {
-
-__device__ inline float exp_t(float x) { return expf(x); }
-__device__ inline double exp_t(double x) { return exp(x); }
-__device__ inline float sqrt_t(float x) { return sqrtf(x); }
-__device__ inline double sqrt_t(double x) { return sqrt(x); }
-
-// r <- softmax over the first C entries (same order of operations as ever: max, exp(v - max), sum in
-// channel order, one reciprocal); entries >= C become 0
-template <int CMAX, typename T>
-__device__ inline void softmax_column(int C, T (&r)[CMAX]) {
-    T m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) m = r[c] > m ? r[c] : m;
-    T s = 0;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) {
-            r[c] = exp_t(r[c] - m);
-            s += r[c];
-        } else {
-            r[c] = 0;
-        }
-    const T inv = (T)1 / s;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) r[c] *= inv;
-}
 
 // the thread's pixel: byte offsets inside image b's score window / inside a (C, H, W) map, or T_OOB
 struct TailPix {
@@ -102,18 +75,7 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
     load_column<CMAX, T>(rs, t.so, SB, C, r);
     load_column<CMAX, T>(ry, t.po, PB, C, yv);
     __builtin_amdgcn_sched_barrier(0);     // (every load of the thread in flight before the first use)
-    softmax_column<CMAX, T>(C, r);
-    T ss = 0;
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < C) {
-            const T de = yv[c] - r[c];  // iterative_inference.py:203-204
-            ss = fma(de, de, ss);
-            if (act) {
-                T yn = yv[c] - step * de;  // :270
-                yv[c] = yn < (T)0 ? (T)0 : (yn > (T)1 ? (T)1 : yn);  // :273
-            }
-        }
+    const T ss = refine_pixel<CMAX, T>(C, r, yv, act, step);     // (tail_math.h)
     store_column<CMAX, T>(ry, act ? t.po : T_OOB, PB, C, yv);
     const T nrm = t.inb ? sqrt_t(ss) : (T)0;  // np.linalg.norm(grad, axis=1), :275
     // bf16 C8 copy of the updated map for the next DAE forward (mma='bf16c8': saves the

@@ -105,18 +105,33 @@ class _Peek:
         return self.items[self.i] if self.i < len(self.items) else None
 
 
-class _Stack8:
-    """The same stack as bf16 C8 chunks (B, cap / 8, H, W, 8) -- mma='bf16c8': the format the dense-block
-    layers read and write (csrc/conv_c8_m16.hip); the statistics (fp32) are those of the stored bf16
-    values, reduced once per produced slice."""
+class _Level8:
+    """The bf16 C8 buffer of ONE resolution of the C8 forward, (B, ctot / 8, H, W, 8), with its per-channel
+    vectors (batch statistics, the folded BatchNorm of the current consumer).  It IS the stack of the up
+    path's dense block at this resolution: [TransitionUp output | skip stack | the block's new layers]
+    (models/FCDenseNet.py:119-127) -- and the down path's dense block at the same resolution builds its
+    stack in place in the `skip` slice, so the ConcatLayer([deconv, skip]) of TransitionUp costs no copy
+    (the block's channels, their statistics and the consumers' pointers are all slices of these tensors)."""
 
-    def __init__(self, B, cap, H, W, device):
-        assert cap % 16 == 0
-        self.buf = torch.empty((B, cap // 8, H, W, 8), dtype=torch.bfloat16, device=device)
-        self.mean = torch.zeros(cap, dtype=torch.float32, device=device)
-        self.inv_std = torch.zeros(cap, dtype=torch.float32, device=device)
-        self.a = torch.zeros(cap, dtype=torch.float32, device=device)     # folded BN of the consumer
-        self.b = torch.zeros(cap, dtype=torch.float32, device=device)
+    def __init__(self, B, ctot, H, W, device):
+        assert ctot % 16 == 0
+        self.buf = torch.zeros((B, ctot // 8, H, W, 8), dtype=torch.bfloat16, device=device)
+        self.mean = torch.zeros(ctot, dtype=torch.float32, device=device)
+        self.inv_std = torch.zeros(ctot, dtype=torch.float32, device=device)
+        self.a = torch.zeros(ctot, dtype=torch.float32, device=device)     # folded BN of the consumer
+        self.b = torch.zeros(ctot, dtype=torch.float32, device=device)
+
+
+class _Stack8:
+    """A growing dense-block stack as bf16 C8 chunks -- mma='bf16c8': the format the dense-block layers read
+    and write (csrc/conv_c8_m16.hip) --: channels [c0, c0 + cap) of a `_Level8`; the statistics (fp32) are
+    those of the stored bf16 values, reduced once per produced slice."""
+
+    def __init__(self, level, c0, cap):
+        assert cap % 16 == 0 and c0 % 16 == 0
+        self.buf = level.buf[:, c0 // 8:(c0 + cap) // 8]        # (a view: same image stride as the level)
+        self.mean, self.inv_std = level.mean[c0:c0 + cap], level.inv_std[c0:c0 + cap]
+        self.a, self.b = level.a[c0:c0 + cap], level.b[c0:c0 + cap]
         self.n = 0
         self.folded_for = None      # the layer entry (a, b) currently hold the folded BatchNorm of
 
@@ -146,6 +161,7 @@ class FCDenseNet:
         self.nlpb, self.n_pool, self.growth = list(n_layers_per_block), n_pool, growth
         self.n_classes, self.device, self.dtype = n_classes, device, dtype
         dev = lambda a: torch.as_tensor(a).to(dtype).contiguous().to(device)
+        self._c8_levels = {}          # mma='bf16c8': the forward's buffers per input geometry (_levels_c8)
         self.layers = []
         for p in params:
             e = {'kind': p['kind']}
@@ -213,9 +229,34 @@ class FCDenseNet:
         stack.added(self.growth, stats=False)
         stack.folded_for = nxt if fold is not None else None
 
+    def _levels_c8(self, B, H, W, n_first):
+        """The buffers of the C8 forward for one input geometry, kept across calls (every element a forward
+        reads is written earlier in the same forward; the zero rows of padding are written once): one
+        `_Level8` per resolution + the bottleneck's."""
+        key = (B, H, W)
+        lv = self._c8_levels.get(key)
+        if lv is None:
+            g, dev = self.growth, self.device
+            n, hw, skip_n = n_first, (H, W), []
+            for i in range(self.n_pool):
+                n += g * self.nlpb[i]
+                skip_n.append((n, hw))
+                hw = (hw[0] // 2, hw[1] // 2)
+            levels = []
+            for L in range(self.n_pool):                 # up block i = n_pool - 1 - L runs at resolution L
+                i = self.n_pool - 1 - L
+                keep = g * self.nlpb[self.n_pool + i]
+                ctot = keep + skip_n[L][0] + g * self.nlpb[self.n_pool + i + 1]
+                levels.append((_Level8(B, ctot, skip_n[L][1][0], skip_n[L][1][1], dev), keep))
+            bott = _Level8(B, n + g * self.nlpb[self.n_pool], hw[0], hw[1], dev)
+            while len(self._c8_levels) >= 2:
+                self._c8_levels.pop(next(iter(self._c8_levels)))
+            lv = self._c8_levels[key] = (levels, bott)
+        return lv
+
     def _forward_c8(self, x):
         B, _, H, W = x.shape
-        g, dev = self.growth, self.device
+        g = self.growth
         it = _Peek(self.layers)
         hidden = [x] if 'input' in self.layer else []
         ints = [int(h[-1]) for h in self.layer if h != 'input']
@@ -223,7 +264,9 @@ class FCDenseNet:
         n = first.Cout
         if not first.c8:
             raise NotImplementedError("mma='bf16c8': the first convolution's filter count must be a multiple of 16")
-        stack = _Stack8(B, n + g * self.nlpb[0], H, W, dev)
+        levels, bott = self._levels_c8(B, H, W, n)
+        # the down path's dense block of resolution L lives in the skip slice of that resolution's buffer
+        stack = _Stack8(levels[0][0], levels[0][1], n + g * self.nlpb[0])
         next(it)['conv'](ops.nchw_to_c8(x), out=stack.buf, out_c0=0)  # first conv (linear)
         stack.added(n)
         skips = []
@@ -231,10 +274,13 @@ class FCDenseNet:
             for _ in range(self.nlpb[i]):
                 self._brc8(it, stack)
             skips.append(stack)
-            # TransitionDown (BN -> ReLU -> 1x1 conv -> pool) on the fp32-NCHW forms
+            # TransitionDown (BN -> ReLU -> 1x1 conv -> pool)
             e = next(it)
             n = stack.n
-            nxt = _Stack8(B, n + g * self.nlpb[i + 1], H // 2, W // 2, dev)
+            if i + 1 < self.n_pool:
+                nxt = _Stack8(levels[i + 1][0], levels[i + 1][1], n + g * self.nlpb[i + 1])
+            else:
+                nxt = _Stack8(bott, 0, n + g * self.nlpb[self.n_pool])
             if 'conv8' in e:
                 # one kernel on the C8 stack: BN + ReLU on the way in, the 2x2 max-pool in the epilogue, bf16
                 # C8 straight into the next block's stack
@@ -269,26 +315,22 @@ class FCDenseNet:
                 raise NotImplementedError('skip larger than the upsampled map')
             keep = e['conv'].Cout
             nlay = self.nlpb[self.n_pool + i + 1]
-            new = _Stack8(B, keep + skip.n + g * nlay, H, W, dev)
+            level, lkeep = levels[self.n_pool - 1 - i]
+            assert lkeep == keep and skip.n == level.buf.shape[1] * 8 - keep - g * nlay
+            new = _Stack8(level, 0, keep + skip.n + g * nlay)
             blk = up = None
             if 'conv8' in e and block0 % 8 == 0:
-                # concat(block_to_upsample) = chunk planes [block0 / 8, n / 8) of the stack, zero-inserted
-                # (plumbing: a strided device copy), then the C8 kernel straight into the new stack's slice,
-                # center-cropped to the skip's size
-                z = torch.zeros((B, (stack.n - block0) // 8, 2 * h_in + 3, 2 * w_in + 3, 8),
-                                dtype=torch.bfloat16, device=dev)
-                z[:, :, 2:2 * h_in + 1:2, 2:2 * w_in + 1:2].copy_(stack.buf[:, block0 // 8:stack.n // 8])
-                e['conv8'](z, window=((uh - H) // 2, (uw - W) // 2, H, W), out=new.buf, out_c0=0)
-                del z
+                # concat(block_to_upsample) = chunk planes [block0 / 8, n / 8) of the stack, read in place and
+                # zero-inserted by the kernel's own patch staging (IISEG_CONV_ZINS), straight into the new
+                # stack's first slice, center-cropped to the skip's size
+                e['conv8'](stack.buf[:, block0 // 8:stack.n // 8], zins=True,
+                           window=((uh - H) // 2, (uw - W) // 2, H, W), out=new.buf, out_c0=0)
             else:
                 blk = ops.c8_slice_to_nchw(stack.buf, block0, stack.n - block0)
                 up = e['conv'](blk, window=((uh - H) // 2, (uw - W) // 2, H, W))
                 ops.nchw_to_c8_slice(up, new.buf, 0)
             new.added(keep)
-            # the skip stack behind it (plumbing: chunk planes and their statistics as they are)
-            new.buf[:, keep // 8:(keep + skip.n) // 8].copy_(skip.buf[:, :skip.n // 8])
-            new.mean[keep:keep + skip.n].copy_(skip.mean[:skip.n])
-            new.inv_std[keep:keep + skip.n].copy_(skip.inv_std[:skip.n])
+            # the skip stack is already behind it, with its statistics (same tensors)
             new.added(skip.n, stats=False)
             stack, block0 = new, new.n
             del blk, up

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2, CONV_X3, check
+from ._lib import ConvDesc, DeconvDesc, CONV_RELU, CONV_UNPOOL, CONV_TRANSPOSED2, CONV_X3, CONV_ZINS, check
 
 # When set to a list, every conv launch appends (kernel, executed_flops, start_event, end_event):
 # HIP events recorded on the launch stream right around the kernel (bench.py's roofline leg).
@@ -280,6 +280,11 @@ class Conv:
             self.mma = 'f32' if self.x3 else 'bf16'
         self.transposed = bool(transposed)
         self.dtype = dtype
+        # (the conv kernels do not promise to propagate a NaN -- build.py EXTRA_FLAGS -- so non-finite
+        # parameters are refused where they enter, once, when the layer is built)
+        if not bool(torch.isfinite(torch.as_tensor(W)).all()) or \
+                (b is not None and not bool(torch.isfinite(torch.as_tensor(b)).all())):
+            raise ValueError('non-finite convolution parameters (NaN / Inf in W or b)')
         self.W = torch.as_tensor(W).to(dtype).contiguous().to(device)
         self.b = None if b is None else torch.as_tensor(b).to(dtype).contiguous().to(device)
         self.layout = layout
@@ -402,7 +407,7 @@ class Conv:
     def __call__(self, x1, x2=None, pre=None, pooled=None, add=None, add_off=(0, 0),
                  window=None, out=None, out_c0=None, place=None, anchor=(0, 0), pool_out=None,
                  mask_in=None, unpool_hw=None, mask_out=None, store_out=True, out_format=None,
-                 in_c=None, bn=None, stats=None, fold=None):
+                 in_c=None, bn=None, stats=None, fold=None, zins=False):
         """x1 (B,C1,H,W) [+ x2 (B,C2,H,W): channel concat, x1 first].  With `pre`/`pooled`
         the logical input is the equality-mask unpool of x1 (DePool2D) at pre's size.
         `add` (B,Cout,AH,AW) is summed into the result starting at `add_off`;
@@ -423,8 +428,9 @@ class Conv:
         input."""
         if is_c8(x1):
             return self._call_c8(x1, x2, add, add_off, window, out, place, pool_out, mask_in,
-                                 unpool_hw, mask_out, store_out, out_format, out_c0, in_c, bn, stats, fold)
-        if in_c is not None or bn is not None or stats is not None or fold is not None:
+                                 unpool_hw, mask_out, store_out, out_format, out_c0, in_c, bn, stats, fold,
+                                 zins)
+        if zins or in_c is not None or bn is not None or stats is not None or fold is not None:
             raise RuntimeError('in_c / bn / stats: C8 input only (layers with at most 16 output channels)')
         dt = self.dtype
         unpool = pre is not None or mask_in is not None
@@ -796,14 +802,15 @@ class Conv:
         lib = self.lib
         unpool = mask_in is not None
         B = x1.shape[0]
-        in_ctot = x1.shape[1] * 8
-        C1 = in_ctot if in_c is None else int(in_c)
-        if C1 % 16 or C1 > in_ctot or C1 < self.Cin or C1 - self.Cin >= 16:
+        in_ctot = c8_ctot(x1)            # (x1 may be a channel slice of a wider tensor: the parent's count)
+        C1 = x1.shape[1] * 8 if in_c is None else int(in_c)
+        if C1 % 16 or C1 > x1.shape[1] * 8 or C1 < self.Cin or C1 - self.Cin >= 16:
             raise RuntimeError('conv of %d input channels on the first %d of %d C8 channels'
                                % (self.Cin, C1, in_ctot))
         if unpool:
             if unpool_hw is None or not is_c8_mask(mask_in) or tuple(mask_in.shape) != tuple(x1.shape) or \
-                    (unpool_hw[0] // 2, unpool_hw[1] // 2) != tuple(x1.shape[2:4]) or C1 != in_ctot:
+                    (unpool_hw[0] // 2, unpool_hw[1] // 2) != tuple(x1.shape[2:4]) or C1 != in_ctot or \
+                    not x1.is_contiguous():
                 raise RuntimeError('C8 DePool2D input: up %s, mask %s, unpool_hw %s'
                                    % (tuple(x1.shape), tuple(mask_in.shape), unpool_hw))
             H, W = int(unpool_hw[0]), int(unpool_hw[1])
@@ -832,10 +839,10 @@ class Conv:
             ok = out.dim() == 4 and out.dtype == torch.float32 and out.shape[1] == self.Cout and out_c0 is None
         else:
             ok = out.dim() == 5 and out.dtype == torch.bfloat16 and out.shape[1] % 2 == 0
-            if ok and (out_c0 is not None or out.shape[1] != 2):
+            if ok and (out_c0 is not None or out.shape[1] != 2 or not out.is_contiguous()):
                 c0 = int(out_c0 or 0)
                 ok = c0 % 16 == 0 and c0 + 16 <= out.shape[1] * 8
-                d.out_ctot, d.out_c0 = out.shape[1] * 8, c0
+                d.out_ctot, d.out_c0 = c8_ctot(out), c0
         if not ok or out.shape[0] != B or (place is None and tuple(out.shape[2:4]) != (OH, OW)):
             raise RuntimeError('bad output target %s for a 16-channel C8 layer' % (tuple(out.shape),))
         if bn is not None:
@@ -852,7 +859,7 @@ class Conv:
             check(lib.iiseg_conv_halo_bf16_pack(_stream(), C.byref(dp), _ptr(self.W), self.so, self.sc,
                                                 _ptr(self._W16c8, torch.bfloat16)),
                   'iiseg_conv_halo_bf16_pack')
-        dtp = lambda t: None if t is None else _ptr(t, t.dtype)
+        dtp = lambda t: None if t is None else (_c8ptr(t) if is_c8(t) else _ptr(t, t.dtype))
         prof = CONV_PROFILE
         ev0 = _ev() if prof is not None else None
         # split-K launches (small maps, long channel loops) sum their slices through a scratch buffer
@@ -884,7 +891,8 @@ class Conv:
         return out
 
     def _call_c8(self, x1, x2, add, add_off, window, out, place, pool_out, mask_in, unpool_hw,
-                 mask_out, store_out, out_format, out_c0=None, in_c=None, bn=None, stats=None, fold=None):
+                 mask_out, store_out, out_format, out_c0=None, in_c=None, bn=None, stats=None, fold=None,
+                 zins=False):
         """The layer on bf16 C8 activations (include/iiseg.h, iiseg_conv_c8).  x1 / x2 / pool_out:
         C8 tensors (`is_c8`); add: C8 bf16 or C8 fp32 (float32, same 5-D shape); mask_in / mask_out:
         uint8 (B, C/8, h, w, 8).  out_format: 'c8' (default), 'c8f32', or 'nchw' (fp32 NCHW, the
@@ -894,7 +902,7 @@ class Conv:
         if not self.c8:
             raise RuntimeError("C8 input needs a 3x3 layer built with mma='bf16c8'")
         if C8_M16 and self.Cout <= 16 and not self.x3 and x2 is None and add is None and pool_out is None and \
-                store_out and (out_format or 'c8') in ('c8', 'nchw'):
+                store_out and (out_format or 'c8') in ('c8', 'nchw') and not zins:
             return self._call_c8_m16(x1, window, out, place, mask_in, unpool_hw, out_format, out_c0, in_c, bn,
                                      stats, fold)
         if stats is not None or fold is not None:
@@ -914,8 +922,17 @@ class Conv:
                 raise RuntimeError('C8 DePool2D input: up %s, mask %s, unpool_hw %s'
                                    % (tuple(x1.shape), tuple(mask_in.shape), unpool_hw))
             H, W = int(unpool_hw[0]), int(unpool_hw[1])
+        elif zins:
+            # the logical input is x1 zero-inserted (include/iiseg.h IISEG_CONV_ZINS): TransitionUp
+            if x3 or x2 is not None or self.pad != 0:
+                raise RuntimeError('zero-inserted input: plain single-source valid layers')
+            H, W = 2 * x1.shape[2] + 3, 2 * x1.shape[3] + 3
         else:
             H, W = x1.shape[2], x1.shape[3]
+        # x1 as a channel slice of a wider C8 tensor (a dense block's stack): the parent's channel count
+        x1_ctot = 0 if x1.is_contiguous() else c8_ctot(x1)
+        if x1_ctot and (x3 or unpool):
+            raise RuntimeError('channel-slice input: plain bf16 launches only')
         CC2 = 0
         if x2 is not None:
             if not is_c8(x2) or x2.shape[0] != B or tuple(x2.shape[2:4]) != (H, W):
@@ -939,7 +956,7 @@ class Conv:
         d.Cout, d.KH, d.KW, d.pad, d.dil = self.Cout, 3, 3, self.pad, 1
         d.oy0, d.ox0, d.OH, d.OW = oy0, ox0, OH, OW
         d.flags = (CONV_RELU if self.relu else 0) | (CONV_UNPOOL if unpool else 0) | \
-            (CONV_X3 if x3 else 0)
+            (CONV_X3 if x3 else 0) | (CONV_ZINS if zins else 0)
         add_kind = 0
         if add is not None:
             add_kind = 1 if is_c8(add) else 2
@@ -969,7 +986,7 @@ class Conv:
                     out_c0 + oc8 * 8 > out.shape[1] * 8 or out.shape[0] != B or \
                     (place is None and tuple(out.shape[2:4]) != (OH, OW)):
                 raise RuntimeError('bad C8 output slice %s @%s' % (None if out is None else tuple(out.shape), out_c0))
-            d.out_ctot, d.out_c0 = out.shape[1] * 8, int(out_c0)
+            d.out_ctot, d.out_c0 = c8_ctot(out), int(out_c0)
         elif out is not None:
             ok = (out.dim() == 4 and out.dtype == torch.float32 and out.shape[1] == self.Cout) \
                 if fmt == 'nchw' else \
@@ -1008,15 +1025,18 @@ class Conv:
                                                 _ptr(self._W16c8, torch.bfloat16)),
                   'iiseg_conv_halo_bf16_pack')
             del Wsrc
-        dtp = lambda t: None if t is None else _ptr(t, t.dtype)
+        dtp = lambda t: None if t is None else (_c8ptr(t) if (is_c8(t) and t is not self._W16c8) else
+                                                _ptr(t, t.dtype))
+        if out is not None and is_c8(out) and not out.is_contiguous():
+            c8_ctot(out)                   # (validates the slice layout)
         # (the pool rides in the conv's epilogue on every pixel tiling: with pool_out the pixels of a
         # tile are ordered by 2x2 pooling windows)
         conv_out, conv_kind, conv_pool, conv_mask = out, kind, pool_out, mask_out
         prof = CONV_PROFILE
         ev0 = _ev() if prof is not None else None
-        check(lib.iiseg_conv_c8(_stream(), C.byref(d), dtp(x1), dtp(x2), dtp(mask_in),
-                                dtp(self._W16c8), _ptr(self.b), dtp(add), add_kind, dtp(conv_out),
-                                conv_kind, dtp(conv_pool), dtp(conv_mask)), 'iiseg_conv_c8')
+        check(lib.iiseg_conv_c8_slice(_stream(), C.byref(d), dtp(x1), int(x1_ctot), dtp(x2), dtp(mask_in),
+                                      dtp(self._W16c8), _ptr(self.b), dtp(add), add_kind, dtp(conv_out),
+                                      conv_kind, dtp(conv_pool), dtp(conv_mask)), 'iiseg_conv_c8_slice')
         if prof is not None:
             prof.append(('conv_c8_kernel<x3>' if x3 else 'conv_c8_kernel', self.flops(B, OH, OW), ev0,
                          _ev()))
@@ -1193,6 +1213,24 @@ def is_c8(t):
         t.shape[-1] == 8
 
 
+def c8_ctot(t):
+    """Channels per image of the C8 TENSOR the operand `t` lies in: `t` may be a channel slice
+    `parent[:, c0 // 8:c1 // 8]` of a contiguous C8 tensor (a dense block's stack inside the buffer of its
+    resolution) -- same image stride as the parent, data pointer at the slice's first chunk plane.  Raises
+    for any other non-contiguous layout."""
+    if not is_c8(t):
+        raise RuntimeError('expected a bf16 C8 tensor')
+    B, C8n, H, W, _ = t.shape
+    st = t.stride()
+    if tuple(st[1:]) != (H * W * 8, W * 8, 8, 1) or (B > 1 and (st[0] % (H * W * 8) or st[0] < C8n * H * W * 8)):
+        raise RuntimeError('C8 operand: a contiguous tensor or a channel slice of one, got strides %s' % (st,))
+    return C8n * 8 if B == 1 else st[0] // (H * W * 8) * 8
+
+
+def _c8ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
 def is_c8_mask(t):
     return isinstance(t, torch.Tensor) and t.dtype == torch.uint8 and t.dim() == 5 and t.shape[-1] == 8
 
@@ -1226,19 +1264,19 @@ def nchw_to_c8_slice(x, out8, c0):
     """fp32 NCHW (B, C, H, W) -> channels [c0, c0 + C) of the wider C8 tensor `out8` (c0 % 8 == 0; a
     partial last chunk is zero-padded)."""
     B, Cc, H, W = x.shape
-    if not is_c8(out8) or not out8.is_contiguous() or c0 % 8 or tuple(out8.shape[2:4]) != (H, W) or \
-            out8.shape[0] != B:
+    if not is_c8(out8) or c0 % 8 or tuple(out8.shape[2:4]) != (H, W) or out8.shape[0] != B:
         raise RuntimeError('nchw_to_c8_slice target %s @%d' % (tuple(out8.shape), c0))
     check(_lib.load().iiseg_nchw_to_c8_slice(_stream(), _ptr(x), C.c_void_p(out8.data_ptr()), B, Cc, H, W,
-                                             out8.shape[1], c0 // 8), 'iiseg_nchw_to_c8_slice')
+                                             c8_ctot(out8) // 8, c0 // 8), 'iiseg_nchw_to_c8_slice')
     return out8
 
 
 def c8_slice_to_nchw(x8, c0, channels, out=None):
     """Channels [c0, c0 + channels) of the C8 tensor `x8` -> fp32 NCHW."""
-    if not is_c8(x8) or not x8.is_contiguous() or c0 % 8:
-        raise RuntimeError('c8_slice_to_nchw needs a contiguous C8 tensor and c0 % 8 == 0')
-    B, C8n, H, W, _ = x8.shape
+    if not is_c8(x8) or c0 % 8:
+        raise RuntimeError('c8_slice_to_nchw needs a C8 tensor and c0 % 8 == 0')
+    B, _, H, W, _ = x8.shape
+    C8n = c8_ctot(x8) // 8
     if out is None:
         out = torch.empty((B, int(channels), H, W), dtype=torch.float32, device=x8.device)
     check(_lib.load().iiseg_c8_slice_to_nchw(_stream(), C.c_void_p(x8.data_ptr()), _ptr(out), B, int(channels),
@@ -1429,13 +1467,70 @@ def grad_update(score, gthrough, y, state, step, off=None):
                                  float(step)), 'iiseg_grad_update')
 
 
-def refine_finalize(state, eps):
+def refine_finalize(state, eps, nblk=None):
+    """`nblk`: partials per image the update kernel wrote (default: those of iiseg_refine_update_*; the context
+    module's fused tail writes one per 16 x 64 tile, `ctx_tail`)."""
     lib = _lib.load()
     check(lib.iiseg_refine_finalize(_stream(), _ptr(state.partial, torch.float64),
                                     _ptr(state.active, torch.int32),
                                     _ptr(state.iters, torch.int32),
-                                    _ptr(state.last_norm, torch.float64), state.B, state.nblk,
+                                    _ptr(state.last_norm, torch.float64), state.B,
+                                    state.nblk if nblk is None else int(nblk),
                                     state.H * state.W, float(eps)), 'iiseg_refine_finalize')
+
+
+CTX_TAIL = os.environ.get('IISEG_CTX_TAIL', '1') != '0'
+
+
+def ctx_tail_supported(conv6, conv7, y):
+    """Can `ctx_tail` run these two layers on this map?  (fp32, 3x3 'valid' dilation 1 + ReLU, then 1x1
+    linear, 12 to 16 padded channels on either side.)"""
+    Cc = y.shape[1]
+    return (CTX_TAIL and y.dtype == torch.float32 and conv6.dtype == torch.float32 and
+            (conv6.KH, conv6.KW, conv6.dil, conv6.pad, conv6.relu) == (3, 3, 1, 0, True) and
+            (conv7.KH, conv7.KW, conv7.pad, conv7.relu) == (1, 1, 0, False) and
+            conv6.Cin == conv6.Cout == conv7.Cin == conv7.Cout == Cc and 9 <= Cc <= 16 and
+            not conv6.transposed and not conv7.transposed)
+
+
+def ctx_tail(conv6, conv7, x, y, state, step, ycat=None, cat_c0=0, cat_off=(0, 0)):
+    """The context module's last two layers + the refinement update as ONE launch (include/iiseg.h,
+    iiseg_ctx_tail_f32): x (B, C, H + 2, W + 2) -> y (B, C, H, W) updated in place (and mirrored into channels
+    [cat_c0, cat_c0 + C) of `ycat` at `cat_off`).  Returns the number of norm partials per image it wrote
+    (pass it to `refine_finalize`)."""
+    lib = _lib.load()
+    B, Cc, H, W = y.shape
+    if tuple(x.shape) != (B, Cc, H + 2, W + 2):
+        raise RuntimeError('ctx_tail: x %s for y %s' % (tuple(x.shape), tuple(y.shape)))
+    d6, wp6, _ = conv6._plan(B, Cc, 0, H + 2, W + 2, None, None, False)
+    d7, wp7, _ = conv7._plan(B, Cc, 0, H, W, None, None, False)
+    nblk = lib.iiseg_ctx_tail_partials(H, W)
+    if B * nblk > state.partial.numel():
+        raise RuntimeError('ctx_tail: the state holds %d partials, %d needed' % (state.partial.numel(), B * nblk))
+    cat = (0, 0, 0, 0, 0, 0)
+    if ycat is not None:
+        if ycat.dim() != 4 or ycat.shape[0] != B or ycat.dtype != torch.float32:
+            raise RuntimeError('ctx_tail: ycat %s' % (tuple(ycat.shape),))
+        cat = (ycat.shape[1], int(cat_c0), ycat.shape[2], ycat.shape[3], int(cat_off[0]), int(cat_off[1]))
+    prof = CONV_PROFILE
+    ev0 = _ev() if prof is not None else None
+    check(lib.iiseg_ctx_tail_f32(_stream(), _ptr(x), _ptr(wp6), d6.Mpad, _ptr(conv6.b), _ptr(wp7), d7.Mpad,
+                                 _ptr(conv7.b), _ptr(y), _ptr(state.active, torch.int32),
+                                 _ptr(state.partial, torch.float64), _ptr(ycat), *cat, B, Cc, H, W, float(step)),
+          'iiseg_ctx_tail_f32')
+    if prof is not None:
+        kern = 'ctx_tail_kernel'
+        prof.append((kern, conv6.flops(B, H, W) + conv7.flops(B, H, W), ev0, _ev()))
+        # algorithmic bytes: x planes read, y read and written, the mirror written
+        KERNEL_BYTES[kern] = KERNEL_BYTES.get(kern, 0.0) + \
+            4.0 * B * Cc * ((H + 2) * (W + 2) + (3 if ycat is not None else 2) * H * W)
+    return nblk
+
+
+def count_nonfinite(x, counter):
+    """counter (int32, 1 element, device) += NaN / Inf elements of x (no synchronisation)."""
+    check(_fn('count_nonfinite', x.dtype)(_stream(), _ptr(x, x.dtype), int(x.numel()),
+                                          _ptr(counter, torch.int32)), 'iiseg_count_nonfinite')
 
 
 def confusion_accumulate(y, t, cm, sums, active=None):
@@ -1476,8 +1571,7 @@ class Conv1x1C8:
         return 2.0 * self.Cin * self.Cout * H * W * B
 
     def __call__(self, x8, in_c=None, bn=None, pool=False, out=None, out_c0=0):
-        if not is_c8(x8) or not x8.is_contiguous():
-            raise RuntimeError('Conv1x1C8 needs a contiguous C8 tensor')
+        in_ctot = c8_ctot(x8)            # (a contiguous C8 tensor or a channel slice of one)
         B, C8n, H, W, _ = x8.shape
         cin = int(in_c) if in_c is not None else C8n * 8
         if cin % 16 or cin > C8n * 8 or cin < self.Cin or cin - self.Cin >= 16:
@@ -1493,10 +1587,10 @@ class Conv1x1C8:
                 out = torch.zeros((B, c8_chunks(self.Cout), H // 2, W // 2, 8), dtype=torch.bfloat16,
                                   device=x8.device)
                 out_c0 = 0
-            if not is_c8(out) or not out.is_contiguous() or out.shape[0] != B or \
-                    tuple(out.shape[2:4]) != (H // 2, W // 2):
+            if not is_c8(out) or out.shape[0] != B or tuple(out.shape[2:4]) != (H // 2, W // 2) or \
+                    out_c0 + self.Cout > out.shape[1] * 8:
                 raise RuntimeError('Conv1x1C8 pool target %s' % (tuple(out.shape),))
-            octot = out.shape[1] * 8
+            octot = c8_ctot(out)
         else:
             if out is None:
                 out = torch.empty((B, self.Cout, H, W), dtype=torch.float32, device=x8.device)
@@ -1508,7 +1602,7 @@ class Conv1x1C8:
             raise RuntimeError('Conv1x1C8: folded BN vectors shorter than the input')
         prof = CONV_PROFILE
         ev0 = _ev() if prof is not None else None
-        check(self.lib.iiseg_conv1x1_c8(_stream(), C.c_void_p(x8.data_ptr()), B, cin, C8n * 8, H, W, _ptr(a),
+        check(self.lib.iiseg_conv1x1_c8(_stream(), C.c_void_p(x8.data_ptr()), B, cin, in_ctot, H, W, _ptr(a),
                                         _ptr(b_), _ptr(wp, torch.bfloat16), _ptr(self.b), self.Cout,
                                         1 if pool else 0, C.c_void_p(out.data_ptr()), octot, int(out_c0)),
               'iiseg_conv1x1_c8')
@@ -1534,12 +1628,13 @@ def bn_stats_c8(buf8, c0, n, mean, inv_std, eps=1e-4):
     inv_std[c0:c0+n] (float32 vectors)."""
     lib = _lib.load()
     B, C8n, H, W, _ = buf8.shape
+    ctot = c8_ctot(buf8)
     key = _ws_key(buf8.device)
     need = lib.iiseg_bn_stats_c8_workspace_elems(int(n))
     ws = _bn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _bn_ws[key] = torch.empty(int(need), dtype=torch.float64, device=buf8.device)
-    check(lib.iiseg_bn_stats_c8(_stream(), _ptr(buf8, torch.bfloat16), B, C8n * 8, int(c0), int(n), H, W,
+    check(lib.iiseg_bn_stats_c8(_stream(), _c8ptr(buf8), B, ctot, int(c0), int(n), H, W,
                                 float(eps), _ptr(mean), _ptr(inv_std), _ptr(ws, torch.float64)),
           'iiseg_bn_stats_c8')
 

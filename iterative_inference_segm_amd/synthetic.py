@@ -158,6 +158,23 @@ def make_damped_set(h_channels=(512,), concat_h=('pool4',), **dae_kw):
     return fp, dp, DAMPED['temperature']
 
 
+# The damped set of BASELINE configs[2] (FC-DenseNet103 + standard DAE, padding 0, h = pool4): the DAE's two
+# gains as above (the loop contracts), and the score layer of the DenseNet scaled by 1 / temperature (the same
+# confidence knob, applied to the 1x1 SoftmaxLayer conv of models/FCDenseNet.py:134: y0 confident, argmax-based
+# checks mean something).  tests/test_gpu_bf16.py, scripts/parity_c3.py.
+def make_damped_densenet_set(plan, seed=2024, dae_seed=4321):
+    """(densenet params, dae params) of the damped parity workload of configs[2]."""
+    params = make_densenet_params(plan, seed=seed)
+    last = dict(params[-1])
+    assert last['kind'] == 'softmax'
+    last['W'] = (last['W'] / DAMPED['temperature']).astype(np.float32)
+    last['b'] = (last['b'] / DAMPED['temperature']).astype(np.float32)
+    params = params[:-1] + [last]
+    dp = make_dae_params(h_channels=(464,), out_gain=DAMPED['out_gain'], dec_gain=DAMPED['dec_gain'],
+                         seed=dae_seed)
+    return params, dp
+
+
 def labels_from_map(y, void_frac=0.05, seed=99, block=16):
     """One-hot labels (N, C+1, H, W), void last, whose class map is the argmax of the probability
     map `y` (N, C, H, W) -- e.g. the float64-refined map of the damped set, so that the mIoU of a

@@ -438,6 +438,48 @@ def test_config3_densenet_on_c8_stacks(built_lib):
     assert list(host(iters)) == [10] * 32 and a.min() >= 0 and a.max() <= 1 and np.isfinite(a).all()
 
 
+def test_config3_as_written_parity_on_the_damped_set(built_lib):
+    """BASELINE configs[2] AS WRITTEN (FC-DenseNet103 + standard DAE, 224x224, batch 32, 10 steps, bf16 operands
+    and bf16 C8 activations, fp32 accumulate) with north_star's number: labels = argmax of the float64-refined
+    map (the float64 HIP path is pinned to the CPU oracle, tests/test_gpu_configs.py), so mIoU(float64) = 1 and
+    "mIoU within +-0.05 of the CPU reference" reads |mIoU(bf16c8) - 1| <= 0.05.  On the DAMPED set of this config
+    (synthetic.make_damped_densenet_set: contractive DAE loop, confident y0) -- on the chaotic default set only
+    the smoke check of test_config3_densenet_on_c8_stacks (agreement >= 0.9) is meaningful.
+    Measured (profiles/r05_parity_c3_32.md, same seeds): mIoU 0.951, refined argmax agreement 0.979 (the y0 of
+    103 batch-normalised layers on bf16 activations agrees with float64 on 0.979 of the pixels, h rel rms
+    3.5e-2; fp32 MFMA: 0.999998 / mIoU 1.000) -- the mIoU bound holds, an argmax agreement of 0.99 does NOT
+    and is not claimed."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    params, dp = S.make_damped_densenet_set(layer_plan())
+
+    def make(dtype, mma=None):
+        return IterativeInference(FCDenseNet(params, 11, layer=['pool4'], dtype=dtype, mma=mma),
+                                  StandardDAE(dp, 11, padding=0, dtype=dtype, mma=mma), 11, [11], dtype=dtype)
+    X = S.make_images(32, 224, 224, seed=7000)
+    ii64 = make(torch.float64)
+    o = ii64.pred_fcn_fn(X)
+    ref = ii64.refine(o[:-1], o[-1], 0.1, 10, early_stop=False)[0]
+    conf = float(o[-1].amax(1).mean())
+    T = S.labels_from_map(host(ref), seed=8000)
+    ref_arg = ref.argmax(1)
+    del ii64, o
+    torch.cuda.empty_cache()
+    ii8 = make(torch.float32, 'bf16c8')
+    o8 = ii8.pred_fcn_fn(X)
+    y8 = ii8.refine(o8[:-1], o8[-1], 0.1, 10, early_stop=False)[0]
+    agree = float((y8.argmax(1) == ref_arg).float().mean())
+    _, jacc, _ = ii8.val_fn(y8, T)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        miou = float(np.nanmean(jacc[0] / jacc[1]))
+    print('configs[2] as written, damped set, batch 32: mIoU %.5f (float64: 1 by construction), refined argmax '
+          'agreement %.6f, mean max-probability of y0 %.3f' % (miou, agree, conf))
+    assert abs(miou - 1.0) <= 0.05            # north_star: mIoU within +-0.05 of the (float64 = CPU) reference
+    assert agree >= 0.97 and conf >= 0.7
+
+
 def test_densenet_c8_small_against_float64(built_lib):
     """A small FC-DenseNet (2 pools, blocks [2, 2, 2, 2, 2]) on C8 stacks against the float64 HIP path on
     the same weights: every stage of the C8 forward (first conv into the stack slice, dense layers with

@@ -382,6 +382,65 @@ def _random_geometries(ops, force):
     assert n_flat <= 39 if force[0] == -1 else (n_flat == 0) if force[0] == 1 else n_flat >= 20
 
 
+@pytest.mark.parametrize('shape', [(2, 32, 38, 44, 64), (5, 48, 14, 14, 128), (2, 16, 21, 27, 64)])
+def test_conv_c8_pool_with_fp32_addend(ops, shape, tiling):
+    """The y half of the conv behind the h concat (models/fcn_down.py:102-122 after model_helpers.py:93-94):
+    conv + cached fp32 addend (the loop-invariant h half) + ReLU + 2x2 max-pool + mask bytes, only the pool
+    stored -- the straight-line epilogue EPI_POOL_ADD2 of conv_c8_kernel on every tiling."""
+    B, Cin, H, W, Cout = shape
+    rng = np.random.default_rng(H + Cout)
+    x = ints(rng, B, Cin, H, W, lo=-2, hi=3)
+    Wt, b, conv = layer(ops, rng, Cin, Cout)
+    addend = ints(rng, B, Cout, H + 3, W + 5, lo=-6, hi=7)
+    pre = np.maximum(onn.conv2d(x, Wt, b, pad=1, relu=False) + addend[:, :, 1:1 + H, 2:2 + W], 0)
+    pooled, bits = _masks(pre)
+    a8 = ops.nchw_to_c8(dev(addend)).float()
+    p8 = ops.empty_c8(B, Cout, H // 2, W // 2, 'cuda')
+    m8 = torch.zeros(p8.shape, dtype=torch.uint8, device='cuda')
+    assert conv(ops.nchw_to_c8(dev(x)), add=a8, add_off=(1, 2), pool_out=p8, mask_out=m8,
+                store_out=False) is None
+    assert np.array_equal(from_c8(p8, Cout), pooled)
+    assert np.array_equal(mask_from_c8(m8)[:, :Cout], bits)
+    # a window of whole pooling windows
+    p8.fill_(3.0); m8.fill_(255)
+    win = conv.pool_window(H, W, (4, 6, 8, 10))
+    conv(ops.nchw_to_c8(dev(x)), add=a8, add_off=(1 + win[0], 2 + win[1]), pool_out=p8, mask_out=m8,
+         store_out=False, window=win)
+    y0, x0, h, w = win[0] // 2, win[1] // 2, win[2] // 2, win[3] // 2
+    want_p = np.full_like(pooled, 3.0); want_m = np.full_like(bits, 255)
+    want_p[:, :, y0:y0 + h, x0:x0 + w] = pooled[:, :, y0:y0 + h, x0:x0 + w]
+    want_m[:, :, y0:y0 + h, x0:x0 + w] = bits[:, :, y0:y0 + h, x0:x0 + w]
+    assert np.array_equal(from_c8(p8, Cout), want_p)
+    assert np.array_equal(mask_from_c8(m8)[:, :Cout], want_m)
+
+
+@pytest.mark.parametrize('shape', [(3, 256, 20, 20, 64, (2, 3, 15, 14)), (6, 192, 12, 12, 128, None),
+                                   (2, 16, 30, 42, 64, None), (2, 128, 34, 36, 32, (0, 0, 34, 36))])
+def test_conv_c8_depool_long_k_with_skip_add(ops, shape, tiling):
+    """DePool2D staging (up chunk + mask bytes through registers) on 1 to 16 k-tiles with the decoder's skip
+    addend, every tiling, bit for bit."""
+    B, Cin, H, W, Cout, window = shape
+    rng = np.random.default_rng(Cin + W)
+    pre = ints(rng, B, Cin, H, W, lo=0, hi=3)
+    pooled, bits = _masks(pre)
+    up = ints(rng, B, Cin, H // 2, W // 2, lo=-1, hi=2)
+    unp = onn.depool_eqmask(up, pre, pooled)
+    Wt = ints(rng, Cout, Cin, 3, 3, lo=-1, hi=2)
+    b = ints(rng, Cout)
+    conv = ops.Conv(Wt, b, pad=1, relu=False, mma='bf16c8')
+    ref = onn.conv2d(unp, Wt, b, pad=1, relu=False)
+    skip = np.clip(-np.round(ref) + ints(rng, B, Cout, H, W, lo=-3, hi=4), -256, 256)
+    tot = ref + skip
+    assert np.abs(tot).max() <= 256
+    m = np.zeros((B, ops.c8_chunks(Cin), H // 2, W // 2, 8), dtype=np.uint8)
+    m[:] = bits.reshape(B, Cin // 8, 8, H // 2, W // 2).transpose(0, 1, 3, 4, 2)
+    y0, x0, h, w = window if window is not None else (0, 0, H, W)
+    kw = dict(window=window) if window is not None else {}
+    got = conv(ops.nchw_to_c8(dev(up)), mask_in=torch.from_numpy(m).cuda(), unpool_hw=(H, W),
+               add=ops.nchw_to_c8(dev(skip)), add_off=(y0, x0), **kw)
+    assert np.array_equal(from_c8(got, Cout), tot[:, :, y0:y0 + h, x0:x0 + w])
+
+
 DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 k-tiles: the deep layers)
     (5, 256, 13, 13, 64, 1, True, None),
     (3, 320, 22, 22, 128, 1, False, (5, 6, 10, 10)),

@@ -214,6 +214,42 @@ def test_config5_contextmod_50_steps(built_lib):
     assert np.abs(a32[:1] - yii_ref).max() <= TOL
 
 
+@pytest.mark.parametrize('size', [(224, 224), (37, 150)])
+def test_contextmod_fused_tail_is_bit_identical(built_lib, size, monkeypatch):
+    """dilconv6 + dilconv7 + softmax + update as ONE launch (csrc/conv_small.hip ctx_tail_kernel,
+    models/contextmod_dae.py:98-105 + iterative_inference.py:270-277) against the three separate launches:
+    the refined map bit for bit, the same iteration counts (stop test on), the norms to rounding (they are
+    summed per tile instead of per 256 pixels); eager loop and graph replay, two batches through one engine
+    (the second one replays the first one's captured step on the kept session buffers)."""
+    from iterative_inference_segm_amd import ops
+    from iterative_inference_segm_amd.contextmod import ContextModDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, cp = S.make_fcn8_params(), S.make_contextmod_params()
+    H, W = size
+    B = 3
+    Xs = [S.make_images(B, H, W, seed=411 + i) for i in range(2)]
+
+    def run(fused, graph):
+        monkeypatch.setattr(ops, 'CTX_TAIL', fused)
+        ii = _ii(FCN8(fp, 11, layer=['input', 'probs_dimshuffle']), ContextModDAE(cp, 11), F32)
+        outs = []
+        for X in Xs:
+            o = ii.pred_fcn_fn(X)
+            # eps chosen inside the range the norms pass through, so that images do stop on the way
+            r = ii.refine(o[:-1], o[-1], 0.5, 12, eps=0.02, graph=graph, first_reconstruction=True)
+            outs.append([host(t) for t in r])
+        return outs
+    ref = run(False, False)
+    for graph in (False, True):
+        got = run(True, graph)
+        for (y0, it0, n0, r0), (y1, it1, n1, r1) in zip(ref, got):
+            assert np.array_equal(y0, y1), np.abs(y0 - y1).max()
+            assert np.array_equal(r0, r1)
+            assert list(it0) == list(it1)
+            assert np.allclose(n0, n1, rtol=1e-9, atol=0)
+    print('contextmod fused tail %dx%d: iterations %s' % (H, W, [list(o[1]) for o in ref]))
+
+
 def test_config5_multi_concat_standard_dae_50_steps(built_lib):
     """Variant (ii), build-defined (no reference parity possible, SURVEY A9'): standard DAE with
     concat_h=['pool3','pool4'] (256 + 512 channels of the FCN-8 host), pad-100, 50 steps at

@@ -779,3 +779,36 @@ def test_depool_byte_masks_are_bit_identical_to_the_stored_pre_pool_maps(built_l
         gm = ii_m.refine(om[:-1], om[-1], 0.05, 2, mode='gradient')
         gp = ii_p.refine(op[:-1], op[-1], 0.05, 2, mode='gradient')
         assert np.array_equal(host(gm[0]), host(gp[0]))
+
+
+@pytest.mark.parametrize('mma', [None, 'bf16'])
+def test_nonfinite_images_are_detected_not_propagated(built_lib, mma):
+    """What the product promises about NaN / Inf (the fp32 / bf16 conv sources are built with
+    -fno-honor-nans, build.py EXTRA_FLAGS: a ReLU may swallow a NaN the reference would propagate): a
+    non-finite pixel is COUNTED when its batch enters pred_fcn_fn (device counter, no synchronisation) and
+    reading results raises -- val_fn / Metrics.result, check_finite (which also resets); clean batches pass."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp = S.make_fcn8_params(width_div=16, fc_channels=64, seed=1)
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=4, seed=2)
+    ii = IterativeInference(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], mma=mma),
+                            StandardDAE(dp, 11, n_filters=4, mma=mma), 11, [11])
+    X = S.make_images(2, 64, 48, seed=3)
+    T = S.make_labels(2, 64, 48, seed=4)
+    out = ii.pred_fcn_fn(X)
+    ii.val_fn(out[-1], T)
+    ii.check_finite()                                  # clean
+    for bad in (np.nan, np.inf):
+        Xb = X.copy()
+        Xb[1, 2, 17, 5] = bad
+        out = ii.pred_fcn_fn(Xb)
+        Yii = ii.refine(out[:-1], out[-1], 0.1, 2)[0]
+        with pytest.raises(FloatingPointError):
+            ii.val_fn(Yii, T)
+        with pytest.raises(FloatingPointError):
+            ii.check_finite()
+        ii.check_finite()                              # the counter was reset
+        out = ii.pred_fcn_fn(X)
+        ii.val_fn(out[-1], T)                          # and clean batches pass again

@@ -412,3 +412,57 @@ def test_conv_wino_f64_fused_unpool(ops, shape, window, anchor, monkeypatch):
         ref = ref[:, :, y0:y0 + h, x0:x0 + w]
     assert np.abs(got - ref).max() <= 1e-12 * (1 + np.abs(ref).max())
     assert np.array_equal(got, mat)
+
+
+_HALO_OFF_SCRIPT = r'''
+import sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from iterative_inference_segm_amd import synthetic as S, ops
+from iterative_inference_segm_amd.api import IterativeInference
+from iterative_inference_segm_amd.dae import StandardDAE
+from iterative_inference_segm_amd.fcn8 import FCN8
+from oracle import dae as odae, fcn8 as ofcn8, refine as orefine
+F64 = torch.float64
+to64 = lambda p: {k: tuple(np.asarray(a, np.float64) for a in v) for k, v in p.items()}
+fp = S.make_fcn8_params(width_div=16, fc_channels=64, seed=1)
+dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=4, seed=2)
+X = S.make_images(2, 64, 48, seed=3).astype(np.float64)
+fcn = FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=F64)
+dae = StandardDAE(dp, 11, concat_h=['pool4'], n_filters=4, dtype=F64)
+# with the halo-tile kernel off no float64 layer may promise the fused pool or the mask bytes
+convs = [c for c in list(vars(dae).values()) + list(vars(fcn).values()) if isinstance(c, ops.Conv)]
+for holder in (dae, fcn):
+    for v in vars(holder).values():
+        if isinstance(v, dict):
+            convs += [c for c in v.values() if isinstance(c, ops.Conv)]
+        if isinstance(v, (list, tuple)):
+            convs += [c for c in v if isinstance(c, ops.Conv)]
+assert convs, 'no Conv layers found'
+assert not any(c.pool_fusable() or c.mask_ok() for c in convs if c.dtype == F64)
+ii = IterativeInference(fcn, dae, 11, [11], dtype=F64)
+out = ii.pred_fcn_fn(X)
+Yii, iters, _ = ii.refine(out[:-1], out[-1], 0.1, 2)
+torch.cuda.synchronize()
+h_ref, y_ref = ofcn8.fcn8_forward(to64(fp), X, layer=['pool4', 'probs_dimshuffle'])
+dp64 = to64(dp)
+yii_ref, it_ref = orefine.refine_batch(lambda hh, yy: odae.dae_forward(dp64, hh, yy, n_filters=4),
+                                       [h_ref], y_ref, 0.1, 2)
+err = float(np.abs(Yii.cpu().numpy() - yii_ref).max())
+assert err <= 1e-9, err
+print('F64_HALO_OFF_OK %%.3g' %% err)
+'''
+
+
+def test_float64_path_with_only_the_halo_kernel_switched_off(built_lib):
+    """ADVICE round 4: IISEG_F64_HALO=0 ALONE (pool fusion and mask bytes left at their defaults) must fall
+    back to the static-tap kernel with separate pool / pre-pooled masks -- not raise 'conv + pool fusion is not
+    available' -- and still match the oracle.  The switch is read once per process: a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IISEG_F64_HALO='0')
+    r = subprocess.run([sys.executable, '-c', _HALO_OFF_SCRIPT % {'root': root}], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'F64_HALO_OFF_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

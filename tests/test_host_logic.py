@@ -257,3 +257,23 @@ def test_entry_point_two_ranks_dry_run(tmp_path):
     assert 'Jaccard: 1.0' in r.stdout
     cfgs = list((tmp_path / 'save').rglob('config.txt'))
     assert len(cfgs) == 1
+
+
+def test_nonfinite_weights_are_refused_when_a_layer_is_built():
+    """The conv kernels are compiled with relaxed NaN handling (build.py EXTRA_FLAGS): a NaN is not promised to
+    propagate (the reference's Theano `rectify` would hand it through, models/fcn_down.py:102-104).  The
+    product's promise instead: non-finite parameters never get in -- ops.Conv raises when it is built."""
+    import numpy as np
+    import pytest
+    from iterative_inference_segm_amd import build, ops
+    build.build()
+    W = np.ones((4, 3, 3, 3), np.float32)
+    b = np.zeros(4, np.float32)
+    ops.Conv(W, b, pad=1, relu=True, device='cpu')
+    for bad in (np.nan, np.inf, -np.inf):
+        Wb = W.copy(); Wb[1, 2, 0, 1] = bad
+        with pytest.raises(ValueError, match='non-finite'):
+            ops.Conv(Wb, b, pad=1, relu=True, device='cpu')
+        bb = b.copy(); bb[3] = bad
+        with pytest.raises(ValueError, match='non-finite'):
+            ops.Conv(W, bb, pad=1, relu=True, device='cpu')
