@@ -330,6 +330,13 @@ int iiseg_conv_c8_slice(void* stream, const iiseg_conv_desc* d, const void* x1, 
                         const void* x2, const uint8_t* mask_in, const void* wp16, const float* bias,
                         const void* add, int add_kind, void* out, int out_kind, void* pool_out,
                         uint8_t* mask_out);
+/* DePool2D materialised on C8 tensors (layers/mylayers.py:88-115) for the pooled-coordinate window
+ * (y0, x0, wh, ww): out (BC8, H, W, 8) bf16 <- up (BC8, H/2, W/2, 8) where the mask byte's bit (y & 1) * 2 +
+ * (x & 1) is set, else 0; elements outside the window are left as they are (rows / columns >= 2 (H/2), 2 (W/2)
+ * must be zero in `out`: they are never written).  The decoder levels with >= 1024 input channels unpool this way
+ * and convolve the result as a plain layer (LDS-DMA staging) instead of selecting through registers per tile. */
+int iiseg_unpool_c8(void* stream, const void* up, const uint8_t* mask, void* out, int BC8, int H, int W,
+                    int y0, int x0, int wh, int ww);
 /* The same layer for AT MOST 16 OUTPUT CHANNELS (csrc/conv_c8_m16.hip: v_mfma_f32_16x16x32_bf16, M = 16
  * channels, 16-pixel blocks, 256-pixel th x tw tiles, three workgroups per CU): the DAE's class-score
  * layer (models/fcn_up.py:83-86) and FC-DenseNet's growth-rate-16 dense-block layers

@@ -88,6 +88,7 @@ SIGNATURES = {
     'iiseg_conv_c8_tiling': (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int32)]),
     'iiseg_conv_c8': (C.c_int, [_vp, C.POINTER(ConvDesc)] + [_vp] * 6 + [_i32, _vp, _i32, _vp, _vp]),
     'iiseg_conv_c8_slice': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 5 + [_i32, _vp, _i32, _vp, _vp]),
+    'iiseg_unpool_c8': (C.c_int, [_vp] * 4 + [C.c_int] * 7),
     'iiseg_conv_c8_m16_supported': (C.c_int, [C.POINTER(ConvDesc)]),
     'iiseg_conv_c8_m16': (C.c_int, [_vp, C.POINTER(ConvDesc), _vp, _i32] + [_vp] * 6 + [_i32]),
     'iiseg_conv_c8_m16_workspace_bytes': (_i64, [C.POINTER(ConvDesc)]),

@@ -1047,6 +1047,40 @@ __global__ __launch_bounds__(256) void pool_mask_c8_kernel(const uint4* __restri
     }
 }
 
+// DePool2D materialised on C8 tensors (layers/mylayers.py:88-115): out[2 qy + dy][2 qx + dx] = up[qy][qx] where
+// bit dy * 2 + dx of the mask byte of the channel is set, else 0, for the pooled-coordinate window
+// (y0, x0, wh, ww); `out` (BC8, H, W, 8) full-size planes (rows / columns >= 2 h2 / 2 w2 are never written: the
+// caller keeps them zero).  One thread = one pooled element of a chunk: a 16-byte load + 8 mask bytes in, four
+// 16-byte stores out.  For the DEEP decoder levels (>= 1024 input channels, 10^2 - 19^2 windows): their conv then
+// stages its patch by LDS-DMA like any plain layer instead of selecting every chunk through registers once per
+// output-channel tile -- the unpooled map of such a level is a few tens of MB, the register staging costs the
+// conv 15-25 % (profiles/r05_c8_unpool_materialise.txt).
+__global__ __launch_bounds__(256) void unpool_c8_kernel(const uint4* __restrict__ up, const uint2* __restrict__ mask,
+                                                        uint4* __restrict__ out, int H, int W, int h2, int w2,
+                                                        int y0, int x0, int wh, int ww, int64_t total) {
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int qx = x0 + (int)(t % ww);
+        int64_t r = t / ww;
+        const int qy = y0 + (int)(r % wh);
+        r /= wh;                                    // b * C8n + c8
+        const int64_t pi = (r * h2 + qy) * w2 + qx;
+        const uint4 u = up[pi];
+        const uint2 m = mask[pi];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (the select of conv_c8_kernel's DePool2D staging: bit k of each mask byte -> 0x0000 / 0xffff per channel)
+            const unsigned t0 = (m.x >> k) & 0x01010101u, t1 = (m.y >> k) & 0x01010101u;
+            const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
+            uint4 v;
+            v.x = u.x & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
+            v.y = u.y & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
+            v.z = u.z & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
+            v.w = u.w & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
+            out[(r * H + 2 * qy + (k >> 1)) * W + 2 * qx + (k & 1)] = v;
+        }
+    }
+}
+
 // IISEG_CONV_X3 weights: w[co][c][3][3] (strides so, sc) -> out (Cout, 2 Cp, 3, 3) fp32 = [W_hi | W_lo],
 // W_hi = bf16(w) and W_lo = bf16(w - W_hi) as floats, channels >= Cin of each group zero -- the filter
 // iiseg_conv_halo_bf16_pack then packs unchanged (every value is a bf16 number)
@@ -1545,4 +1579,17 @@ extern "C" int iiseg_pool_mask_c8x3(void* stream, const void* pre, void* pooled,
     if (B <= 0 || C8n <= 0) return IISEG_ERR_SHAPE;
     return pool_mask_c8_impl(stream, pre, 1, pooled, mask, B * C8n, PH, PW, py0, px0, H, W, y0, x0, wh,
                              ww, C8n);
+}
+
+extern "C" int iiseg_unpool_c8(void* stream, const void* up, const uint8_t* mask, void* out, int BC8, int H, int W,
+                               int y0, int x0, int wh, int ww) {
+    if (!up || !mask || !out) return IISEG_ERR_NULL;
+    const int h2 = H / 2, w2 = W / 2;
+    if (BC8 <= 0 || H < 2 || W < 2 || wh <= 0 || ww <= 0 || y0 < 0 || x0 < 0 || y0 + wh > h2 || x0 + ww > w2)
+        return IISEG_ERR_SHAPE;
+    const int64_t total = (int64_t)BC8 * wh * ww;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    IISEG_LAUNCH(unpool_c8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint4*)up,
+                       (const uint2*)mask, (uint4*)out, H, W, h2, w2, y0, x0, wh, ww, total);
+    return iiseg_check_launch();
 }

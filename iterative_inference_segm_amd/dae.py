@@ -44,6 +44,11 @@ def param_order(concat_h=('pool4',), conv_before_pool=1, additional_pool=2,
     return names
 
 
+# mma='bf16c8': decoder levels with at least this many input channels materialise DePool2D (ops.unpool_c8) and run
+# their conv as a plain layer (0: every level unpools in its conv's patch staging)
+C8_UNPOOL_MIN_CIN = int(os.environ.get('IISEG_C8_UNPOOL_MIN_CIN', '1024'))
+
+
 def _center(big, small):
     return (big - small) // 2
 
@@ -623,7 +628,25 @@ class StandardDAE:
             if self.skip and p > 1:                      # :96-102 ElemwiseSumLayer, center crop
                 oth = pool_hw[p - 1]
                 kw.update(add=pool8[p - 1], add_off=(_center(oth[0], oh) + y0, _center(oth[1], ow) + x0))
-            t = conv(t, **kw)                            # else :104-113 CroppingLayer
+            if 0 < C8_UNPOOL_MIN_CIN <= conv.Cin and not self.x3 and conv.Cout > 16:
+                # Deep levels: DePool2D materialised first (a few tens of MB at these sizes), the conv then runs
+                # as a PLAIN layer -- LDS-DMA patch staging instead of up chunk + mask bytes selected through
+                # registers by every output-channel tile of every pixel tile (same values: bit-identical).  The
+                # map is kept per session (rows / columns past the last pooling window stay zero).
+                skey = 'unp%d' % p
+                u = session.get(skey) if session is not None else None
+                if u is None or tuple(u.shape) != (B, t.shape[1], ph, pw, 8):
+                    u = torch.zeros((B, t.shape[1], ph, pw, 8), dtype=torch.bfloat16, device=dev)
+                    if session is not None:
+                        session[skey] = u
+                wy0, wx0 = max(cy + y0 - 1, 0), max(cx + x0 - 1, 0)            # input rows / columns the window reads
+                wy1, wx1 = min(cy + y0 + nh + 1, 2 * (ph // 2)), min(cx + x0 + nw + 1, 2 * (pw // 2))
+                qy0, qx0 = wy0 // 2, wx0 // 2
+                ops.unpool_c8(t, masks[p], u, window=(qy0, qx0, (wy1 + 1) // 2 - qy0, (wx1 + 1) // 2 - qx0))
+                kw.pop('mask_in'); kw.pop('unpool_hw')
+                t = conv(u, **kw)
+            else:
+                t = conv(t, **kw)                        # else :104-113 CroppingLayer
             if self.conv_log is not None:
                 self.conv_log.append((name, conv.flops(B, ph, pw), conv.flops(B, nh, nw)))
         self._saved = None

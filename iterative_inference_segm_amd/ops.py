@@ -1306,6 +1306,21 @@ def c8_to_nchw(x8, channels, out=None, x3=False):
     return out
 
 
+def unpool_c8(up, mask, out, window=None):
+    """DePool2D materialised on C8 tensors (include/iiseg.h iiseg_unpool_c8): `out` (B, C8, H, W, 8) <- up
+    (B, C8, H/2, W/2, 8) under the mask bytes, for the pooled-coordinate `window` (y0, x0, h, w) (default: all);
+    the rest of `out` is left as it is."""
+    B, C8n, H, W, _ = out.shape
+    if not (is_c8(up) and is_c8(out) and is_c8_mask(mask)) or tuple(up.shape) != (B, C8n, H // 2, W // 2, 8) or \
+            tuple(mask.shape) != tuple(up.shape) or not (up.is_contiguous() and out.is_contiguous() and
+                                                          mask.is_contiguous()):
+        raise RuntimeError('unpool_c8: up %s mask %s out %s' % (tuple(up.shape), tuple(mask.shape), tuple(out.shape)))
+    y0, x0, wh, ww = window if window is not None else (0, 0, H // 2, W // 2)
+    check(_lib.load().iiseg_unpool_c8(_stream(), _c8ptr(up), C.c_void_p(mask.data_ptr()), _c8ptr(out), B * C8n,
+                                      H, W, int(y0), int(x0), int(wh), int(ww)), 'iiseg_unpool_c8')
+    return out
+
+
 def pool_mask_c8(pre, pooled, mask, origin, full_hw, window, x3=False):
     """2x2 max-pool (+ DePool2D mask bytes, `mask` may be None) of the pooled-coordinate `window`
     (y0, x0, h, w) from the stored piece `pre` (C8 bf16, or C8 fp32: the unrounded conv results)

@@ -441,6 +441,45 @@ def test_conv_c8_depool_long_k_with_skip_add(ops, shape, tiling):
     assert np.array_equal(from_c8(got, Cout), tot[:, :, y0:y0 + h, x0:x0 + w])
 
 
+def test_unpool_c8_materialised_and_the_deep_decoder_levels(ops, monkeypatch):
+    """ops.unpool_c8 (DePool2D materialised on C8 tensors, layers/mylayers.py:88-115) against the oracle, a
+    window of it, and the engine: the decoder levels with >= 1024 input channels that unpool this way and run
+    their conv as a plain layer give the SAME score map, bit for bit, as the levels that unpool in the conv's
+    patch staging (full-size standard DAE, h = pool4, two steps of one session)."""
+    rng = np.random.default_rng(77)
+    B, Cc, H, W = 3, 32, 13, 18
+    pre = ints(rng, B, Cc, H, W, lo=0, hi=3)
+    pooled, bits = _masks(pre)
+    up = ints(rng, B, Cc, H // 2, W // 2, lo=-5, hi=6)
+    ref = onn.depool_eqmask(up, pre, pooled)
+    m = np.zeros((B, ops.c8_chunks(Cc), H // 2, W // 2, 8), dtype=np.uint8)
+    m[:] = bits.reshape(B, Cc // 8, 8, H // 2, W // 2).transpose(0, 1, 3, 4, 2)
+    m8 = torch.from_numpy(m).cuda()
+    out = torch.zeros((B, ops.c8_chunks(Cc), H, W, 8), dtype=torch.bfloat16, device='cuda')
+    ops.unpool_c8(ops.nchw_to_c8(dev(up)), m8, out)
+    assert np.array_equal(from_c8(out, Cc), ref)
+    out.fill_(7.0)
+    ops.unpool_c8(ops.nchw_to_c8(dev(up)), m8, out, window=(1, 2, 3, 5))
+    want = np.full_like(ref, 7.0)
+    want[:, :, 2:8, 4:14] = ref[:, :, 2:8, 4:14]
+    assert np.array_equal(from_c8(out, Cc), want)
+    # the engine
+    from iterative_inference_segm_amd import dae as D, synthetic as S
+    dp = S.make_dae_params()
+    h = torch.from_numpy(rng.random((2, 512, 26, 26), dtype=np.float32)).cuda()
+    ys = [torch.softmax(torch.from_numpy(rng.standard_normal((2, 11, 224, 224)).astype(np.float32)).cuda(), 1)
+          for _ in range(2)]
+    res = {}
+    for mincin in (0, 1024):
+        monkeypatch.setattr(D, 'C8_UNPOOL_MIN_CIN', mincin)
+        net = D.StandardDAE(dp, 11, mma='bf16c8')
+        sess = net.new_session([h], ys[0])
+        res[mincin] = [host(net.scores([h], y, session=sess)) for y in ys]
+        assert ('unp6' in sess) == (mincin > 0) and ('unp4' not in sess)
+    for a, b in zip(res[0], res[1024]):
+        assert np.array_equal(a, b)
+
+
 DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 k-tiles: the deep layers)
     (5, 256, 13, 13, 64, 1, True, None),
     (3, 320, 22, 22, 128, 1, False, (5, 6, 10, 10)),
