@@ -41,6 +41,9 @@ namespace {
 // Patch capacity of every variant: 5 DMA rounds of 256 chunks = 640 chunks per 8-channel half (two
 // halves per 16-channel k-tile).  LDS per workgroup with 64 output channels: 2 x (18 KB weights +
 // 20 KB patch) = 76 KB, two workgroups per CU.
+#ifndef C8_STAGE_TAP
+#define C8_STAGE_TAP 0          // -1: stage the next k-tile at the top of the step (the round-4 order)
+#endif
 constexpr int C8_NE = 5;
 constexpr int C8_PCAP = C8_NE * 128;
 
@@ -453,18 +456,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             } else if (more) {
                 C8_DMA_W(xc + 1, (xc & 1) ^ 1)
             }
-        } else if constexpr (!UNPOOL) {
-            if (more && !(p.debug & 16)) {     // (debug 16: timing experiment, no DMA issued at all)
-                C8_DMA_X(2 * (kt + 1), pb ^ 1)
-                C8_DMA_W(kt + 1, wb ^ 1)
-            }
-        } else {
-            if (more) {
-                C8_LOAD_U(2 * (kt + 1), 2 * (kt + 1))
-                C8_DMA_W(kt + 1, wb ^ 1)
-                stored = pb ^ 1;
-            }
         }
+        // Plain mode: the next k-tile is staged BEHIND the MFMAs of tap 0 (below), not here: after the barrier a
+        // wave first fetches its tap-0 operands and starts the matrix pipe, and issues the ~20 DMA / load
+        // instructions of the next k-tile (address set-up included) while those MFMAs run -- at the top of the
+        // step they stood between the barrier and the first MFMA of every k-tile.
+        auto stage_next = [&]() __attribute__((always_inline)) {
+            if constexpr (!X3 && !UNPOOL) {
+                if (more && !(p.debug & 16)) {     // (debug 16: timing experiment, no DMA issued at all)
+                    C8_DMA_X(2 * (kt + 1), pb ^ 1)
+                    C8_DMA_W(kt + 1, wb ^ 1)
+                }
+            } else if constexpr (!X3) {
+                if (more) {
+                    C8_LOAD_U(2 * (kt + 1), 2 * (kt + 1))
+                    C8_DMA_W(kt + 1, wb ^ 1)
+                    stored = pb ^ 1;
+                }
+            }
+        };
+        constexpr int STAGE_TAP = NBUF == 1 ? -1 : C8_STAGE_TAP;     // (one-k-tile layers stage nothing)
+        if constexpr (STAGE_TAP < 0) stage_next();
         // operands of tap t+1 are read from LDS while the MFMAs of tap t run (two register sets)
         uint4 a[2][TM], bq[2][TN];
         auto lds_operands = [&](auto TAP, auto SET) __attribute__((always_inline)) {
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
                             __builtin_bit_cast(bf16x8, a[tap & 1][i]),
                             __builtin_bit_cast(bf16x8, bq[tap & 1][j]), acc[i][j], 0, 0, 0);
             }
+            if constexpr (tap == STAGE_TAP) stage_next();
             __builtin_amdgcn_sched_barrier(0);             // keep that order tap by tap
         });
         if constexpr (UNPOOL) {
