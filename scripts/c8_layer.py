@@ -33,6 +33,8 @@ LAYERS = {
     'dae.up_conv3': (256, 128, 105, 1, (24, 58), 'unpool'),
     'dae.up_conv2': (128, 64, 211, 1, (49, 113), 'unpool'),
     'dae.up_conv1': (64, 11, 422, 1, (99, 224), 'unpool'),
+    'dae.up_conv6p': (2048, 1024, 13, 1, (2, 10), 'plain'),     # the same levels as PLAIN layers (DePool2D materialised)
+    'dae.up_conv5p': (1024, 512, 26, 1, (5, 17), 'plain'),
 }
 name = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -62,6 +64,9 @@ else:
         f = lambda: conv(x8, window=pw, pool_out=po8, mask_out=mo8, store_out=False)
     else:
         f = lambda: conv(x8, window=window)
+if os.environ.get('IISEG_C8_FORCE_SPLIT'):      # slices of a chunked layer (include/iiseg.h iiseg_conv_c8_force_split)
+    from iterative_inference_segm_amd import _lib as _l
+    assert _l.load().iiseg_conv_c8_force_split(int(os.environ['IISEG_C8_FORCE_SPLIT'])) == 0
 f(); f()
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

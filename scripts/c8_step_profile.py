@@ -12,10 +12,19 @@ from iterative_inference_segm_amd import ops, synthetic as S
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 mode = sys.argv[2] if len(sys.argv) > 2 else 'bf16c8'
-ii, _, _ = bench.build_model('cuda', ['pool4'], mma=mode)
+cfg = sys.argv[3] if len(sys.argv) > 3 else 'c1'      # c1: configs[1] (FCN-8 + DAE); c3: configs[2] (FC-DenseNet103 + DAE)
+if cfg == 'c3':
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    ii = IterativeInference(FCDenseNet(S.make_densenet_params(layer_plan()), 11, layer=['pool4'], mma=mode),
+                            StandardDAE(S.make_dae_params(h_channels=(464,)), 11, padding=0, mma=mode), 11, [11])
+else:
+    ii, _, _ = bench.build_model('cuda', ['pool4'], mma=mode)
 Xs = [torch.from_numpy(S.make_images(B, 224, 224, seed=1234 + 1000 * i)).cuda() for i in range(2)]
 Ts = [torch.from_numpy(S.make_labels(B, 224, 224, seed=99 + 1000 * i)).cuda() for i in range(2)]
-ii.prepare(B, 224, 224)
+if cfg != 'c3':
+    ii.prepare(B, 224, 224)
 for i in range(3):
     bench.one_step(ii, Xs[i % 2], Ts[i % 2], 10, 0.1)
 rows = {}

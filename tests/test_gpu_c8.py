@@ -755,3 +755,32 @@ def test_conv_c8_m16_fused_statistics_and_next_fold(ops, shape):
     assert np.array_equal(host(m_got)[:n], host(mean)[:n]) and not host(m_got)[n + 16:].any()
     fa, fb = ops.bn_fold(b2, g2, m_got, i_got, n + 16, cap=cap)
     assert torch.equal(fa, a2) and torch.equal(fb, bb2)
+
+
+def test_c8_full_config_image_bits_do_not_depend_on_the_batch(built_lib):
+    """BASELINE configs[1] on bf16 C8 at full size: an image refined inside the batch of 64, in the reference's own
+    batch of 10 (iterative_inference.py:117) and in a batch of 3 gives BIT-IDENTICAL maps -- other pixel tilings
+    (the flat lists run across images), other workgroup counts, the three-stage ring the launches that leave the
+    chip half empty run on: every output is one fixed-order sum.  Data-parallel shards of any size therefore
+    reproduce the single-GPU result bit for bit."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp, dp = S.make_fcn8_params(), S.make_dae_params()
+
+    def make():
+        return IterativeInference(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], mma='bf16c8'),
+                                  StandardDAE(dp, 11, mma='bf16c8'), 11, [11])
+    X = S.make_images(64, 224, 224, seed=331)
+    ii = make()
+    o = ii.pred_fcn_fn(X)
+    Y64, _, n64 = ii.refine(o[:-1], o[-1], 0.1, 10, early_stop=False)
+    y0, Y64, n64 = host(o[-1]), host(Y64), host(n64)
+    for sub in (list(range(10)), [5, 17, 63]):
+        jj = make()
+        o2 = jj.pred_fcn_fn(X[sub])
+        assert np.array_equal(host(o2[-1]), y0[sub])
+        Y2, _, n2 = jj.refine(o2[:-1], o2[-1], 0.1, 10, early_stop=False)
+        assert np.array_equal(host(Y2), Y64[sub])
+        assert np.array_equal(host(n2), n64[sub])
