@@ -6,8 +6,8 @@ O=$R/$1; shift
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for L in "$@"; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES -d $O/a_$L --output-format csv -- python3 $R/scripts/c8_layer.py $L 3 > $O/a_$L.log 2>&1 || { tail -5 $O/a_$L.log; exit 1; }
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS -d $O/b_$L --output-format csv -- python3 $R/scripts/c8_layer.py $L 3 > $O/b_$L.log 2>&1 || { tail -5 $O/b_$L.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES -d $O/a_$L --output-format csv -- python3 $R/scripts/c8_layer.py $L 3 ${C8_LAYER_BATCH:-64} > $O/a_$L.log 2>&1 || { tail -5 $O/a_$L.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS -d $O/b_$L --output-format csv -- python3 $R/scripts/c8_layer.py $L 3 ${C8_LAYER_BATCH:-64} > $O/b_$L.log 2>&1 || { tail -5 $O/b_$L.log; exit 1; }
 done
 cd $R
 python3 - $O "$@" <<'PY'
