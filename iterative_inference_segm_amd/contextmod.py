@@ -11,6 +11,11 @@ import torch
 from . import ops
 from .weights import load_param_list
 
+# inside a refinement loop the image half of the first layer (3 of its 14 input channels; h is the image and does not
+# change) is computed once per batch and the y half CONTINUES its FMA chain from that map (bit-identical: the
+# chain is bias, then the channels in order, h first -- P13); 0: the whole layer every step
+CTX_HSPLIT = os.environ.get('IISEG_CTX_HSPLIT', '1') != '0'
+
 PARAM_ORDER = ['conv1'] + ['dilconv%d' % i for i in range(1, 8)]   # get_all_param_values (P14)
 DILATIONS = [1, 2, 4, 8, 16, 1]                                     # contextmod_dae.py:78-101
 
@@ -43,6 +48,8 @@ class ContextModDAE:
         self.dil1_valid = ops.Conv(W, b, pad=0, relu=True, dil=DILATIONS[0], layout='iohw', device=device,
                                    dtype=dtype)
         self._sessions = {}
+        self._conv1_params = (params['conv1'][0], params['conv1'][1], device, dtype)
+        self._hsplit = {}           # h channels -> (image-half conv, y-half conv) of the first layer
 
     def conv_layers(self):
         d = {'conv1': self.conv1, 'dilconv7': self.last}
@@ -60,18 +67,50 @@ class ContextModDAE:
         # The buffers are kept per geometry and handed out again (a captured refinement step points into them:
         # a new batch replays the same graph); what a call changes: the h channels (copied here) and the y
         # channels (every step).  The zero borders are written once.
-        key = (B, ch, y.shape[1], H, W, y.dtype, str(y.device))
+        split = CTX_HSPLIT and y.dtype == torch.float32
+        key = (B, ch, y.shape[1], H, W, y.dtype, str(y.device), split)
         sess = self._sessions.get(key)
         if sess is None:
-            # [h, y] with the one-pixel zero border of conv1's pad, and conv1's output inside PadLayer(32)'s zeros
-            cat = torch.zeros((B, ch + y.shape[1], H + 2, W + 2), dtype=y.dtype, device=y.device)
-            pad32 = torch.zeros((B, self.conv1.Cout, H + 64, W + 64), dtype=y.dtype, device=y.device)
+            # [h, y] with the one-pixel zero border of conv1's pad, and conv1's output inside PadLayer(32)'s zeros;
+            # split form: h and y in buffers of their own (both halves are dense single-source layers)
+            zeros = lambda c, hh, ww: torch.zeros((B, c, hh, ww), dtype=y.dtype, device=y.device)
+            pad32 = zeros(self.conv1.Cout, H + 64, W + 64)
             while len(self._sessions) >= 4:
                 self._sessions.pop(next(iter(self._sessions)))
-            sess = self._sessions[key] = {'cat': cat, 'ch': ch, 'pad32': pad32}
-        sess['cat'][:, :ch, 1:-1, 1:-1].copy_(h)
+            if split:
+                sess = {'hpad': zeros(ch, H + 2, W + 2), 'cat': zeros(y.shape[1], H + 2, W + 2), 'ch': 0,
+                        'hb': torch.empty((B, self.conv1.Cout, H, W), dtype=y.dtype, device=y.device),
+                        'pad32': pad32, 'split': self._split_convs(ch)}
+            else:
+                sess = {'cat': zeros(ch + y.shape[1], H + 2, W + 2), 'ch': ch, 'pad32': pad32, 'split': None}
+            self._sessions[key] = sess
+        if sess['split'] is not None:
+            # the loop-invariant image half: bias + the h channels' taps, linear, once per batch
+            sess['hpad'][:, :, 1:-1, 1:-1].copy_(h)
+            sess['split'][0](sess['hpad'], out=sess['hb'])
+        else:
+            sess['cat'][:, :ch, 1:-1, 1:-1].copy_(h)
         sess['y_in_cat'] = False        # the y channels hold another loop's map
         return sess
+
+    def _split_convs(self, ch):
+        pair = self._hsplit.get(ch)
+        if pair is None:
+            W, b, device, dtype = self._conv1_params
+            W = torch.as_tensor(W)
+            pair = self._hsplit[ch] = (
+                ops.Conv(W[:, :ch].contiguous(), b, pad=0, relu=False, device=device, dtype=dtype),
+                ops.Conv(W[:, ch:].contiguous(), None, pad=0, relu=True, device=device, dtype=dtype))
+        return pair
+
+    def _first_layer(self, session):
+        """conv1 of a session step into the PadLayer(32) buffer: the whole layer on [h, y], or its y half
+        continuing from the cached image half."""
+        if session['split'] is not None:
+            session['split'][1](session['cat'], add=session['hb'], add_off=(0, 0), out=session['pad32'],
+                                place=(32, 32))
+        else:
+            self.conv1_valid(session['cat'], out=session['pad32'], place=(32, 32))
 
     def scores(self, h_list, y, mask_override=None, session=None):
         if len(h_list) != 1:
@@ -80,7 +119,7 @@ class ContextModDAE:
             if not session.get('y_in_cat'):
                 session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
             session['y_in_cat'] = False      # (the caller's update changes y, not the buffer: see `fused_step`)
-            self.conv1_valid(session['cat'], out=session['pad32'], place=(32, 32))
+            self._first_layer(session)
             t = self.dil1_valid(session['pad32'])
             rest = self.dil[1:]
         else:
@@ -107,7 +146,7 @@ class ContextModDAE:
             return None
         if not session.get('y_in_cat'):
             session['cat'][:, session['ch']:, 1:-1, 1:-1].copy_(y)
-        self.conv1_valid(session['cat'], out=session['pad32'], place=(32, 32))
+        self._first_layer(session)
         t = self.dil1_valid(session['pad32'])
         for conv in self.dil[1:-1]:
             t = conv(t)

@@ -70,6 +70,20 @@ __global__ __launch_bounds__(256) void conv_small_f32_kernel(const ConvParams p,
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e][j] = bv;
     }
+    if (p.add) {
+        // (no bias then: the chain CONTINUES from the addend -- four pixels of a channel are one 16-byte load)
+        const int APL = p.AH * p.AW;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.add + (size_t)b * p.Cout * APL), 0, p.Cout * APL * 4, RSRC_W3);
+        const unsigned a0 = any_ok ? 4u * (unsigned)((p.ay0 + wy) * p.AW + p.ax0 + wx) : OOB;
+#pragma unroll
+        for (int c = 0; c < COP; ++c) {
+            const f32x4 av = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                ra, (int)((c < p.Cout && a0 != OOB) ? a0 + 4u * (unsigned)(c * APL) : OOB), 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e][c / 2][c & 1] = av[e];
+        }
+    }
     constexpr int CT = T == 9 ? 2 : 3;     // channels per trip: CT T weight rows = a multiple of the 3-row ring
     f32x4 xv[CT][T];
     auto load = [&](int c, int s) __attribute__((always_inline)) {
@@ -355,9 +369,12 @@ __global__ __launch_bounds__(256, COP <= 12 ? 3 : 2) void ctx_tail_kernel(const 
 // between at most 16 channels on either side, any dilation
 bool iiseg_conv_small_ok(const ConvParams& p, int KH, int KW) {
     static const int on = getenv("IISEG_CONV_SMALL") ? atoi(getenv("IISEG_CONV_SMALL")) : 1;
-    if (!on || p.transposed || p.pad != 0 || p.C2 != 0 || p.C1 > 16 || p.Cout > 16 || p.add || p.pool || p.mask_in ||
+    if (!on || p.transposed || p.pad != 0 || p.C2 != 0 || p.C1 > 16 || p.Cout > 16 || p.pool || p.mask_in ||
         p.mask_out || p.bn_mean || !p.out)
         return false;
+    // a skip-add only as the START of the FMA chain (no bias): the continuation of another launch's chain -- the
+    // y half of the context module's first layer starts from the cached image half (contextmod.py)
+    if (p.add && (p.bias || (int64_t)p.Cout * p.AH * p.AW * 4 >= (1ll << 31) - 16)) return false;
     if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3))) return false;
     if (p.Mpad < 16 || (p.Mpad & 3)) return false;
     if ((int64_t)p.C1 * p.H * p.W * 4 >= (1ll << 31) - 4) return false;      // per-image 32-bit byte offsets

@@ -658,10 +658,11 @@ class Conv:
             kern = self.kernel
             if dt == torch.float64 and self.lib.iiseg_conv_halo_f64_supported(C.byref(d)):
                 kern = 'conv_halo_f64_kernel'
-            if dt == torch.float32 and add is None and self.lib.iiseg_conv_small_supported(C.byref(d)):
+            if dt == torch.float32 and (add is None or self.b is None) and \
+                    self.lib.iiseg_conv_small_supported(C.byref(d)):
                 kern = 'conv_small_f32_kernel'         # vector ALU, HBM-bound: algorithmic bytes for the roofline
                 KERNEL_BYTES[kern] = KERNEL_BYTES.get(kern, 0.0) + \
-                    4.0 * B * (self.Cin * d.H * d.W + self.Cout * d.OH * d.OW)
+                    4.0 * B * (self.Cin * d.H * d.W + (2 if add is not None else 1) * self.Cout * d.OH * d.OW)
             if kern == 'conv_halo_f32_kernel' and C2 > 0 and C1 % 4:
                 kern = 'conv_taps_f32_kernel'      # a k-tile would straddle the two sources
             prof.append((kern, self.flops(B, d.OH, d.OW), ev0, ev1))

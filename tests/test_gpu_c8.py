@@ -480,6 +480,33 @@ def test_unpool_c8_materialised_and_the_deep_decoder_levels(ops, monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('case', [(3, 48, 9, 11, 64, 16, 96), (2, 32, 14, 14, 80, 0, 32), (5, 16, 5, 7, 48, 32, 64)])
+def test_conv_c8_zero_inserted_channel_slice_input(ops, case, tiling):
+    """FC-DenseNet's TransitionUp (models/FCDenseNet.py:118-121: Deconv2DLayer 3x3, stride 2, 'valid', P3) on the
+    C8 kernel: the block to upsample is read IN PLACE -- a channel slice [c0, c0 + Cin) of a wider stack -- and
+    zero-inserted by the kernel's own patch staging (IISEG_CONV_ZINS).  Against the oracle's transposed convolution
+    on integer data, bit for bit, whole map and a centre-crop window written into a slice of a wider output stack."""
+    B, Cin, H, W, Cout, c0, ctot = case
+    rng = np.random.default_rng(H * W + Cin)
+    stack = ints(rng, B, ctot, H, W, lo=-2, hi=3)
+    Wd = ints(rng, Cin, Cout, 3, 3, lo=-1, hi=2)                       # Deconv2DLayer W[in, out, 3, 3]
+    b = ints(rng, Cout)
+    ref = onn.deconv2d(stack[:, c0:c0 + Cin], Wd, b, stride=2)          # (B, Cout, 2 H + 1, 2 W + 1)
+    assert ref.shape[2:] == (2 * H + 1, 2 * W + 1) and np.abs(ref).max() <= 256
+    conv = ops.Conv(np.ascontiguousarray(Wd.transpose(1, 0, 2, 3)), b, pad=0, relu=False, mma='bf16c8')
+    s8 = ops.nchw_to_c8(dev(stack))
+    view = s8[:, c0 // 8:(c0 + Cin) // 8]
+    assert not view.is_contiguous() or c0 == 0 and Cin == ctot
+    got = conv(view, zins=True)
+    assert np.array_equal(from_c8(got, Cout), ref)
+    # centre crop to (2 H, 2 W) straight into channels [16, 16 + Cout) of a wider stack
+    out = torch.full((B, ops.c8_chunks(Cout) + 4, 2 * H, 2 * W, 8), 5.0, dtype=torch.bfloat16, device='cuda')
+    conv(view, zins=True, window=(0, 1, 2 * H, 2 * W), out=out, out_c0=16)
+    full = from_c8(out, out.shape[1] * 8)
+    assert np.array_equal(full[:, 16:16 + Cout], ref[:, :, 0:2 * H, 1:1 + 2 * W])
+    assert (full[:, :16] == 5.0).all() and (full[:, 16 + ops.c8_chunks(Cout) * 8:] == 5.0).all()
+
+
 DEEP_CASES = [  # B, Cin, H, W, Cout, pad, relu, window  (flat tiling, 16 to 32 k-tiles: the deep layers)
     (5, 256, 13, 13, 64, 1, True, None),
     (3, 320, 22, 22, 128, 1, False, (5, 6, 10, 10)),

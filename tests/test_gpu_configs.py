@@ -229,8 +229,12 @@ def test_contextmod_fused_tail_is_bit_identical(built_lib, size, monkeypatch):
     B = 3
     Xs = [S.make_images(B, H, W, seed=411 + i) for i in range(2)]
 
-    def run(fused, graph):
+    from iterative_inference_segm_amd import contextmod as CM
+
+    def run(fused, graph, hsplit=True):
         monkeypatch.setattr(ops, 'CTX_TAIL', fused)
+        # (the cached image half of the first layer -- the y half continues its FMA chain -- on and off as well)
+        monkeypatch.setattr(CM, 'CTX_HSPLIT', hsplit)
         ii = _ii(FCN8(fp, 11, layer=['input', 'probs_dimshuffle']), ContextModDAE(cp, 11), F32)
         outs = []
         for X in Xs:
@@ -239,9 +243,9 @@ def test_contextmod_fused_tail_is_bit_identical(built_lib, size, monkeypatch):
             r = ii.refine(o[:-1], o[-1], 0.5, 12, eps=0.02, graph=graph, first_reconstruction=True)
             outs.append([host(t) for t in r])
         return outs
-    ref = run(False, False)
-    for graph in (False, True):
-        got = run(True, graph)
+    ref = run(False, False, hsplit=False)
+    for fused, graph, hsplit in ((True, False, True), (True, True, True), (False, False, True), (True, True, False)):
+        got = run(fused, graph, hsplit)
         for (y0, it0, n0, r0), (y1, it1, n1, r1) in zip(ref, got):
             assert np.array_equal(y0, y1), np.abs(y0 - y1).max()
             assert np.array_equal(r0, r1)
