@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libiiseg_hip.so')
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 CONV_RELU = 1
 CONV_UNPOOL = 2

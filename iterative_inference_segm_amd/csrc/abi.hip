@@ -64,5 +64,5 @@ extern "C" const char* iiseg_last_hip_error(void) {
     return hipGetErrorString((hipError_t)iiseg_hip_error_slot());
 }
 
-extern "C" int iiseg_abi_version(void) { return 30; }
+extern "C" int iiseg_abi_version(void) { return 31; }
 extern "C" const char* iiseg_target_arch(void) { return "gfx950"; }

@@ -217,12 +217,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
 #pragma unroll
     for (int i = 0; i < NE; ++i) piece[i] = i * NT + wave_u * 64 < 2 * half;
 
+    constexpr bool UPQ = UNPOOL && !FLAT && !X3;      // DePool2D staged by pooled positions (below)
     // ---- patch staging offsets: chunk e = i * 256 + tid -> (half h, patch row, patch column) ----
     unsigned voff[NE];                 // byte offset of the chunk in its source (k-tile 0), or OOB
     unsigned voffm[UNPOOL ? NE : 1];   // UNPOOL: byte offset of its 8 mask bytes
     int bsel[UNPOOL ? NE : 1];         // UNPOOL: bit (y & 1) * 2 + (x & 1) of the mask byte
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
+    for (int i = 0; i < (UPQ ? 0 : NE); ++i) {
         const int e = i * NT + tid;
         const int h = e >= half ? 1 : 0;
         const int rr = e - h * half;
@@ -255,6 +256,43 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
             voff[i] = ok ? (unsigned)((b * IC1 + h) * hw2 + ((iy >> 1) - 1) * p.w2 + (ix >> 1) - 1) * 16u : OOB;
         } else {
             voff[i] = ok ? (unsigned)((b * IC1 + h) * HW + iy * p.W + ix) * 16u : OOB;
+        }
+    }
+    // UPQ (DePool2D input on RECT tiles): a thread stages POOLED positions -- one `up` chunk + its 8 mask bytes,
+    // two loads -- and writes the up to four patch elements of the 2x2 window (one select each, the mask bit a
+    // compile-time shift); the per-element form above fetches the same pooled chunk four times (3.4 x the vector
+    // memory instructions and their address arithmetic per k-tile, 30 instead of 12 staging registers).
+    constexpr int NQ = 2;              // pooled positions per thread and k-tile: 2 halves x at most 256
+    unsigned qoff[UPQ ? NQ : 1], qoffm[UPQ ? NQ : 1];
+    int qlds[UPQ ? NQ : 1][4];
+    bool pieceq[UPQ ? NQ : 1];
+    if constexpr (UPQ) {
+        const int iy0 = p.oy0 + wy0 - p.pad, ix0 = p.ox0 + wx0 - p.pad;      // patch origin, input coordinates
+        const int PH = p.th + 2;
+        const int Y20 = iy0 >> 1, X20 = ix0 >> 1;                            // (arithmetic shifts: floor)
+        const int QH = ((iy0 + PH - 1) >> 1) - Y20 + 1, QW = ((ix0 + PWs - 1) >> 1) - X20 + 1, QP = QH * QW;
+        const unsigned qw_magic = ((1u << 20) + (unsigned)QW - 1u) / (unsigned)QW;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int e = i * NT + tid;
+            const int h = e >= QP ? 1 : 0;
+            const int rr = e - h * QP;
+            const int qy = (int)(((unsigned)rr * qw_magic) >> 20), qx = rr - qy * QW;
+            const int Y2 = Y20 + qy, X2 = X20 + qx;
+            const bool in = e < 2 * QP;
+            // outside the h2 x w2 pooled map (padding, the odd trailing row / column) there is no window: the
+            // loads return zeros and the patch elements written from them are zeros (layers/mylayers.py:95-114)
+            const bool valid = in && (unsigned)Y2 < (unsigned)p.h2 && (unsigned)X2 < (unsigned)p.w2;
+            const unsigned pq = (unsigned)(h * hw2 + Y2 * p.w2 + X2);
+            qoff[i] = valid ? pq * 16u : OOB;
+            qoffm[i] = valid ? pq * 8u : OOB;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int py = 2 * Y2 + (sl >> 1) - iy0, px = 2 * X2 + (sl & 1) - ix0;
+                qlds[i][sl] = (in && (unsigned)py < (unsigned)PH && (unsigned)px < (unsigned)PWs)
+                                  ? h * half + py * PWs + px : -1;
+            }
+            pieceq[i] = i * NT + wave_u * 64 < 2 * QP;
         }
     }
     // sources: RECT = image tb of each tensor (32-bit offsets inside one image), FLAT = whole tensor
@@ -379,10 +417,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
     }
     // UNPOOL: up chunk (chunk KC of `up`) + mask bytes (chunk KM of the mask) into registers, selected
     // and written to LDS later
-    u32x4 xu[UNPOOL ? NE : 1];
-    u32x2 xm[UNPOOL ? NE : 1];
+    u32x4 xu[UNPOOL ? (UPQ ? NQ : NE) : 1];
+    u32x2 xm[UNPOOL ? (UPQ ? NQ : NE) : 1];
 #define C8_LOAD_U(KC, KM)                                                                          \
-    {                                                                                              \
+    if constexpr (UPQ) {                                                                           \
+        const unsigned so = (unsigned)((KC) * hw2) * 16u;                                          \
+        const unsigned som = (unsigned)((KM) * hw2) * 8u;                                          \
+        static_for<0, NQ>([&](auto I) __attribute__((always_inline)) {                             \
+            constexpr int i = decltype(I)::value;                                                  \
+            if (i == 0 || pieceq[i]) {                                                             \
+                xu[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(           \
+                    r_x1, (int)qoff[i], (int)so, 0));                                              \
+                xm[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(            \
+                    r_m, (int)qoffm[i], (int)som, 0));                                             \
+            }                                                                                      \
+        });                                                                                        \
+    } else {                                                                                       \
         const unsigned so = (unsigned)((KC) * hw2) * 16u;                                          \
         const unsigned som = (unsigned)((KM) * hw2) * 8u;                                          \
         static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                             \
@@ -396,6 +446,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : (NBUF == 1 ? (EPI != EPI_GEN
         });                                                                                        \
     }
 #define C8_STORE_U(BUF)                                                                            \
+    if constexpr (UPQ) {                                                                           \
+        static_for<0, NQ * 4>([&](auto I) __attribute__((always_inline)) {                         \
+            constexpr int i = decltype(I)::value / 4, sl = decltype(I)::value % 4;                 \
+            if (i > 0 && !pieceq[i]) return;                                                       \
+            /* bit sl of byte j of the mask pair: pre == pooled for channel j at the window's pixel sl */ \
+            const unsigned t0 = (xm[i][0] >> sl) & 0x01010101u;                                    \
+            const unsigned t1 = (xm[i][1] >> sl) & 0x01010101u;                                    \
+            const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;                               \
+            uint4 v;                                                                               \
+            v.x = xu[i][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);                           \
+            v.y = xu[i][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);                           \
+            v.z = xu[i][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);                           \
+            v.w = xu[i][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);                           \
+            if (qlds[i][sl] >= 0) Ps[BUF][qlds[i][sl]] = v;                                        \
+        });                                                                                        \
+    } else                                                                                         \
     static_for<0, NE>([&](auto I) __attribute__((always_inline)) {                                 \
         constexpr int i = decltype(I)::value;                                                      \
         if (i >= 3 && !piece[i]) return;                                                           \

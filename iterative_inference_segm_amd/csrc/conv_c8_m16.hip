@@ -143,6 +143,30 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
             voff[i] = ok ? (unsigned)(iy * p.W + ix) * 16u : OOB;
         }
     }
+    // M16_UNPOOL: staged by POOLED positions (one `up` chunk + its 8 mask bytes per 2x2 window, up to four patch
+    // elements written from them) instead of per patch element: a third of the loads of the layer that is bound
+    // by exactly those (the class-score layer: 42 % of its wave cycles parked on them, profiles/r04_pmc_layers.md).
+    // One pooled position per thread and half: (th + 2) / 2 + 1 rows x (tw + 2) / 2 + 1 columns <= 256 (host).
+    unsigned qoff = OOB, qoffm = OOB;
+    int qlds[4] = {-1, -1, -1, -1};
+    if constexpr (MODE == M16_UNPOOL) {
+        const int iy0 = p.oy0 + wy0 - p.pad, ix0 = p.ox0 + wx0 - p.pad;      // patch origin, input coordinates
+        const int PH = p.th + 2;
+        const int Y20 = iy0 >> 1, X20 = ix0 >> 1;                            // (arithmetic shifts: floor)
+        const int QH = ((iy0 + PH - 1) >> 1) - Y20 + 1, QW = ((ix0 + PWs - 1) >> 1) - X20 + 1;
+        const unsigned qw_magic = ((1u << 20) + (unsigned)QW - 1u) / (unsigned)QW;
+        const int qy = (int)(((unsigned)tid * qw_magic) >> 20), qx = tid - qy * QW;
+        const int Y2 = Y20 + qy, X2 = X20 + qx;
+        const bool in = tid < QH * QW;
+        const bool valid = in && (unsigned)Y2 < (unsigned)p.h2 && (unsigned)X2 < (unsigned)p.w2;
+        qoff = valid ? (unsigned)(Y2 * p.w2 + X2) * 16u : OOB;
+        qoffm = valid ? (unsigned)(Y2 * p.w2 + X2) * 8u : OOB;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            const int py = 2 * Y2 + (sl >> 1) - iy0, px = 2 * X2 + (sl & 1) - ix0;
+            qlds[sl] = (in && (unsigned)py < (unsigned)PH && (unsigned)px < (unsigned)PWs) ? py * PWs + px : -1;
+        }
+    }
     const int plane = MODE == M16_UNPOOL ? hw2 : HW;
     const char* base1 = (const char*)p.x1 + (size_t)tb * p.in_c8tot * plane * 16;
     const unsigned n1 = (unsigned)(CC * plane) * 16u;
@@ -220,13 +244,15 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int so = (int)((unsigned)((kc + h) * plane) * 16u);
+            if constexpr (MODE == M16_UNPOOL) {
+                xu[h][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)qoff, so, 0));
+                xm[h][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_m, (int)qoffm, so >> 1, 0));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
                 if (!piece[i]) continue;
                 xu[h][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)voff[i], so, 0));
-                if constexpr (MODE == M16_UNPOOL)
-                    xm[h][i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(
-                        r_m, (int)voffm[i], so >> 1, 0));
             }
         }
     };
@@ -248,19 +274,29 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { sa[q] = ca[c0 + q]; sb[q] = cb[c0 + q]; }
             }
+            if constexpr (MODE == M16_UNPOOL) {
+                // the four pixels of the thread's pooling window: bit sl of byte j of the mask pair says
+                // pre == pooled for channel j there (layers/mylayers.py:111-114)
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const unsigned t0 = (xm[h][0][0] >> sl) & 0x01010101u;
+                    const unsigned t1 = (xm[h][0][1] >> sl) & 0x01010101u;
+                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
+                    uint4 v;
+                    v.x = xu[h][0][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
+                    v.y = xu[h][0][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
+                    v.z = xu[h][0][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
+                    v.w = xu[h][0][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
+                    if (qlds[sl] >= 0) Ps[buf][h][qlds[sl]] = v;
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < NPC; ++i) {
                 if (!piece[i]) continue;
                 uint4 v;
                 if constexpr (MODE == M16_UNPOOL) {
-                    // byte j of the mask pair, bit bsel: pre == pooled at this pixel for channel j
-                    const unsigned t0 = (xm[h][i][0] >> bsel[i]) & 0x01010101u;
-                    const unsigned t1 = (xm[h][i][1] >> bsel[i]) & 0x01010101u;
-                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
-                    v.x = xu[h][i][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
-                    v.y = xu[h][i][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
-                    v.z = xu[h][i][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
-                    v.w = xu[h][i][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
+                    v = make_uint4(0u, 0u, 0u, 0u);      // (not reached: staged by pooled positions above)
                 } else {
                     // BatchNorm + ReLU of the stored bf16 values, rounded to bf16 once more; chunks of
                     // the zero-padding ring (out-of-range offset: the load returned zeros) stay zero
