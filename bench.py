@@ -48,6 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from iterative_inference_segm_amd import dist as iidist  # noqa: E402
+from iterative_inference_segm_amd.api import EnginePool  # noqa: E402
 from iterative_inference_segm_amd import synthetic as S  # noqa: E402
 
 N_CLASSES = 11
@@ -75,10 +76,29 @@ def build_model(device, concat_h, dtype=torch.float32, mma=None, fcn_mma='same')
     return IterativeInference(fcn, dae, N_CLASSES, [N_CLASSES], device=device, dtype=dtype), fp, dp
 
 
+def make_pool(n, build, X, T, num_iter, step_size, prepare=True):
+    """`n` engines from `build()` behind an api.EnginePool, load-time work done: the weights-only borders
+    of this geometry (`prepare`) and one batch per engine, which brings the lazily built state into being
+    (packed weights, workspaces, the captured HIP graph of the refinement step).  Untimed set-up, like
+    `prepare`; the W warm-up steps of the contract come after it."""
+    pool = EnginePool([build() for _ in range(max(1, n))])
+    if prepare:
+        pool.prepare(X.shape[0], X.shape[2], X.shape[3])
+    if len(pool) > 1:
+        for _ in range(len(pool)):
+            one_step(pool, X, T, num_iter, step_size)
+        pool.synchronize()
+    return pool
+
+
 def one_step(ii, X, T, num_iter, step_size, graph=None):
     """One batch of the per-batch path (iterative_inference.py:237-287); returns the device-side
     metric accumulators (refined, FCN, one-shot DAE).  graph=False: every step launched from
     Python (the roofline pass needs its per-launch events)."""
+    if isinstance(ii, EnginePool):
+        # whole batches in flight: this batch on the pool's next engine / stream (api.EnginePool)
+        with ii.lane(X, T) as engine:
+            return one_step(engine, X, T, num_iter, step_size, graph)
     out = ii.pred_fcn_fn(X)                                            # :237-239
     H, Y = out[:-1], out[-1]
     m_fcn = ii.val_device(Y, T)                                        # :242
@@ -275,7 +295,7 @@ HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 GFLOP_C3, GFLOP_C4 = 254.6, 1867.8      # nominal GFLOP per refined image, configs[2] / [3]
 
 
-def other_configs(device, step_size, no_roofline):
+def other_configs(device, step_size, no_roofline, n_fly=1):
     """BASELINE configs[2], [3], [4] (parity-test cases, not the headline): one warm-up + 3 timed
     batches each through the same per-batch path as the headline (`one_step`), and the conv roofline
     of the dominant kernel from HIP events (the same untimed extra pass).  Single GPU only."""
@@ -331,20 +351,22 @@ def other_configs(device, step_size, no_roofline):
     ]
     res = {}
     for key, build, mma, B, (H, W), steps, gflop, what in cases:
-        ii = build(mma)
         Xs = [torch.from_numpy(S.make_images(B, H, W, seed=4000 + i)).to(device) for i in range(2)]
         Ts = [torch.from_numpy(S.make_labels(B, H, W, seed=4100 + i)).to(device) for i in range(2)]
-        if hasattr(ii, 'prepare'):
-            ii.prepare(B, H, W)
-        one_step(ii, Xs[0], Ts[0], steps, step_size)
+        # small batches leave more of the chip idle per launch: one more batch in flight
+        nf = n_fly + 1 if n_fly > 1 and B <= 16 else n_fly
+        pool = make_pool(nf, lambda: build(mma), Xs[0], Ts[0], steps, step_size)
+        ii = pool.engines[0]
+        nt = 3 * nf
+        one_step(pool, Xs[0], Ts[0], steps, step_size)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(3):
-            one_step(ii, Xs[(i + 1) % 2], Ts[(i + 1) % 2], steps, step_size)
+        for i in range(nt):
+            one_step(pool, Xs[(i + 1) % 2], Ts[(i + 1) % 2], steps, step_size)
         torch.cuda.synchronize()
-        d = (time.perf_counter() - t0) / 3
+        d = (time.perf_counter() - t0) / nt
         ent = {'what': what, 'value': round(B / d, 2), 'unit': 'images/s', 'ms_per_step': round(d * 1e3, 2),
-               'batch': B, 'size': [H, W], 'num_iter': steps, 'timed_batches': 3,
+               'batch': B, 'size': [H, W], 'num_iter': steps, 'timed_batches': nt, 'in_flight': nf,
                'dtype': 'f32' if mma is None else 'bf16 operands, f32 accumulate, bf16 C8 activations'}
         if gflop is not None:
             ent['nominal_equivalent_tflops'] = round(B / d * gflop / 1e3, 1)
@@ -358,8 +380,15 @@ def other_configs(device, step_size, no_roofline):
             if 'gb_per_launch' in rl:
                 ent['roofline']['gb_per_launch'] = rl['gb_per_launch']
             ent['roofline']['whole_path_frac'] = rl['whole_path']['frac']
+        if nf > 1:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3):
+                one_step(ii, Xs[(i + 1) % 2], Ts[(i + 1) % 2], steps, step_size)
+            torch.cuda.synchronize()
+            ent['one_in_flight'] = round(3 * B / (time.perf_counter() - t0), 2)
         res[key] = ent
-        del ii, Xs, Ts
+        del ii, pool, Xs, Ts
         torch.cuda.empty_cache()
     return res
 
@@ -409,6 +438,10 @@ def compact_line(line, detail_file):
     if 'roofline' in line:
         out['roofline'] = _rl_short(line['roofline'], ('gflop_per_launch', 'kernel_ms_per_step',
                                                        'all_conv_ms_per_step'))
+    if 'in_flight' in line:
+        out['in_flight'] = line['in_flight']['engines']
+        if 'one_in_flight' in line['in_flight']:
+            out['one_in_flight'] = line['in_flight']['one_in_flight']['value']
     out['detail'] = detail_file
     for k in ('per_rank_images_per_s', 'metric_all_reduce_ms', 'executed_gflop_per_image'):
         if k in line:
@@ -430,6 +463,8 @@ def compact_line(line, detail_file):
         cf = {}
         for k, e in line['configs'].items():
             c = {'value': e['value'], 'ms': e['ms_per_step']}
+            if 'one_in_flight' in e:
+                c['in_flight'], c['one_in_flight'] = e['in_flight'], e['one_in_flight']
             rl = e.get('roofline')
             if rl:
                 c['kernel'], c['frac'] = rl['kernel'], rl['frac']
@@ -450,7 +485,8 @@ def compact_line(line, detail_file):
     # ---- the tail ----
     if 'strict_f64' in line:
         e = line['strict_f64']
-        out['strict_f64'] = {k: e[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'batch') if k in e}
+        out['strict_f64'] = {k: e[k] for k in ('value', 'unit', 'ms_per_step', 'dtype', 'batch', 'in_flight')
+                             if k in e}
     if 'cpu_baseline' in line:
         e = line['cpu_baseline']
         out['cpu_baseline'] = {'value': e['value'], 'unit': e['unit'], 'cores': e['cores'], 'kind': e['kind'],
@@ -461,6 +497,7 @@ def compact_line(line, detail_file):
     if 'bf16' in line:
         e = line['bf16']
         b = {'value': e['value'], 'unit': e['unit'], 'ms_per_step': e['ms_per_step'], 'mode': e['mode'],
+             'in_flight': e.get('in_flight', 1), 'one_in_flight': e.get('one_in_flight', {}).get('value'),
              'miou_iterative_inference': e['miou_iterative_inference'],
              'delta_miou_vs_f32': e['delta_miou_vs_f32']}
         d = e.get('damped_set_64_images', {})
@@ -574,8 +611,13 @@ def main():
     ap.add_argument('--bf16-mode', default='bf16c8', choices=['bf16c8', 'bf16'],
                     help="activations of the bf16 leg: 'bf16c8' = bf16 C8 chunks between the layers "
                          "(conv_c8_bf16.hip), 'bf16' = fp32 NCHW (round-2 form)")
-    ap.add_argument('--no-two-streams', action='store_true',
-                    help='skip the legs that run the batch as concurrent sub-batches on several HIP streams')
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help='whole batches in flight: engines of the api.EnginePool every leg runs on (each on '
+                         'its own HIP stream, batches round-robin; 1 = the single-stream path)')
+    ap.add_argument('--split-streams', action='store_true',
+                    help='also run the legs that split ONE batch into concurrent sub-batches on several HIP '
+                         'streams (the round-3/4 scheduling probe; whole batches in flight supersede it)')
+    ap.add_argument('--no-two-streams', action='store_true', help='(accepted and ignored: see --split-streams)')
     ap.add_argument('--streams', default='2', help='comma-separated stream counts of those legs')
     ap.add_argument('--all-legs', action='store_true',
                     help='N > 1: also run the per_batch_only / full_recompute / bf16 / strict_f64 legs '
@@ -607,9 +649,15 @@ def worker(args):
     concat_h = ['pool4']
     if world > 1 and not args.all_legs:
         # a scaling run measures the headline leg; the ablation legs are single-GPU diagnostics
-        args.no_full_recompute = args.no_bf16 = args.no_strict_f64 = args.no_two_streams = True
+        args.no_full_recompute = args.no_bf16 = args.no_strict_f64 = True
         args.no_bf16x3 = args.no_configs = args.no_early_stop = True
-    ii, fp, dp = build_model(device, concat_h)
+    args.no_two_streams = not args.split_streams
+    n_fly = max(1, args.in_flight)
+    built = []
+
+    def build_main():
+        built.append(build_model(device, concat_h))
+        return built[-1][0]
     B = args.batch
     # weak scaling: every rank refines its own shard of `B` synthetic images per step;
     # distinct image batches per step (up to 4, then rotating): nothing image-dependent can be
@@ -620,9 +668,10 @@ def worker(args):
     Ts = [torch.from_numpy(S.make_labels(B, 224, 224, seed=99 + rank + 1000 * i)).to(device)
           for i in range(n_distinct)]
     # load-time constant folding of the weights-only borders for this geometry (from a zero image)
-    ii.prepare(B, 224, 224)
+    pool = make_pool(n_fly, build_main, Xs[0], Ts[0], args.num_iter, args.step_size)
+    ii, fp, dp = built[0]
 
-    t0, results = timed_steps(ii, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
+    t0, results = timed_steps(pool, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
                               world, device)
     # the path's only collective: one all-reduce of the metric accumulator (RCCL over xGMI)
     accs = [iidist.EvalAccumulator(N_CLASSES) for _ in range(3)]
@@ -649,6 +698,18 @@ def worker(args):
         allr = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
         per_rank = [float(t.item()) for t in allr]
+
+    def leg(model, xs, ts, steps, warmup):
+        t1, _ = timed_steps(model, xs, ts, steps, warmup, args.num_iter, args.step_size, world, device)
+        torch.cuda.synchronize()
+        iidist.barrier()
+        d = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([d], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            d = float(tmax.item())
+        v = world * xs[0].shape[0] * steps / d
+        return {'value': round(v, 3), 'unit': 'images/s', 'ms_per_step': round(d / steps * 1e3, 2)}
 
     images = world * B * args.steps
     value = images / dt
@@ -681,6 +742,15 @@ def worker(args):
     prows, pfile = _parity_report()
     line['parity']['damped_set_64_images'] = dict(prows.get('fp32 MFMA', {}), source=pfile,
                                                   reference='float64 HIP path, pinned to the CPU oracle')
+    line['in_flight'] = {
+        'engines': n_fly,
+        'note': 'whole batches in flight (api.EnginePool): batch i runs on engine i %% %d, each engine on its '
+                'own HIP stream with its own sessions / graphs / scratch; every batch goes through exactly '
+                'the launches of the single-engine path (same kernels, same batch size, bit-identical '
+                'results: tests/test_gpu_e2e.py); ms_per_step = timed seconds / K, i.e. the rate, not the '
+                'latency of one batch' % n_fly}
+    if n_fly > 1:
+        line['in_flight']['one_in_flight'] = leg(ii, Xs, Ts, args.steps, 1)
     line['per_rank_images_per_s'] = [round(v, 1) for v in per_rank]
     line['metric_all_reduce_ms'] = round(t_ar * 1e3, 3)
     line['distinct_image_batches'] = n_distinct   # rotated through the timed steps (bit-identity of the
@@ -705,33 +775,25 @@ def worker(args):
         line['roofline'] = rl
         line['executed_gflop_per_image'] = round(rl['all_conv_gflop_per_step'] / B, 1)
 
-    def leg(model, xs, ts, steps, warmup):
-        t1, _ = timed_steps(model, xs, ts, steps, warmup, args.num_iter, args.step_size, world, device)
-        torch.cuda.synchronize()
-        iidist.barrier()
-        d = time.perf_counter() - t1
-        if world > 1:
-            tmax = torch.tensor([d], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            d = float(tmax.item())
-        v = world * xs[0].shape[0] * steps / d
-        return {'value': round(v, 3), 'unit': 'images/s', 'ms_per_step': round(d / steps * 1e3, 2)}
-
     if not args.no_full_recompute:
         # same timing protocol with the exact work eliminations switched off, in two stages:
         #   per_batch_only : nothing is kept from one batch to the next (no weights-only border
         #                    stores); decoder DCE / in-loop invariants / h-half stay on
         #   full_recompute : every layer of every step and batch recomputed in full
-        ii.fcn.fold_border = ii.dae.fold_border = False
-        line['per_batch_only'] = dict(leg(ii, Xs, Ts, args.steps, 1), note='IISEG_FCN_BORDER_FOLD=0 '
+        def knobs(border, loop):
+            for e in pool.engines:
+                e.fcn.fold_border = e.dae.fold_border = border
+                e.dae.dce = e.dae.licm = loop
+        knobs(False, True)
+        line['per_batch_only'] = dict(leg(pool, Xs, Ts, args.steps, n_fly), note='IISEG_FCN_BORDER_FOLD=0 '
                                       'IISEG_DAE_BORDER_FOLD=0: no state carried between batches')
-        ii.dae.dce = ii.dae.licm = False
+        knobs(False, False)
         line['full_recompute'] = dict(
-            leg(ii, Xs, Ts, args.steps, 1),
+            leg(pool, Xs, Ts, args.steps, n_fly),
             note='IISEG_DECODER_DCE=0 IISEG_ENCODER_LICM=0 IISEG_FCN_BORDER_FOLD=0 '
                  'IISEG_DAE_BORDER_FOLD=0: all 872.3 nominal GFLOP/image recomputed in full every '
                  'step and batch (same kernels)')
-        ii.dae.dce = ii.dae.licm = ii.fcn.fold_border = ii.dae.fold_border = True
+        knobs(True, True)
     def concurrent_leg(mma):
         """The same batch as N concurrent sub-batches: N engines (own nets, sessions, graphs and
         scratch), each on its own HIP stream, so that the tail of one engine's kernels (the last,
@@ -781,9 +843,10 @@ def worker(args):
         # 16-bit MFMA leg (VERDICT row N1; north_star: ">= 1000 images/s at >= 40 % of fp16 MFMA
         # peak"): bf16 operands + fp32 accumulation on the wide 3x3 layers, everything else as in
         # the fp32 run.  Statistical parity only; the headline `value` stays the fp32 line.
-        ii16, _, _ = build_model(device, concat_h, mma=args.bf16_mode)
-        ii16.prepare(B, 224, 224)
-        t1, res16 = timed_steps(ii16, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
+        pool16 = make_pool(n_fly, lambda: build_model(device, concat_h, mma=args.bf16_mode)[0], Xs[0], Ts[0],
+                           args.num_iter, args.step_size)
+        ii16 = pool16.engines[0]
+        t1, res16 = timed_steps(pool16, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
                                 world, device)
         acc16 = iidist.EvalAccumulator(N_CLASSES)
         for ms in res16:
@@ -803,7 +866,7 @@ def worker(args):
                  'dtype': 'bf16 operands, f32 accumulate' +
                           (', bf16 C8 activations between the 3x3 layers' if args.bf16_mode == 'bf16c8'
                            else ', fp32 NCHW activations'),
-                 'mode': args.bf16_mode,
+                 'mode': args.bf16_mode, 'in_flight': n_fly,
                  'ms_per_step': round(d16 / args.steps * 1e3, 2),
                  'miou_iterative_inference': round(miou16, 5),
                  'delta_miou_vs_f32': round(miou16 - miou, 5),
@@ -817,19 +880,22 @@ def worker(args):
         if not args.no_roofline:
             leg16['roofline'] = conv_roofline(ii16, X, T, args.num_iter, args.step_size,
                                               d16 / args.steps * 1e3, PEAK_TFLOPS_BF16_MFMA)
+        if n_fly > 1:
+            leg16['one_in_flight'] = leg(ii16, Xs, Ts, args.steps, 1)
         if not args.no_two_streams:
             leg16['concurrent_streams'] = concurrent_leg(args.bf16_mode)
         line['bf16'] = leg16
-        del ii16
+        del ii16, pool16
         torch.cuda.empty_cache()
     if not args.no_bf16x3:
         # the fp32-CLASS mode of the 16-bit matrix pipe (VERDICT row N1, mode (ii)): the DAE loop on
         # bf16 hi / lo pairs (16 significant bits per operand, x_lo W_hi + x_hi W_lo + x_hi W_hi in one
         # fp32 accumulation, csrc/conv_c8_bf16.hip X3), the FCN-8 on its fp32 MFMA kernels.  A leg:
         # the headline `value` stays the fp32-MFMA line.
-        iix3, _, _ = build_model(device, concat_h, mma='bf16x3')
-        iix3.prepare(B, 224, 224)
-        t1, resx3 = timed_steps(iix3, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
+        poolx3 = make_pool(n_fly, lambda: build_model(device, concat_h, mma='bf16x3')[0], Xs[0], Ts[0],
+                           args.num_iter, args.step_size)
+        iix3 = poolx3.engines[0]
+        t1, resx3 = timed_steps(poolx3, Xs, Ts, args.steps, args.warmup, args.num_iter, args.step_size,
                                 world, device)
         accx3 = iidist.EvalAccumulator(N_CLASSES)
         for ms in resx3:
@@ -843,7 +909,7 @@ def worker(args):
         legx3 = {'value': round(world * B * args.steps / dx3, 3), 'unit': 'images/s',
                  'dtype': 'bf16 hi/lo pairs (16 significant bits per operand), three bf16 MFMA products '
                           'per term, f32 accumulate; FCN-8 on the f32 MFMA kernels',
-                 'mode': 'bf16x3',
+                 'mode': 'bf16x3', 'in_flight': n_fly,
                  'ms_per_step': round(dx3 / args.steps * 1e3, 2),
                  'miou_iterative_inference': round(mioux3, 5),
                  'delta_miou_vs_f32': round(mioux3 - miou, 5),
@@ -862,18 +928,18 @@ def worker(args):
                                               'of a split-operand term (FLOPs counted once)')
         if not args.no_two_streams:
             legx3['concurrent_streams'] = concurrent_leg('bf16x3')
-        del iix3
+        del iix3, poolx3
         torch.cuda.empty_cache()
         # the opt-in form with the FCN-8's 3x3 layers on pairs too (FCN8(mma='bf16x3')): faster, and
         # 0.993 instead of 0.999 of the damped set's pixels within 1e-4 (tests/test_gpu_x3.py)
-        iix3, _, _ = build_model(device, concat_h, mma='bf16x3', fcn_mma='bf16x3')
-        iix3.prepare(B, 224, 224)
+        poolx3 = make_pool(n_fly, lambda: build_model(device, concat_h, mma='bf16x3', fcn_mma='bf16x3')[0],
+                           Xs[0], Ts[0], args.num_iter, args.step_size)
         legx3['fcn_on_pairs_too'] = dict(
-            leg(iix3, Xs, Ts, args.steps, args.warmup),
+            leg(poolx3, Xs, Ts, args.steps, args.warmup),
             note="FCN8(mma='bf16x3') as well: opt-in, lower parity (>= 0.99 of the damped set's pixels "
                  'within 1e-4 of float64 asserted, tests/test_gpu_x3.py)')
         line['bf16x3'] = legx3
-        del iix3
+        del poolx3
         torch.cuda.empty_cache()
     if not args.no_early_stop and world == 1:
         # The loop with the reference's stop test ON (iterative_inference.py:265-277, eps 1e-3, num_iter 50) on the
@@ -914,19 +980,20 @@ def worker(args):
     if not args.no_configs and world == 1:
         # BASELINE configs[2], [3], [4] next to the headline (parity-test cases: tests/test_gpu_configs.py)
         torch.cuda.empty_cache()
-        line['configs'] = other_configs(device, args.step_size, args.no_roofline)
+        line['configs'] = other_configs(device, args.step_size, args.no_roofline, n_fly)
     if not args.no_strict_f64:
         # the float64 path (reference CPU numerics): same config at batch 32, the leg
         # that carries the end-to-end 1e-4 parity claim (tests/test_gpu_f64.py)
-        del ii
+        del ii, pool
+        built.clear()
         torch.cuda.empty_cache()
         b64 = min(B, 32)
-        ii64, _, _ = build_model(device, concat_h, dtype=torch.float64)
-        ii64.prepare(b64, 224, 224)
         X64 = [x[:b64].to(torch.float64) for x in Xs[:2]]
         T64 = [t[:b64].to(torch.float64) for t in Ts[:2]]
-        f64 = leg(ii64, X64, T64, 3, 1)
-        f64.update(dtype='f64', batch=b64,
+        ii64 = make_pool(n_fly, lambda: build_model(device, concat_h, dtype=torch.float64)[0], X64[0], T64[0],
+                         args.num_iter, args.step_size)
+        f64 = leg(ii64, X64, T64, 4, 2)
+        f64.update(dtype='f64', batch=b64, in_flight=n_fly,
                    note='float64 HIP kernels (v_mfma_f64_16x16x4_f64; Winograd F(2x2,3x3) on the wide '
                         '3x3 layers), identical loop and work eliminations; refined map within 1e-4 '
                         'of the float64 oracle end to end '

@@ -812,3 +812,56 @@ def test_nonfinite_images_are_detected_not_propagated(built_lib, mma):
         ii.check_finite()                              # the counter was reset
         out = ii.pred_fcn_fn(X)
         ii.val_fn(out[-1], T)                          # and clean batches pass again
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mma', [None, 'bf16'])
+def test_engine_pool_batches_in_flight_are_bit_identical(built_lib, mma):
+    """api.EnginePool: batches handed round-robin to N engines on N HIP streams (whole batches in flight) give,
+    batch for batch, the bits of one engine working through them in order -- refined maps, iteration counts,
+    norms and the metric accumulators -- also when a lane gets a batch of another size in between."""
+    from iterative_inference_segm_amd import synthetic as S
+    from iterative_inference_segm_amd.api import EnginePool, IterativeInference
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    fp = S.make_fcn8_params(width_div=16, fc_channels=64, seed=1)
+    dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=4, seed=2)
+
+    def engine():
+        return IterativeInference(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], mma=mma),
+                                  StandardDAE(dp, 11, n_filters=4, mma=mma), 11, [11])
+    sizes = [3, 3, 3, 2, 3, 3, 2]
+    Xs = [torch.from_numpy(S.make_images(b, 64, 48, seed=30 + i)).cuda() for i, b in enumerate(sizes)]
+    Ts = [torch.from_numpy(S.make_labels(b, 64, 48, seed=60 + i)).cuda() for i, b in enumerate(sizes)]
+
+    def batch(ii, X, T):
+        out = ii.pred_fcn_fn(X)
+        y, its, nrm = ii.refine(out[:-1], out[-1], 0.1, 6, early_stop=False)[:3]
+        return y, its, nrm, ii.val_device(y, T)
+
+    single = engine()
+    single.prepare(3, 64, 48)
+    want = [batch(single, X, T) for X, T in zip(Xs, Ts)]
+    torch.cuda.synchronize()
+    for n in (2, 3):
+        pool = EnginePool([engine() for _ in range(n)])
+        assert len(pool) == n and len({s.cuda_stream for s in pool.streams}) == n
+        pool.prepare(3, 64, 48)
+        got = []
+        for X, T in zip(Xs, Ts):
+            with pool.lane(X, T) as ii:
+                assert torch.cuda.current_stream() == pool.streams[len(got) % n]
+                got.append(batch(ii, X, T))
+        pool.join()
+        for (y, its, nrm, m), (y0, its0, nrm0, m0) in zip(got, want):
+            assert torch.equal(y, y0) and torch.equal(its, its0) and torch.equal(nrm, nrm0)
+            m.result()                               # (Metrics.result waits for its own lane)
+            assert torch.equal(m.cm, m0.cm) and torch.equal(m.sums, m0.sums)
+    one = EnginePool([single])
+    assert one.streams == [None]
+    with one.lane(Xs[0]) as ii:
+        assert ii is single
+        y = batch(ii, Xs[0], Ts[0])[0]
+    one.join()
+    one.synchronize()
+    assert torch.equal(y, want[0][0])

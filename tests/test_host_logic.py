@@ -277,3 +277,19 @@ def test_nonfinite_weights_are_refused_when_a_layer_is_built():
         bb = b.copy(); bb[3] = bad
         with pytest.raises(ValueError, match='non-finite'):
             ops.Conv(W, bb, pad=1, relu=True, device='cpu')
+
+
+def test_engine_pool_needs_an_engine_and_one_engine_is_the_plain_path():
+    """api.EnginePool on the host: no engine is an error; a pool of one hands out that engine on the caller's
+    stream (no stream objects are made, so it also runs where there is no GPU)."""
+    from iterative_inference_segm_amd.api import EnginePool
+    with pytest.raises(ValueError):
+        EnginePool([])
+    e = object()
+    pool = EnginePool([e])
+    assert len(pool) == 1 and pool.streams == [None]
+    for _ in range(3):
+        with pool.lane() as got:
+            assert got is e
+    pool.join()
+    pool.synchronize()
