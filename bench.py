@@ -353,8 +353,9 @@ def other_configs(device, step_size, no_roofline, n_fly=1):
     for key, build, mma, B, (H, W), steps, gflop, what in cases:
         Xs = [torch.from_numpy(S.make_images(B, H, W, seed=4000 + i)).to(device) for i in range(2)]
         Ts = [torch.from_numpy(S.make_labels(B, H, W, seed=4100 + i)).to(device) for i in range(2)]
-        # small batches leave more of the chip idle per launch: one more batch in flight
-        nf = n_fly + 1 if n_fly > 1 and B <= 16 else n_fly
+        # batches of 32 and fewer leave more of the chip idle per launch: one more batch in flight (measured,
+        # 2 -> 3: configs[2] 2418 -> 2719, batch 10 1943 -> 2100 images/s; at batch 64 no difference)
+        nf = n_fly + 1 if n_fly > 1 and B <= 32 else n_fly
         pool = make_pool(nf, lambda: build(mma), Xs[0], Ts[0], steps, step_size)
         ii = pool.engines[0]
         nt = 3 * nf

@@ -8,9 +8,13 @@ Y_fcn).  Differences, all forced by the environment: lab paths keyed on getuser(
 (iterative_inference.py:32-51) become `--savepath/--loadpath/--weights_path`; dict flags are
 JSON; `--synthetic` supplies seeded data / weights when no checkpoint or dataset exists; with
 WORLD_SIZE > 1 (torchrun) batches shard over the GPUs of the node and the metric accumulators
-are all-reduced once (RCCL).  All arithmetic runs in the HIP kernels of libiiseg_hip.so.
+are all-reduced once (RCCL); on each GPU `--in_flight` batches (default 2) are being worked on at a
+time, each by its own engine on its own HIP stream (api.EnginePool), and the host reads a batch's
+results -- printing, batch%d.npz -- when the batch after it has been queued.  All arithmetic runs in
+the HIP kernels of libiiseg_hip.so.
 """
 import argparse
+import collections
 import json
 import os
 
@@ -19,7 +23,7 @@ import torch
 
 from iterative_inference_segm_amd import dist as iidist
 from iterative_inference_segm_amd import synthetic as S
-from iterative_inference_segm_amd.api import EPSILON, IterativeInference
+from iterative_inference_segm_amd.api import EPSILON, EnginePool, IterativeInference
 from iterative_inference_segm_amd.dae import buildDAE, param_order
 from iterative_inference_segm_amd.data_loader import load_data
 from iterative_inference_segm_amd.fcn8 import buildFCN8
@@ -152,14 +156,18 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
               full_im_ft=False, savepath=None, loadpath=None, test_from_0_255=False,
               weights_path=None, synthetic=False, n_images=20, image_size=(224, 224),
               batch_size=10, early_stop=True, save_npz=True, verbose=True, update='residual',
-              dry_run=False):
+              dry_run=False, in_flight=None):
     """Signature of reference iterative_inference.py:56-59 plus keyword-only extras.
     Returns a dict of the three summary lines (the reference returns None and only prints).
 
     dry_run: rehearse the multi-rank protocol without any HIP work (CPU, gloo): argument handling,
     rendezvous from the torchrun environment, rank-0 directory / config.txt creation, the sharding
     of the reference batches over ranks, one all-reduce of the three metric accumulators and the
-    summary from rank 0.  The per-batch "metrics" are counts of the synthetic labels themselves."""
+    summary from rank 0.  The per-batch "metrics" are counts of the synthetic labels themselves.
+
+    in_flight (default IISEG_IN_FLIGHT or 2): whole batches being worked on at a time on this GPU, each by
+    its own engine (own nets, sessions, graphs) on its own HIP stream; per-batch outputs and the running
+    totals are the same and come in the same order, one batch later."""
     # Update DAE parameters (:64-79)
     dae_dict = {'kind': 'fcn8', 'dropout': 0.0, 'skip': True, 'unpool_type': 'standard',
                 'n_filters': 64, 'conv_before_pool': 1, 'additional_pool': 0,
@@ -197,10 +205,19 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     if dry_run:
         return _dry_run(dataset, which_set, synthetic, n_images, image_size, batch_size,
                         test_from_0_255, rank, world, device, say)
-    ii, data_iter = build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_set,
-                                   device, synthetic=synthetic, n_images=n_images,
-                                   image_size=image_size, batch_size=batch_size,
-                                   test_from_0_255=test_from_0_255, say=say)
+    if in_flight is None:
+        in_flight = int(os.environ.get('IISEG_IN_FLIGHT', '2'))
+    in_flight = max(1, int(in_flight)) if device.type == 'cuda' else 1
+    engines = []
+    for k in range(in_flight):
+        ii, it_k = build_networks(dataset, segm_net, dae_dict, loadpath, weights_path, which_set,
+                                  device, synthetic=synthetic, n_images=n_images,
+                                  image_size=image_size, batch_size=batch_size,
+                                  test_from_0_255=test_from_0_255, say=say if k == 0 else (lambda *a, **kw: None))
+        engines.append(ii)
+        if k == 0:
+            data_iter = it_k
+    pool = EnginePool(engines, device=device)
     n_batches_test = data_iter.nbatches
     n_classes = data_iter.non_void_nclasses
     void_labels = data_iter.void_labels
@@ -210,21 +227,14 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     say('Start infering')
     say('Inference step: ' + str(learn_step) + 'num iter ' + str(num_iter))
     tot = {k: iidist.EvalAccumulator(n_classes) for k in ('fcn', 'dae', 'ii')}
-    for i in iidist.shard_batches(n_batches_test, rank, world):
-        say('-' * 30 + '\n' + '*' * 5 + 'Batch %d out of %d' % (i + 1, n_batches_test) + '*' * 5
-            + '\n' + '-' * 30)
-        X_test_batch, L_test_batch = data_iter.batch(i) if hasattr(data_iter, 'batch') \
-            else data_iter.next()
-        L_dev = torch.from_numpy(np.ascontiguousarray(L_test_batch, dtype=np.float32)).to(device)
-        pred = ii.pred_fcn_fn(X_test_batch)                      # :237-239
-        Y_test_batch, H_test_batch = pred[-1], pred[:-1]
-        m_fcn = ii.val_device(Y_test_batch, L_dev)               # :242
-        Y_dae = ii.pred_dae_fn(*(H_test_batch + [Y_test_batch]))  # :250
-        m_dae = ii.val_device(Y_dae, L_dev)                      # :251
-        Y_ii, iters, _ = ii.refine(H_test_batch, Y_test_batch, learn_step, num_iter,
-                                   eps=_EPSILON, early_stop=early_stop, mode=update)   # :257-284
-        m_ii = ii.val_device(Y_ii, L_dev)                        # :287
-        for key, m in (('fcn', m_fcn), ('dae', m_dae), ('ii', m_ii)):
+    pending = collections.deque()
+
+    def retire():
+        # the host side of the oldest batch in flight: metrics, running totals, batch%d.npz
+        i, X_b, L_b, Y_fcn, Y_ii, ms, done = pending.popleft()
+        if done is not None:
+            done.synchronize()
+        for key, m in zip(('fcn', 'dae', 'ii'), ms):
             acc, _, mse = m.result()
             tot[key].add_batch(m.cm.cpu().numpy(), acc, mse)
         if world == 1:
@@ -233,8 +243,33 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
                 loss, acc, miou, _, nb = tot[key].results()
                 say(label + '\n    Loss: %s\n    Acc: %s\n    Jaccard: %s' % (loss, acc, miou))
         if save_npz:                                             # :293 (with the path separator)
-            np.savez(os.path.join(savepath, 'batch' + str(i) + '.npz'), X=X_test_batch,
-                     L=L_test_batch, Y_ii=Y_ii.cpu().numpy(), Y_fcn=Y_test_batch.cpu().numpy())
+            np.savez(os.path.join(savepath, 'batch' + str(i) + '.npz'), X=X_b,
+                     L=L_b, Y_ii=Y_ii.cpu().numpy(), Y_fcn=Y_fcn.cpu().numpy())
+
+    for i in iidist.shard_batches(n_batches_test, rank, world):
+        say('-' * 30 + '\n' + '*' * 5 + 'Batch %d out of %d' % (i + 1, n_batches_test) + '*' * 5
+            + '\n' + '-' * 30)
+        X_test_batch, L_test_batch = data_iter.batch(i) if hasattr(data_iter, 'batch') \
+            else data_iter.next()
+        with pool.lane() as ii:     # the next engine; everything below is queued on its stream
+            L_dev = torch.from_numpy(np.ascontiguousarray(L_test_batch, dtype=np.float32)).to(device)
+            pred = ii.pred_fcn_fn(X_test_batch)                      # :237-239
+            Y_test_batch, H_test_batch = pred[-1], pred[:-1]
+            m_fcn = ii.val_device(Y_test_batch, L_dev)               # :242
+            Y_dae = ii.pred_dae_fn(*(H_test_batch + [Y_test_batch]))  # :250
+            m_dae = ii.val_device(Y_dae, L_dev)                      # :251
+            Y_ii, iters, _ = ii.refine(H_test_batch, Y_test_batch, learn_step, num_iter,
+                                       eps=_EPSILON, early_stop=early_stop, mode=update)   # :257-284
+            m_ii = ii.val_device(Y_ii, L_dev)                        # :287
+            # (results keep their own buffers: the engine's next batch does not overwrite them)
+            done = torch.cuda.Event() if device.type == 'cuda' else None
+            if done is not None:
+                done.record()
+        pending.append((i, X_test_batch, L_test_batch, Y_test_batch, Y_ii, (m_fcn, m_dae, m_ii), done))
+        if len(pending) >= len(pool):
+            retire()
+    while pending:
+        retire()
 
     # one all-reduce of the metric accumulators (RCCL over xGMI; no-op on one GPU)
     for acc in tot.values():
@@ -334,6 +369,9 @@ def main():
     parser.add_argument('--no_early_stop', action='store_true')
     parser.add_argument('--dry_run', action='store_true',
                         help='CPU rehearsal of the multi-rank protocol (gloo), no HIP work')
+    parser.add_argument('--in_flight', type=int, default=None,
+                        help='whole batches worked on at a time on each GPU (engines / HIP streams; default '
+                             'IISEG_IN_FLIGHT or 2; 1 = one batch after the other)')
     parser.add_argument('--update', choices=['residual', 'gradient'], default='residual',
                         help="'residual': the reference's y += step*(r - y) (default); 'gradient': "
                              "descend the true gradient of ||r(y|h) - y||^2 (extension)")
@@ -354,7 +392,8 @@ def main():
               training_dict=args.training_dict, weights_path=args.weights_path,
               synthetic=args.synthetic, n_images=args.n_images,
               image_size=tuple(args.image_size), batch_size=args.batch_size,
-              early_stop=not args.no_early_stop, update=args.update, dry_run=args.dry_run)
+              early_stop=not args.no_early_stop, update=args.update, dry_run=args.dry_run,
+              in_flight=args.in_flight)
 
 
 if __name__ == '__main__':

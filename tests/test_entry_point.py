@@ -184,3 +184,29 @@ def test_default_mma_bf16c8_with_the_non_standard_dae_kinds(built_lib, tmp_path,
         res[mma] = out['ii']
         assert out['ii']['batches'] == 1 and np.isfinite(out['ii']['loss'])
     assert abs(res['bf16c8']['jaccard'] - res['f32']['jaccard']) <= 0.05
+
+
+@pytest.mark.gpu
+def test_batches_in_flight_do_not_change_what_the_driver_writes(built_lib, tmp_path):
+    """inference(in_flight=N): N batches being worked on at a time (api.EnginePool, one engine / HIP stream
+    each) -- the summary and every batch%d.npz are those of the one-after-the-other run, bit for bit,
+    including the last, smaller batch and the early stop's host reads."""
+    import iterative_inference as ii
+    dd = {'kind': 'standard', 'unpool_type': 'trackind', 'n_filters': 4, 'additional_pool': 2,
+          'concat_h': ['pool4'], 'skip': True, 'from_gt': False}
+    outs = {}
+    for n in (1, 2, 3):
+        outs[n] = ii.inference('camvid', 'fcn8', 0.1, 5, dae_dict_updates=dd, savepath=str(tmp_path / ('s%d' % n)),
+                               loadpath=str(tmp_path / ('l%d' % n)), weights_path=str(tmp_path / 'w'),
+                               synthetic=True, n_images=9, image_size=(64, 48), batch_size=2, verbose=False,
+                               in_flight=n)
+        assert outs[n]['ii']['batches'] == 5
+    files = {n: sorted((tmp_path / ('s%d' % n)).rglob('batch*.npz')) for n in outs}
+    assert len(files[1]) == 5
+    for n in (2, 3):
+        assert json.dumps(outs[n], sort_keys=True) == json.dumps(outs[1], sort_keys=True)   # (NaN-safe)
+        assert [f.name for f in files[n]] == [f.name for f in files[1]]
+        for a, b in zip(files[1], files[n]):
+            with np.load(str(a)) as fa, np.load(str(b)) as fb:
+                for k in ('X', 'L', 'Y_fcn', 'Y_ii'):
+                    assert np.array_equal(fa[k], fb[k]), (n, a.name, k)
