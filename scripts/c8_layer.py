@@ -64,9 +64,6 @@ else:
         f = lambda: conv(x8, window=pw, pool_out=po8, mask_out=mo8, store_out=False)
     else:
         f = lambda: conv(x8, window=window)
-if os.environ.get('IISEG_C8_FORCE_SPLIT'):      # slices of a chunked layer (include/iiseg.h iiseg_conv_c8_force_split)
-    from iterative_inference_segm_amd import _lib as _l
-    assert _l.load().iiseg_conv_c8_force_split(int(os.environ['IISEG_C8_FORCE_SPLIT'])) == 0
 f(); f()
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
