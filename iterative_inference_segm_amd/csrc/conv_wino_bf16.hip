@@ -786,8 +786,19 @@ void launch_gemm_bf16(hipStream_t s, WinoBfParams p, float* M, int n_xi) {
         // carries twice the flops of the 256 x 128 form for 1.2x its time
         p.n_ttiles = p.Tpad / 256;
         p.n_mtiles = p.Mpad / 256;
-        IISEG_LAUNCH((wino_gemm_bf16_kernel<256, 256, 2, 4, 64, 2>),
-                           dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
+        // Plain GEMMs (fc6 / fc7: one long k-range per block, nothing else on the CU): 32-channel k-tiles in a
+        // four-deep ring -- the same LDS, three tiles in flight instead of one; same k order, same bits.  A/B on
+        // one box (scripts/fc_gemm_time.py, whole call): fc6 0.886 -> 0.822 ms, fc7 0.151 -> 0.152.  The Winograd
+        // GEMMs (16 points, short k-ranges) keep the two-deep 64-channel ring they were tuned on.
+        // IISEG_BF16_GEMM_VAR = 0 / 1 forces one form.
+        static const int env = getenv("IISEG_BF16_GEMM_VAR") ? atoi(getenv("IISEG_BF16_GEMM_VAR")) : -1;
+        const int var = env >= 0 ? env : (n_xi == 1 ? 1 : 0);
+        if (var == 1)
+            IISEG_LAUNCH((wino_gemm_bf16_kernel<256, 256, 2, 4, 32, 4>),
+                               dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
+        else
+            IISEG_LAUNCH((wino_gemm_bf16_kernel<256, 256, 2, 4, 64, 2>),
+                               dim3(n_xi * p.n_ttiles * p.n_mtiles), dim3(512), 0, s, p, M);
         return;
     }
     p.n_ttiles = p.Tpad / 128;
