@@ -24,6 +24,12 @@ step runs on a DIFFERENT image batch.  All are tested to give BIT-IDENTICAL refi
 also carries the run with the cross-batch border stores off (`per_batch_only`) and with every
 elimination off (`full_recompute`, all 872.3 nominal GFLOP/image executed).
 
+Scheduling.  Every leg runs with whole batches in flight (api.EnginePool, `--in-flight N`, default 2 -- one more for
+batches of 32 images and fewer): batch i on engine i % N, each engine on its own HIP stream with its own sessions /
+graphs / scratch.  Every batch goes through exactly the launches of the single-engine path (bit-identical results,
+tests/test_gpu_e2e.py); `ms_per_step` is timed seconds / K.  `one_in_flight` next to a value is the same leg on one
+engine; the roofline passes time one engine's launches one at a time.
+
 Extra objects on the ONE JSON line rank 0 prints:
   roofline     the dominant kernel from HIP events around every conv launch (extra, untimed pass
                behind a queued-up stream so that no bracket contains host launch gaps), plus
