@@ -353,3 +353,61 @@ def test_fcn8_kind_dae_full_size(built_lib):
     assert max(e32) <= TOL and res['f32'][4] == list(it_ref)
     b = res['bf16'][3]
     assert np.isfinite(b).all() and b.min() >= 0 and b.max() <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# whole batches in flight (api.EnginePool) on the other model families
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('family', ['densenet_c8', 'contextmod', 'fcn8_f64'])
+def test_engine_pool_other_families_bit_identical(built_lib, family):
+    """Batches round-robin over three engines / HIP streams against one engine in order, bit for bit: the
+    FC-DenseNet host on bf16 C8 stacks (per-geometry level buffers, batch-statistics BatchNorm scratch) with a
+    pad-0 DAE, the context-module DAE (kept sessions, fused tail, replayed graph) and the float64 path."""
+    from iterative_inference_segm_amd.api import EnginePool
+    from iterative_inference_segm_amd.contextmod import ContextModDAE
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    from iterative_inference_segm_amd.fcn8 import FCN8
+    if family == 'densenet_c8':
+        nl = [2, 3, 2, 2, 2, 2, 2, 2, 2, 3, 2]
+        dparams = S.make_densenet_params(layer_plan(n_layers_per_block=nl, n_first=16, growth=16), seed=7)
+        hch = 16 + 16 * (2 + 3 + 2 + 2)
+        dp = S.make_dae_params(h_channels=(hch,), n_filters=16, seed=9)
+        size, dtype = (64, 96), F32
+
+        def engine():
+            net = FCDenseNet(dparams, 11, layer=['pool4'], n_layers_per_block=nl, growth=16, mma='bf16c8')
+            return _ii(net, StandardDAE(dp, 11, n_filters=16, padding=0, mma='bf16c8'), F32)
+    elif family == 'contextmod':
+        fp, cp = S.make_fcn8_params(width_div=16, fc_channels=64, seed=1), S.make_contextmod_params()
+        size, dtype = (48, 70), F32
+
+        def engine():
+            return _ii(FCN8(fp, 11, layer=['input', 'probs_dimshuffle']), ContextModDAE(cp, 11), F32)
+    else:
+        fp = S.make_fcn8_params(width_div=16, fc_channels=64, seed=1)
+        dp = S.make_dae_params(h_channels=(fp['conv4_3'][0].shape[0],), n_filters=4, seed=2)
+        size, dtype = (64, 48), F64
+
+        def engine():
+            return _ii(FCN8(fp, 11, layer=['pool4', 'probs_dimshuffle'], dtype=F64),
+                       StandardDAE(dp, 11, n_filters=4, dtype=F64), F64)
+    Xs = [torch.from_numpy(S.make_images(3, size[0], size[1], seed=70 + i)).to(dtype).cuda() for i in range(7)]
+
+    def batch(ii, X):
+        out = ii.pred_fcn_fn(X)
+        return ii.refine(out[:-1], out[-1], 0.1, 6, early_stop=False)[:3]
+
+    single = engine()
+    want = [batch(single, X) for X in Xs]
+    torch.cuda.synchronize()
+    pool = EnginePool([engine() for _ in range(3)])
+    got = []
+    for X in Xs:
+        with pool.lane(X) as ii:
+            got.append(batch(ii, X))
+    pool.join()
+    torch.cuda.synchronize()
+    for k, (g, w) in enumerate(zip(got, want)):
+        for a, b in zip(g, w):
+            assert torch.equal(a, b), (family, k)
