@@ -13,8 +13,11 @@
 //     the latency of a k-tile's staging (a k-tile is 40 short MFMAs per wave: the next k-tile's loads,
 //     issued one k-tile ahead, are not back when they are needed), so what counts is work per staging
 //     round trip x workgroups in flight: 512-pixel tiles took 20 % off 256-pixel ones; two register sets
-//     with the loads issued two k-tiles ahead were built and measured SLOWER (0.154 vs 0.132 ms on the
-//     class-score layer: 190-210 registers, two workgroups per CU instead of three);
+//     with the loads issued two k-tiles ahead were built and measured SLOWER with the per-element staging
+//     (0.154 vs 0.132 ms on the class-score layer: 190-210 registers, two workgroups per CU instead of
+//     three); with DePool2D staged by pooled positions a set is 12 registers and the two-ahead form is what
+//     runs (140 registers, still three workgroups; 0.1250 -> 0.1220 ms over three alternating repeats: the
+//     layer issues 1140 vector instructions per 160 MFMAs and wave, that is what bounds it);
 //   * input staging per 8-channel half (the half is a compile-time constant of a piece): LDS-DMA, or
 //     through registers for DePool2D (up chunk + 8 mask bytes, layers/mylayers.py:88-115) and for
 //     BatchNorm + ReLU applied on the way in (per-channel scale / shift read as scalars; the padding
@@ -27,6 +30,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "iiseg.h"
 #include "common.h"
 #include "conv_common.h"
@@ -318,27 +322,7 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
 
     const int kt0 = p.phase == 1 ? p.nkt * sidx / S : 0;
     const int kt1 = p.phase == 1 ? p.nkt * (sidx + 1) / S : (p.phase == 2 ? 0 : p.nkt);
-    if (p.phase != 2) {
-        if constexpr (MODE == M16_PLAIN) {
-            dma_x(2 * kt0, 0);
-            dma_w(kt0, 0);
-        } else {
-            load_x(2 * kt0);
-            dma_w(kt0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            store_x(2 * kt0, 0);
-        }
-    }
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        // own DMA pieces (and LDS writes) retired, then the barrier publishes them and tells that every
-        // wave is done reading what the previous step read
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (more) {
-            if constexpr (MODE == M16_PLAIN) dma_x(2 * (kt + 1), buf ^ 1); else load_x(2 * (kt + 1));
-            dma_w(kt + 1, buf ^ 1);
-        }
+    auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
         const uint4* Wb = &Ws[buf][0];
         const uint4* Pb = &Ps[buf][0][0];
 #pragma unroll
@@ -353,10 +337,94 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
                 acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                                    __builtin_bit_cast(bf16x8, b[k]), acc[k], 0, 0, 0);
         }
-        if constexpr (MODE != M16_PLAIN) {
-            if (more) {
+    };
+    if constexpr (MODE == M16_UNPOOL) {
+        // DePool2D: one `up` chunk + 8 mask bytes per thread and half = 12 registers per k-tile, so TWO k-tiles
+        // are kept in registers and the loads of k-tile kt + 2 are issued at the top of step kt: when step kt + 1
+        // expands them into the LDS they are a whole step old (the workgroup-wide wait in front of the barrier
+        // has already covered them) and the wait between the MFMAs and the LDS writes is gone.  (Round 4 measured
+        // the same idea slower with the per-element staging: 48 registers per set, a workgroup less per CU.)
+        u32x4 qu[2][2];
+        u32x2 qk[2][2];
+        auto load_q = [&](auto SET, int kc) __attribute__((always_inline)) {
+            constexpr int s = decltype(SET)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int so = (int)((unsigned)((kc + h) * plane) * 16u);
+                qu[s][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)qoff, so, 0));
+                qk[s][h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_m, (int)qoffm, so >> 1, 0));
+            }
+        };
+        auto store_q = [&](auto SET, int buf) __attribute__((always_inline)) {
+            constexpr int s = decltype(SET)::value;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // the four pixels of the thread's pooling window: bit sl of byte j of the mask pair says
+                // pre == pooled for channel j there (layers/mylayers.py:111-114)
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const unsigned t0 = (qk[s][h][0] >> sl) & 0x01010101u;
+                    const unsigned t1 = (qk[s][h][1] >> sl) & 0x01010101u;
+                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
+                    uint4 v;
+                    v.x = qu[s][h][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
+                    v.y = qu[s][h][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
+                    v.z = qu[s][h][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
+                    v.w = qu[s][h][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
+                    if (qlds[sl] >= 0) Ps[buf][h][qlds[sl]] = v;
+                }
+            }
+        };
+        typedef std::integral_constant<int, 0> S0;
+        typedef std::integral_constant<int, 1> S1;
+        if (p.phase != 2 && kt0 < kt1) {
+            load_q(S0{}, 2 * kt0);
+            dma_w(kt0, 0);
+            if (kt0 + 1 < kt1) load_q(S1{}, 2 * (kt0 + 1));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            store_q(S0{}, 0);
+        }
+        // step kt: k-tile kt is in LDS buffer `buf`, k-tile kt + 1 in register set SET ^ 1 (loaded or in flight)
+        auto step = [&](auto SET, int kt) __attribute__((always_inline)) {
+            constexpr int s = decltype(SET)::value;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 1 < kt1) dma_w(kt + 1, s ^ 1);
+            if (kt + 2 < kt1) load_q(SET, 2 * (kt + 2));
+            mfma_tile(s);
+            if (kt + 1 < kt1) store_q(std::integral_constant<int, s ^ 1>{}, s ^ 1);
+        };
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            step(S0{}, kt);
+            if (kt + 1 < kt1) step(S1{}, kt + 1);
+        }
+    } else {
+        if (p.phase != 2) {
+            if constexpr (MODE == M16_PLAIN) {
+                dma_x(2 * kt0, 0);
+                dma_w(kt0, 0);
+            } else {
+                load_x(2 * kt0);
+                dma_w(kt0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                store_x(2 * (kt + 1), buf ^ 1);
+                store_x(2 * kt0, 0);
+            }
+        }
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            const bool more = kt + 1 < kt1;
+            // own DMA pieces (and LDS writes) retired, then the barrier publishes them and tells that every
+            // wave is done reading what the previous step read
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (more) {
+                if constexpr (MODE == M16_PLAIN) dma_x(2 * (kt + 1), buf ^ 1); else load_x(2 * (kt + 1));
+                dma_w(kt + 1, buf ^ 1);
+            }
+            mfma_tile(buf);
+            if constexpr (MODE != M16_PLAIN) {
+                if (more) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    store_x(2 * (kt + 1), buf ^ 1);
+                }
             }
         }
     }
