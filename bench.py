@@ -25,7 +25,7 @@ also carries the run with the cross-batch border stores off (`per_batch_only`) a
 elimination off (`full_recompute`, all 872.3 nominal GFLOP/image executed).
 
 Scheduling.  Every leg runs with whole batches in flight (api.EnginePool, `--in-flight N`, default 2 -- one more for
-batches of 32 images and fewer): batch i on engine i % N, each engine on its own HIP stream with its own sessions /
+batches of 32 images and fewer, two more for 16 and fewer): batch i on engine i % N, each engine on its own HIP stream with its own sessions /
 graphs / scratch.  Every batch goes through exactly the launches of the single-engine path (bit-identical results,
 tests/test_gpu_e2e.py); `ms_per_step` is timed seconds / K.  `one_in_flight` next to a value is the same leg on one
 engine; the roofline passes time one engine's launches one at a time.
@@ -359,9 +359,10 @@ def other_configs(device, step_size, no_roofline, n_fly=1):
     for key, build, mma, B, (H, W), steps, gflop, what in cases:
         Xs = [torch.from_numpy(S.make_images(B, H, W, seed=4000 + i)).to(device) for i in range(2)]
         Ts = [torch.from_numpy(S.make_labels(B, H, W, seed=4100 + i)).to(device) for i in range(2)]
-        # batches of 32 and fewer leave more of the chip idle per launch: one more batch in flight (measured,
-        # 2 -> 3: configs[2] 2418 -> 2719, batch 10 1943 -> 2100 images/s; at batch 64 no difference)
-        nf = n_fly + 1 if n_fly > 1 and B <= 32 else n_fly
+        # batches of 32 and fewer leave more of the chip idle per launch: one more batch in flight, two more for
+        # 16 and fewer (measured, configs[2] 2 -> 3: 2418 -> 2719; batch 10, 3 -> 4: 1943 -> 2100, 1677 -> 2350
+        # images/s; at batch 64 no difference)
+        nf = n_fly + (2 if B <= 16 else 1 if B <= 32 else 0) if n_fly > 1 else n_fly
         pool = make_pool(nf, lambda: build(mma), Xs[0], Ts[0], steps, step_size)
         ii = pool.engines[0]
         nt = 3 * nf

@@ -165,7 +165,7 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
     of the reference batches over ranks, one all-reduce of the three metric accumulators and the
     summary from rank 0.  The per-batch "metrics" are counts of the synthetic labels themselves.
 
-    in_flight (default IISEG_IN_FLIGHT, else 2 -- 3 for batches of 32 images and fewer): whole batches being worked on at a time on this GPU, each by
+    in_flight (default IISEG_IN_FLIGHT, else 2 -- 3 for batches of 32 images and fewer, 4 for 16 and fewer): whole batches being worked on at a time on this GPU, each by
     its own engine (own nets, sessions, graphs) on its own HIP stream; per-batch outputs and the running
     totals are the same and come in the same order, one batch later."""
     # Update DAE parameters (:64-79)
@@ -206,8 +206,8 @@ def inference(dataset, segm_net, learn_step=0.005, num_iter=500, dae_dict_update
         return _dry_run(dataset, which_set, synthetic, n_images, image_size, batch_size,
                         test_from_0_255, rank, world, device, say)
     if in_flight is None:
-        # batches of 32 images and fewer leave more of the chip idle per launch: one more in flight
-        in_flight = int(os.environ.get('IISEG_IN_FLIGHT', '2' if batch_size > 32 else '3'))
+        # batches of 32 images and fewer leave more of the chip idle per launch: one more in flight, two more for 16 and fewer
+        in_flight = int(os.environ.get('IISEG_IN_FLIGHT', '2' if batch_size > 32 else '3' if batch_size > 16 else '4'))
     in_flight = max(1, int(in_flight)) if device.type == 'cuda' else 1
     engines = []
     for k in range(in_flight):
@@ -372,7 +372,7 @@ def main():
                         help='CPU rehearsal of the multi-rank protocol (gloo), no HIP work')
     parser.add_argument('--in_flight', type=int, default=None,
                         help='whole batches worked on at a time on each GPU (engines / HIP streams; default '
-                             'IISEG_IN_FLIGHT, else 2, 3 for batches <= 32; 1 = one batch after the other)')
+                             'IISEG_IN_FLIGHT, else 2, 3 for batches <= 32, 4 for <= 16; 1 = one batch after the other)')
     parser.add_argument('--update', choices=['residual', 'gradient'], default='residual',
                         help="'residual': the reference's y += step*(r - y) (default); 'gradient': "
                              "descend the true gradient of ||r(y|h) - y||^2 (extension)")

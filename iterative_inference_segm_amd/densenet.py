@@ -30,6 +30,10 @@ C8_1X1 = os.environ.get('IISEG_DENSENET_C8_1X1', '1') != '0'
 # bn_fold / bn_stats_c8 launches)
 M16_FUSE_BN = os.environ.get('IISEG_M16_FUSE_BN', '1') != '0'
 
+# mma='bf16c8': the forward of one input geometry replayed from a captured HIP graph from its third call on (0: its
+# ~430 launches issued from Python every time -- 7-9 ms of host time per forward against 6.5 ms of kernels)
+FWD_GRAPH = os.environ.get('IISEG_DENSENET_GRAPH', '1') != '0'
+
 GROWTH = 16
 N_POOL = 5
 LAYERS_PER_BLOCK = [4, 5, 7, 10, 12, 15, 12, 10, 7, 5, 4]      # FCDenseNet.py:208
@@ -162,6 +166,7 @@ class FCDenseNet:
         self.n_classes, self.device, self.dtype = n_classes, device, dtype
         dev = lambda a: torch.as_tensor(a).to(dtype).contiguous().to(device)
         self._c8_levels = {}          # mma='bf16c8': the forward's buffers per input geometry (_levels_c8)
+        self._c8_graphs = {}          # ... and its captured launch sequence (_forward_c8_graph)
         self.layers = []
         for p in params:
             e = {'kind': p['kind']}
@@ -344,8 +349,42 @@ class FCDenseNet:
         probs = ops.crop_softmax(score, H, W, off=(0, 0))
         return hidden + [probs]
 
+    def _forward_c8_graph(self, x):
+        """The C8 forward from a captured HIP graph.  Everything in it is static per input geometry: the level
+        buffers (`_levels_c8`), the launch sequence (the Python-side BatchNorm-fold bookkeeping starts from the
+        same state every forward) and, under one engine's workspace tag, the scratch the launches point into.
+        First call of a geometry: eager (weights get packed, scratch comes into being); second: capture; then one
+        copy of x into the graph's input + one replay.  Same kernels in the same order: same bits.  The results
+        are handed out as copies -- a later forward does not overwrite what an earlier one returned."""
+        dev = x.device
+        key = (tuple(x.shape), ops._WS_TAG[0])
+        ctx = self._c8_graphs.get(key)
+        if ctx is None:
+            while len(self._c8_graphs) >= 2:
+                self._c8_graphs.pop(next(iter(self._c8_graphs)))
+            self._c8_graphs[key] = {'graph': None}
+            return self._forward_c8(x)
+        self._c8_graphs[key] = self._c8_graphs.pop(key)          # most recently used last
+        if ctx['graph'] is not None and ctx['ws'] != ops.workspace_ptrs(dev):
+            ctx['graph'] = None          # (scratch regrown elsewhere since the capture)
+        if ctx['graph'] is None:
+            xs = x.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self._forward_c8(xs)
+            B, _, H, W = x.shape
+            ctx.update(graph=g, x=xs, outs=outs, ws=ops.workspace_ptrs(dev),
+                       keep=(ops.workspace_refs(dev), self._c8_levels.get((B, H, W))))
+        else:
+            ctx['x'].copy_(x)
+        ctx['graph'].replay()
+        return [o.clone() for o in ctx['outs']]
+
     def forward(self, x):
         if self.c8:
+            if FWD_GRAPH and x.is_cuda and ops.CONV_PROFILE is None and not torch.cuda.is_current_stream_capturing():
+                return self._forward_c8_graph(x)
             return self._forward_c8(x)
         B, _, H, W = x.shape
         g, dt, dev = self.growth, self.dtype, self.device

@@ -10,6 +10,8 @@ from iterative_inference_segm_amd import synthetic as S
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 cases = [('bf16c8', 64, 'pipe', (1, 2, 3)), ('bf16c8', 10, 'pipe', (1, 2, 3)), (None, 64, 'pipe', (1, 2, 3)),
          ('bf16c8', 64, 'split', (2,)), (None, 64, 'split', (2,))]
+if os.environ.get('PROBE') == 'small':
+    cases = [('bf16c8', 10, 'pipe', (1, 3, 4, 6)), ('bf16c8', 64, 'pipe', (1, 2))]
 for mode, B, kind, lanes in cases:
     Xs = [torch.from_numpy(S.make_images(B, 224, 224, seed=1234 + 1000 * i)).cuda() for i in range(3)]
     Ts = [torch.from_numpy(S.make_labels(B, 224, 224, seed=99 + 1000 * i)).cuda() for i in range(3)]
@@ -37,8 +39,10 @@ for mode, B, kind, lanes in cases:
         t = time.perf_counter()
         for i in range(steps):
             stepn(i)
+        tq = time.perf_counter() - t
         torch.cuda.synchronize()
         d = time.perf_counter() - t
-        print('%-7s batch %3d %-5s lanes %d: %8.1f images/s  %.2f ms/batch' % (mode or 'fp32', B, kind, n, B * steps / d, d / steps * 1e3), flush=True)
+        print('%-7s batch %3d %-5s lanes %d: %8.1f images/s  %.2f ms/batch (host queued a batch in %.2f ms)'
+              % (mode or 'fp32', B, kind, n, B * steps / d, d / steps * 1e3, tq / steps * 1e3), flush=True)
         del engines, streams
         torch.cuda.empty_cache()

@@ -504,3 +504,31 @@ def test_densenet_c8_small_against_float64(built_lib):
         assert e <= 3e-2, name
     agree = float((host(o8[-1]).argmax(1) == host(o64[-1]).argmax(1)).mean())
     assert agree >= 0.97
+
+
+def test_densenet_c8_forward_from_a_captured_graph_is_bit_identical(built_lib, monkeypatch):
+    """FCDenseNet(mma='bf16c8') replays the forward of an input geometry from a captured HIP graph from its third
+    call on (densenet.FWD_GRAPH): every call -- eager first, capture + replay second, replays after, a second
+    geometry in between, the first one again -- returns the bits of the eager launches, and what an earlier call
+    returned is not touched by a later one."""
+    from iterative_inference_segm_amd import densenet as D, synthetic as S
+    nl = [2, 2, 2, 2, 2]
+    params = S.make_densenet_params(D.layer_plan(n_layers_per_block=nl, n_pool=2), seed=11)
+
+    def net():
+        return D.FCDenseNet(params, 11, layer=['input', 'pool1', 'pool2'], n_layers_per_block=nl, n_pool=2, mma='bf16c8')
+    shapes = [(4, 36, 44), (4, 36, 44), (4, 36, 44), (2, 52, 40), (4, 36, 44), (2, 52, 40), (2, 52, 40), (4, 36, 44)]
+    Xs = [torch.from_numpy(S.make_images(b, h, w, seed=20 + i)).cuda() for i, (b, h, w) in enumerate(shapes)]
+    monkeypatch.setattr(D, 'FWD_GRAPH', False)
+    eager = net()
+    want = [[t.clone() for t in eager(X)] for X in Xs]
+    assert not eager._c8_graphs
+    monkeypatch.setattr(D, 'FWD_GRAPH', True)
+    n = net()
+    got = [n(X) for X in Xs]
+    torch.cuda.synchronize()
+    assert len(n._c8_graphs) == 2 and all(c['graph'] is not None for c in n._c8_graphs.values())
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert len(g) == len(w) == 4
+        for a, b in zip(g, w):
+            assert torch.equal(a, b), k
