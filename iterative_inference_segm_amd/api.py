@@ -307,6 +307,10 @@ class IterativeInference:
                 [self.provenance_of(a) if isinstance(a, torch.Tensor) else None for a in H_in]
             persistent = bool(tags) and all(t is not None for t in tags) and \
                 getattr(self.dae, 'licm', False) and getattr(self.dae, 'fold_border', False)
+            # ... or one whose buffers stay the same from batch to batch without any record (the C8 DAE hands
+            # out buffer-stable sessions: StandardDAE.new_session)
+            persistent = persistent or (getattr(self.dae, 'stable_sessions', False) and
+                                        getattr(self.dae, 'licm', False))
             if want_graph == '1' or persistent or int(num_iter) >= 16:
                 return self._refine_graph(H_in, Y, step, int(num_iter), eps if early_stop else -1.0,
                                           tags, first_reconstruction)

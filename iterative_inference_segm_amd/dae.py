@@ -166,6 +166,7 @@ class StandardDAE:
         # keep the weights-only border of the encoder maps across batches (see new_session)
         self.fold_border = os.environ.get('IISEG_DAE_BORDER_FOLD', '1') != '0'
         self._store = None
+        self._scratch_sessions = {}   # C8, no provenance records: buffer-stable sessions per geometry (new_session)
         self.trace = None   # set to a dict to keep intermediates (debug / parity tests)
         # DePool2D masks as bytes: where the encoder conv that pools and the decoder conv that
         # unpools both run on halo kernels, the pre-pool map is never stored -- the encoder writes
@@ -213,7 +214,29 @@ class StandardDAE:
                 return st
             self._store = {'primed': False, 'key': key}
             return self._store
+        if self.c8 and y is not None and h_list is not None and \
+                all(isinstance(h, torch.Tensor) for h in h_list):
+            # No records, C8 path: nothing of the previous batch may be REUSED, but its buffers can be written
+            # again -- the session of this geometry is handed out unprimed (the first step computes every map in
+            # full, into the same tensors), so a refinement step captured as a HIP graph on it stays valid for
+            # the next batch (api._refine_graph; e.g. the FC-DenseNet host, whose h carries no record).
+            key = (tuple(tuple(h.shape) for h in h_list), tuple(y.shape), y.dtype)
+            st = self._scratch_sessions.get(key)
+            if st is None:
+                while len(self._scratch_sessions) >= 2:
+                    self._scratch_sessions.pop(next(iter(self._scratch_sessions)))
+                st = self._scratch_sessions[key] = {'stable': True}
+            else:
+                self._scratch_sessions[key] = self._scratch_sessions.pop(key)
+            st.update(primed=False, h_stale=True, y8_fresh=False, h_fresh=False)
+            return st
         return {'primed': False}
+
+    @property
+    def stable_sessions(self):
+        """Sessions without provenance records keep their buffers from batch to batch (C8 path): a captured
+        refinement step stays valid, so api.refine replays it for short loops too."""
+        return bool(self.c8)
 
     def conv_layers(self):
         d = dict(self.enc)
@@ -503,8 +526,11 @@ class StandardDAE:
             if primed and session.get('masked') != 'c8':
                 primed = False
             session['masked'] = 'c8'
-            if not primed:
-                session['gen'] = session.get('gen', 0) + 1
+        # (`gen` tells a captured graph that buffers were allocated anew; a buffer-stable session -- new_session
+        # without records -- writes the tensors it already has)
+        stable = session is not None and session.get('stable', False)
+        realloc = session is not None and not primed and not stable
+        h_stale = stable and session.get('h_stale', False)
         # y as a C8 tensor: converted here, unless the refinement step that produced y has already
         # written it (`c8_feed`: api passes the session's buffer to ops.refine_update)
         if session is not None and session.get('y8_fresh') and session.get('y8') is not None and \
@@ -546,8 +572,18 @@ class StandardDAE:
                 kw['window'] = conv.pool_window(t.shape[2], t.shape[3], dep)
                 pooled_t, m = session['pool%d' % (p + 1)], session['mask%d' % (p + 1)]
             else:
-                pooled_t = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev, x3=self.x3)
-                m = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev, dtype=torch.uint8)
+                pooled_t = m = None
+                if stable:
+                    pooled_t, m = session.get('pool%d' % (p + 1)), session.get('mask%d' % (p + 1))
+                    nch = ops.c8_chunks(conv.Cout)
+                    if pooled_t is None or m is None or \
+                            tuple(pooled_t.shape) != (B, nch * (2 if self.x3 else 1), fh // 2, fw // 2, 8) or \
+                            tuple(m.shape) != (B, nch, fh // 2, fw // 2, 8):
+                        pooled_t = m = None
+                if pooled_t is None:
+                    pooled_t = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev, x3=self.x3)
+                    m = ops.empty_c8(B, conv.Cout, fh // 2, fw // 2, dev, dtype=torch.uint8)
+                    realloc = realloc or stable
             kw.update(pool_out=pooled_t, mask_out=m, store_out=False)
             if pending_h is not None and name in self.hsplit:
                 conv_h, conv_y = self.hsplit[name]
@@ -557,6 +593,10 @@ class StandardDAE:
                     hb = conv_h(ops.nchw_to_c8(pending_h, x3=self.x3), out_format='c8f32')
                     if keep:
                         session['hb_' + name] = hb
+                    realloc = realloc or stable
+                elif h_stale:                            # buffer-stable session, new batch: all of it again
+                    conv_h(ops.nchw_to_c8(pending_h, x3=self.x3), window=(0, 0, hb.shape[2], hb.shape[3]),
+                           out=hb, place=(0, 0), out_format='c8f32')
                 elif h_fresh:                            # reused session: only where h changed
                     hd = session['h_dep'][pos - 1]
                     hy0, hh = clip(hd[0] + conv_h.pad - 2, hd[0] + hd[2] + conv_h.pad, hb.shape[2])
@@ -592,6 +632,9 @@ class StandardDAE:
         if session is not None:
             session['primed'] = True
             session['h_fresh'] = False
+            session['h_stale'] = False
+            if realloc:
+                session['gen'] = session.get('gen', 0) + 1
         if pending_h is not None:
             raise NotImplementedError('h concatenated at the last pool feeds DePool2D directly '
                                       '(additional_pool=0); not shape-consistent in the reference')

@@ -411,3 +411,36 @@ def test_engine_pool_other_families_bit_identical(built_lib, family):
     for k, (g, w) in enumerate(zip(got, want)):
         for a, b in zip(g, w):
             assert torch.equal(a, b), (family, k)
+
+
+def test_c8_dae_without_records_replays_one_captured_step_across_batches(built_lib):
+    """An h without a provenance record (the FC-DenseNet host; any h the caller made himself): the C8 DAE hands out
+    the SAME session buffers unprimed for every batch of a geometry (StandardDAE.new_session), so the refinement
+    step captured on the first batch is replayed for the next ones -- and every batch's result is the eager
+    loop's, bit for bit (nothing of a previous batch survives: different h and y each time, one batch repeated)."""
+    from iterative_inference_segm_amd.dae import StandardDAE
+    from iterative_inference_segm_amd.densenet import FCDenseNet, layer_plan
+    nl = [2, 3, 2, 2, 2, 2, 2, 2, 2, 3, 2]
+    dparams = S.make_densenet_params(layer_plan(n_layers_per_block=nl, n_first=16, growth=16), seed=7)
+    dp = S.make_dae_params(h_channels=(16 + 16 * (2 + 3 + 2 + 2),), n_filters=16, seed=9)
+
+    def engine():
+        net = FCDenseNet(dparams, 11, layer=['pool4'], n_layers_per_block=nl, growth=16, mma='bf16c8')
+        return _ii(net, StandardDAE(dp, 11, n_filters=16, padding=0, mma='bf16c8'), F32)
+    Xs = [torch.from_numpy(S.make_images(3, 64, 96, seed=80 + i)).cuda() for i in (0, 1, 2, 1, 3)]
+    outs = {}
+    for graph in (False, None):
+        ii = engine()
+        res = []
+        for X in Xs:
+            o = ii.pred_fcn_fn(X)
+            res.append([t.clone() for t in ii.refine(o[:-1], o[-1], 0.1, 6, early_stop=False, graph=graph)[:3]])
+        outs[graph] = res
+        if graph is None:
+            assert len(ii._graphs) == 1
+            ctx = next(iter(ii._graphs.values()))
+            assert ctx['graph'] is not None and len(ii.dae._scratch_sessions) == 1
+    for k, (a, b) in enumerate(zip(outs[False], outs[None])):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), k
+    assert torch.equal(outs[None][1][0], outs[None][3][0])      # the repeated batch: same result both times
