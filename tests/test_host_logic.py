@@ -293,3 +293,30 @@ def test_engine_pool_needs_an_engine_and_one_engine_is_the_plain_path():
             assert got is e
     pool.join()
     pool.synchronize()
+
+
+def test_bench_line_is_short_and_ends_with_the_16_bit_leg():
+    """bench.compact_line on the detail record of a real run (profiles/r05_bench_n1_detail.json): the ONE line rank
+    0 prints carries the contract's keys first, stays under 5 KB, and ends with strict_f64, cpu_baseline and the
+    bf16 leg -- its roofline fraction, the fraction over every 3x3 launch, the batches in flight and the value
+    with one batch in flight -- where a truncated log tail keeps them."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    detail = json.load(open(os.path.join(root, 'profiles', 'r05_bench_n1_detail.json')))
+    out = bench.compact_line(detail, 'gpurun_out/bench_detail.json')
+    text = json.dumps(out)
+    assert len(text) < 5000
+    keys = list(out)
+    assert keys[:13] == ['metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                         'scaling', 'vs_baseline', 'dtype', 'data', 'config']
+    assert keys[-3:] == ['strict_f64', 'cpu_baseline', 'bf16']
+    assert out['value'] == detail['value'] and out['in_flight'] == detail['in_flight']['engines']
+    assert out['one_in_flight'] == detail['in_flight']['one_in_flight']['value']
+    b = out['bf16']
+    assert b['in_flight'] == 2 and b['one_in_flight'] and 0.3 < b['roofline']['frac'] < 0.6
+    assert 0.3 < b['roofline']['all_3x3_frac'] <= b['roofline']['frac']
+    assert out['roofline']['bound'] == 'mfma' and out['cpu_baseline']['kind'] == 'port'
+    tail = text[-1200:]
+    assert '"all_3x3_frac"' in tail and '"one_in_flight"' in tail
