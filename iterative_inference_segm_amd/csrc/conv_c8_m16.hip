@@ -17,7 +17,9 @@
 //     (0.154 vs 0.132 ms on the class-score layer: 190-210 registers, two workgroups per CU instead of
 //     three); with DePool2D staged by pooled positions a set is 12 registers and the two-ahead form is what
 //     runs (140 registers, still three workgroups; 0.1250 -> 0.1220 ms over three alternating repeats: the
-//     layer issues 1140 vector instructions per 160 MFMAs and wave, that is what bounds it);
+//     layer issues 1140 vector instructions per 160 MFMAs and wave, that is what bounds it), and for the
+//     BatchNorm + ReLU mode as well (24 registers per set, 163-167 in all: FC-DenseNet103 forward 6.63 -> 6.46 ms
+//     of kernels over three alternating repeats);
 //   * input staging per 8-channel half (the half is a compile-time constant of a piece): LDS-DMA, or
 //     through registers for DePool2D (up chunk + 8 mask bytes, layers/mylayers.py:88-115) and for
 //     BatchNorm + ReLU applied on the way in (per-channel scale / shift read as scalars; the padding
@@ -241,81 +243,82 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
                 if (piece[i]) dma16(s_x1, lds_p + (unsigned)((buf * 2 + h) * HCAP + i * 256) * 16u, voff[i], so);
         }
     };
-    // register staging (UNPOOL / BNRELU): loads here, transformed and written to LDS after the MFMAs
-    u32x4 xu[2][NPC];
-    u32x2 xm[MODE == M16_UNPOOL ? 2 : 1][NPC];
-    auto load_x = [&](int kc) __attribute__((always_inline)) {
+    // Register staging (UNPOOL / BNRELU): loaded here, transformed and written to LDS after the MFMAs.  TWO k-tiles
+    // are kept in registers (DePool2D: one `up` chunk + 8 mask bytes per thread and half = 12 registers per set;
+    // BatchNorm + ReLU: up to three chunks per half = 24): the loads of k-tile kt + 2 are issued at the top of step
+    // kt, so when step kt + 1 expands them into the LDS they are a whole step old -- the workgroup-wide wait in
+    // front of the barrier has already covered them and there is no wait between the MFMAs and the LDS writes.
+    // (Round 4 measured the same idea slower with DePool2D staged per patch element: 48 registers per set, a
+    // workgroup less per CU.  Now 140-144 registers, still three workgroups.)
+    constexpr int NRP = MODE == M16_UNPOOL ? 1 : NPC;
+    u32x4 xu[2][2][NRP];
+    u32x2 xm[2][2];
+    auto load_x = [&](auto SET, int kc) __attribute__((always_inline)) {
+        constexpr int s = decltype(SET)::value;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int so = (int)((unsigned)((kc + h) * plane) * 16u);
             if constexpr (MODE == M16_UNPOOL) {
-                xu[h][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)qoff, so, 0));
-                xm[h][0] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_m, (int)qoffm, so >> 1, 0));
-                continue;
-            }
+                xu[s][h][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)qoff, so, 0));
+                xm[s][h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_m, (int)qoffm, so >> 1, 0));
+            } else {
 #pragma unroll
-            for (int i = 0; i < NPC; ++i) {
-                if (!piece[i]) continue;
-                xu[h][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)voff[i], so, 0));
+                for (int i = 0; i < NRP; ++i) {
+                    if (!piece[i]) continue;
+                    xu[s][h][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)voff[i], so, 0));
+                }
             }
         }
     };
-    auto store_x = [&](int kc, int buf) __attribute__((always_inline)) {
+    auto store_x = [&](auto SET, int kc, int buf) __attribute__((always_inline)) {
+        constexpr int s = decltype(SET)::value;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float sa[8], sb[8];
-            if constexpr (MODE == M16_BNRELU) {
+            if constexpr (MODE == M16_UNPOOL) {
+                // the four pixels of the thread's pooling window: bit sl of byte j of the mask pair says
+                // pre == pooled for channel j there (layers/mylayers.py:111-114)
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const unsigned t0 = (xm[s][h][0] >> sl) & 0x01010101u;
+                    const unsigned t1 = (xm[s][h][1] >> sl) & 0x01010101u;
+                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
+                    uint4 v;
+                    v.x = xu[s][h][0][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
+                    v.y = xu[s][h][0][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
+                    v.z = xu[s][h][0][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
+                    v.w = xu[s][h][0][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
+                    if (qlds[sl] >= 0) Ps[buf][h][qlds[sl]] = v;
+                }
+            } else {
                 // the 8 channels of this half: wave-uniform addresses, read through the CONSTANT address space so
                 // that they ARE scalar loads (s_load_dwordx8, lgkmcnt): through the generic pointers hipcc made them
                 // four global_load_dwordx4 with a full vmcnt wait in front of the LDS writes of every k-tile (the
                 // (a, b) table is written by an earlier kernel, never here).  FC-DenseNet103 forward 7.78 -> 7.32 ms;
                 // issued earlier still (with the activation loads, live across the MFMAs) they spill scalar
                 // registers: 7.32-7.62 ms
+                float sa[8], sb[8];
                 typedef const float __attribute__((address_space(4))) cfloat;
                 const int c0 = __builtin_amdgcn_readfirstlane((kc + h) * 8);
                 cfloat* ca = (cfloat*)(uintptr_t)p.bn_a;
                 cfloat* cb = (cfloat*)(uintptr_t)p.bn_b;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { sa[q] = ca[c0 + q]; sb[q] = cb[c0 + q]; }
-            }
-            if constexpr (MODE == M16_UNPOOL) {
-                // the four pixels of the thread's pooling window: bit sl of byte j of the mask pair says
-                // pre == pooled for channel j there (layers/mylayers.py:111-114)
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const unsigned t0 = (xm[h][0][0] >> sl) & 0x01010101u;
-                    const unsigned t1 = (xm[h][0][1] >> sl) & 0x01010101u;
-                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
-                    uint4 v;
-                    v.x = xu[h][0][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
-                    v.y = xu[h][0][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
-                    v.z = xu[h][0][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
-                    v.w = xu[h][0][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
-                    if (qlds[sl] >= 0) Ps[buf][h][qlds[sl]] = v;
-                }
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < NPC; ++i) {
-                if (!piece[i]) continue;
-                uint4 v;
-                if constexpr (MODE == M16_UNPOOL) {
-                    v = make_uint4(0u, 0u, 0u, 0u);      // (not reached: staged by pooled positions above)
-                } else {
+                for (int i = 0; i < NRP; ++i) {
+                    if (!piece[i]) continue;
                     // BatchNorm + ReLU of the stored bf16 values, rounded to bf16 once more; chunks of
                     // the zero-padding ring (out-of-range offset: the load returned zeros) stay zero
                     const bool inside = voff[i] != OOB;
                     unsigned w[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const unsigned u = xu[h][i][q];
+                        const unsigned u = xu[s][h][i][q];
                         const float lo = fmaxf(__builtin_fmaf(bf_lo(u), sa[2 * q], sb[2 * q]), 0.f);
                         const float hi = fmaxf(__builtin_fmaf(bf_hi(u), sa[2 * q + 1], sb[2 * q + 1]), 0.f);
                         w[q] = inside ? pack_bf16(lo, hi) : 0u;
                     }
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                    if (i * 256 + tid < half) Ps[buf][h][i * 256 + tid] = make_uint4(w[0], w[1], w[2], w[3]);
                 }
-                if (i * 256 + tid < half) Ps[buf][h][i * 256 + tid] = v;
             }
         }
     };
@@ -338,60 +341,26 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
                                                                    __builtin_bit_cast(bf16x8, b[k]), acc[k], 0, 0, 0);
         }
     };
-    if constexpr (MODE == M16_UNPOOL) {
-        // DePool2D: one `up` chunk + 8 mask bytes per thread and half = 12 registers per k-tile, so TWO k-tiles
-        // are kept in registers and the loads of k-tile kt + 2 are issued at the top of step kt: when step kt + 1
-        // expands them into the LDS they are a whole step old (the workgroup-wide wait in front of the barrier
-        // has already covered them) and the wait between the MFMAs and the LDS writes is gone.  (Round 4 measured
-        // the same idea slower with the per-element staging: 48 registers per set, a workgroup less per CU.)
-        u32x4 qu[2][2];
-        u32x2 qk[2][2];
-        auto load_q = [&](auto SET, int kc) __attribute__((always_inline)) {
-            constexpr int s = decltype(SET)::value;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int so = (int)((unsigned)((kc + h) * plane) * 16u);
-                qu[s][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x1, (int)qoff, so, 0));
-                qk[s][h] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r_m, (int)qoffm, so >> 1, 0));
-            }
-        };
-        auto store_q = [&](auto SET, int buf) __attribute__((always_inline)) {
-            constexpr int s = decltype(SET)::value;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // the four pixels of the thread's pooling window: bit sl of byte j of the mask pair says
-                // pre == pooled for channel j there (layers/mylayers.py:111-114)
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const unsigned t0 = (qk[s][h][0] >> sl) & 0x01010101u;
-                    const unsigned t1 = (qk[s][h][1] >> sl) & 0x01010101u;
-                    const unsigned b0 = (t0 << 8) - t0, b1 = (t1 << 8) - t1;
-                    uint4 v;
-                    v.x = qu[s][h][0] & __builtin_amdgcn_perm(b0, b0, 0x01010000u);
-                    v.y = qu[s][h][1] & __builtin_amdgcn_perm(b0, b0, 0x03030202u);
-                    v.z = qu[s][h][2] & __builtin_amdgcn_perm(b1, b1, 0x01010000u);
-                    v.w = qu[s][h][3] & __builtin_amdgcn_perm(b1, b1, 0x03030202u);
-                    if (qlds[sl] >= 0) Ps[buf][h][qlds[sl]] = v;
-                }
-            }
-        };
+    if constexpr (MODE != M16_PLAIN) {
         typedef std::integral_constant<int, 0> S0;
         typedef std::integral_constant<int, 1> S1;
         if (p.phase != 2 && kt0 < kt1) {
-            load_q(S0{}, 2 * kt0);
+            load_x(S0{}, 2 * kt0);
             dma_w(kt0, 0);
-            if (kt0 + 1 < kt1) load_q(S1{}, 2 * (kt0 + 1));
+            if (kt0 + 1 < kt1) load_x(S1{}, 2 * (kt0 + 1));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            store_q(S0{}, 0);
+            store_x(S0{}, 2 * kt0, 0);
         }
-        // step kt: k-tile kt is in LDS buffer `buf`, k-tile kt + 1 in register set SET ^ 1 (loaded or in flight)
+        // step kt: k-tile kt is in LDS buffer SET, k-tile kt + 1 in register set SET ^ 1 (loaded or in flight)
         auto step = [&](auto SET, int kt) __attribute__((always_inline)) {
             constexpr int s = decltype(SET)::value;
+            // own DMA pieces, register loads and LDS writes retired, then the barrier publishes them and tells that
+            // every wave is done reading what the previous step read
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt + 1 < kt1) dma_w(kt + 1, s ^ 1);
-            if (kt + 2 < kt1) load_q(SET, 2 * (kt + 2));
+            if (kt + 2 < kt1) load_x(SET, 2 * (kt + 2));
             mfma_tile(s);
-            if (kt + 1 < kt1) store_q(std::integral_constant<int, s ^ 1>{}, s ^ 1);
+            if (kt + 1 < kt1) store_x(std::integral_constant<int, s ^ 1>{}, 2 * (kt + 1), s ^ 1);
         };
         for (int kt = kt0; kt < kt1; kt += 2) {
             step(S0{}, kt);
@@ -399,33 +368,19 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
         }
     } else {
         if (p.phase != 2) {
-            if constexpr (MODE == M16_PLAIN) {
-                dma_x(2 * kt0, 0);
-                dma_w(kt0, 0);
-            } else {
-                load_x(2 * kt0);
-                dma_w(kt0, 0);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                store_x(2 * kt0, 0);
-            }
+            dma_x(2 * kt0, 0);
+            dma_w(kt0, 0);
         }
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
-            const bool more = kt + 1 < kt1;
-            // own DMA pieces (and LDS writes) retired, then the barrier publishes them and tells that every
-            // wave is done reading what the previous step read
+            // own DMA pieces retired, then the barrier publishes them and tells that every wave is done reading
+            // what the previous step read
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (more) {
-                if constexpr (MODE == M16_PLAIN) dma_x(2 * (kt + 1), buf ^ 1); else load_x(2 * (kt + 1));
+            if (kt + 1 < kt1) {
+                dma_x(2 * (kt + 1), buf ^ 1);
                 dma_w(kt + 1, buf ^ 1);
             }
             mfma_tile(buf);
-            if constexpr (MODE != M16_PLAIN) {
-                if (more) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    store_x(2 * (kt + 1), buf ^ 1);
-                }
-            }
         }
     }
 
