@@ -303,6 +303,11 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
                 cfloat* cb = (cfloat*)(uintptr_t)p.bn_b;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { sa[q] = ca[c0 + q]; sb[q] = cb[c0 + q]; }
+                // (an FMA takes one scalar operand: the shifts go to vector registers ONCE per half -- left to
+                // itself hipcc re-materialises them with a v_mov in front of every FMA of every piece: 144 moves)
+                float vb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) asm volatile("v_mov_b32 %0, %1" : "=v"(vb[q]) : "s"(sb[q]));
 #pragma unroll
                 for (int i = 0; i < NRP; ++i) {
                     if (!piece[i]) continue;
@@ -313,8 +318,8 @@ __global__ __launch_bounds__(256, 3) void conv_c8_m16_kernel(const M16Params p) 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const unsigned u = xu[s][h][i][q];
-                        const float lo = fmaxf(__builtin_fmaf(bf_lo(u), sa[2 * q], sb[2 * q]), 0.f);
-                        const float hi = fmaxf(__builtin_fmaf(bf_hi(u), sa[2 * q + 1], sb[2 * q + 1]), 0.f);
+                        const float lo = fmaxf(__builtin_fmaf(bf_lo(u), sa[2 * q], vb[2 * q]), 0.f);
+                        const float hi = fmaxf(__builtin_fmaf(bf_hi(u), sa[2 * q + 1], vb[2 * q + 1]), 0.f);
                         w[q] = inside ? pack_bf16(lo, hi) : 0u;
                     }
                     if (i * 256 + tid < half) Ps[buf][h][i * 256 + tid] = make_uint4(w[0], w[1], w[2], w[3]);
